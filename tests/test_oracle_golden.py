@@ -1,0 +1,71 @@
+"""CPU: the oracle restatement against the reference-generated golden vectors
+(tests/golden/, made by tools/gen_golden.py from the upstream code)."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import (GOLDEN, galprior, load_loglike_case, loglike_golden_files,
+                     relerr)
+from oracle import brutus_oracle as O
+from brutus_amd import synth
+
+TOL = 1e-10  # observed ~1e-14 (libm vs numpy SIMD `pow` last-ulp differences)
+
+
+@pytest.mark.parametrize("path", loglike_golden_files(),
+                         ids=lambda p: os.path.basename(p)[8:-4])
+def test_loglike_matches_reference(path):
+    z, kw, par, perr = load_loglike_case(path)
+    tr = {}
+    out = O.loglike(z["flux"], z["err"], z["mask"], z["models"], parallax=par,
+                    parallax_err=perr, return_vals=True, trace=tr, **kw)
+    lnl, Ndim, chi2, scale, av, rv, icov = out
+    assert Ndim == int(z["Ndim"])
+    assert tr["K2"] == int(z["K2"])
+    assert len(tr["init_sel"]) == int(z["nsel"])
+    for name, got in (("lnl", lnl), ("chi2", chi2), ("scale", scale),
+                      ("av", av), ("rv", rv), ("icov", icov)):
+        assert relerr(z[name], got) < TOL, name
+
+
+def test_fit_star_matches_reference():
+    z = np.load(os.path.join(GOLDEN, "fit_synth.npz"))
+    models, labels, lmask = synth.make_grid(int(z["grid_nmodel"]),
+                                            int(z["grid_nfilt"]),
+                                            seed=int(z["grid_seed"]))
+    lnprior = O.static_lnprior(labels, lmask)
+    assert np.array_equal(lnprior, z["lnprior"])
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(z["flux"])):
+        rs = np.random.RandomState(int(z["seed0"]) + i)
+        out = O.fit_star(z["flux"][i], z["err"][i], z["mask"][i], models,
+                         lnprior, labels, z["coords"][i], z["parallax"][i],
+                         z["parallax_err"][i], rs, galprior, Nmc_prior=50,
+                         Ndraws=250)
+        assert np.array_equal(out[0], z["sidxs"][i]), "star %d indices" % i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-9, (i, n)
+
+
+def test_helpers_match_reference():
+    z = np.load(os.path.join(GOLDEN, "helpers.npz"))
+    assert relerr(z["inv3_out"], O.inverse3(z["inv3_in"])) < 1e-13
+    assert relerr(z["chi2_df5"], O.chisquare_logpdf(z["chi2_x"], 5)) < 1e-14
+    assert relerr(z["chi2_df9"], O.chisquare_logpdf(z["chi2_x"], 9)) < 1e-14
+    mvn = O.sample_multivariate_normal(z["mvn_mean"], z["mvn_cov"], 11,
+                                       np.random.RandomState(9))
+    assert relerr(z["mvn_out"], mvn) < 1e-13
+    assert relerr(z["imf_out"], O.imf_lnprior(z["imf_m"])) < 1e-14
+    s, e = z["sp_scales"], z["sp_serrs"]
+    assert relerr(z["sp_hi"], O.scale_parallax_lnprior(s, e, 1.0, 0.1)) < 1e-14
+    assert relerr(z["sp_lo"], O.scale_parallax_lnprior(s, e, 1.0, 0.3)) < 1e-14
+    assert relerr(z["sp_nan"], O.scale_parallax_lnprior(s, e, np.nan, 0.3)) == 0
+    assert relerr(z["pl_out"], O.parallax_lnprior(np.sqrt(s), 1.1, 0.2)) < 1e-14
+    assert relerr(z["pl_nan"], O.parallax_lnprior(np.sqrt(s), np.nan, 0.2)) == 0
+    assert relerr(z["p2s_hi"], np.array(O.parallax_to_scale(1.0, 0.1))) < 1e-15
+    assert relerr(z["p2s_lo"], np.array(O.parallax_to_scale(1.0, 0.3))) < 1e-15
+    mag, magerr = O.magnitude(z["mag_flux"], z["mag_ferr"])
+    assert relerr(z["mag_out"], mag) < 1e-15
+    assert relerr(z["magerr_out"], magerr) < 1e-15

@@ -1,0 +1,260 @@
+#!/usr/bin/env python
+"""Generate the golden vectors under tests/golden/ by running the UPSTREAM
+reference (imported from /root/reference under tools/ref_shim.py).
+
+Run in the build container only (the reference does not travel to the GPU
+box):   PYTHONDONTWRITEBYTECODE=1 python tools/gen_golden.py
+
+Every file holds inputs and the reference's outputs for those inputs -- data,
+no reference source.  The reference has no tests or golden vectors of its own
+(SURVEY.md section 4), so these are the pins for the CPU restatement in
+oracle/ and, through it, for the HIP path.
+
+Grid coefficients are float32 values promoted to float64 before they are
+handed to the reference: that reproduces numba's arithmetic (f64 on f32-rounded
+values), which the pure-Python shim would otherwise not (NEP 50).
+"""
+import os
+import sys
+
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+sys.path.insert(0, ROOT)
+sys.path.insert(0, HERE)
+
+import numpy as np  # noqa: E402
+
+import ref_shim  # noqa: E402
+from brutus_amd import synth  # noqa: E402
+
+F, U, P, C = ref_shim.import_reference()
+OUT = os.path.join(ROOT, "tests", "golden")
+
+
+def galprior(dists, coord, labels=None):
+    """Analytic stand-in for the Galactic prior hook (the reference default
+    needs astropy).  Same definition lives in tests/helpers.py."""
+    with np.errstate(all="ignore"):
+        lp = 2. * np.log(dists) - dists / 2. + 0.01 * np.cos(np.deg2rad(coord[1]))
+    if labels is not None:
+        lp = lp + 0.1 * labels['feh']
+    return lp
+
+
+def star_from_model(models, idx, av, rv, dist, frac_err, rng, noise=True):
+    c = models[idx].astype(np.float64)
+    sed = c[:, 0] + av * (c[:, 1] + rv * c[:, 2])
+    f = 10. ** (-0.4 * sed) / dist ** 2
+    e = frac_err * f
+    if noise:
+        f = f + rng.normal(size=f.shape) * e
+    return f, e
+
+
+def loglike_cases():
+    rng = np.random.RandomState(42)
+    cases = []
+
+    def add(name, nmodel, nfilt, gseed, av, rv, dist, ferr, par=None,
+            perr=None, mask_band=None, neg_band=None, **kw):
+        models, _, _ = synth.make_grid(nmodel, nfilt, seed=gseed)
+        idx = rng.randint(nmodel)
+        f, e = star_from_model(models, idx, av, rv, dist, ferr, rng)
+        m = np.ones(nfilt, dtype=bool)
+        if mask_band is not None:
+            m[mask_band] = False
+            f[mask_band] = np.nan  # masked bands may hold garbage
+        if neg_band is not None:
+            f[neg_band] = -0.3 * abs(f[neg_band])
+        cases.append(dict(name=name, models=models, flux=f, err=e, mask=m,
+                          parallax=par, parallax_err=perr, kw=kw))
+
+    add("hisnr_par_12", 2048, 12, 11, 1.2, 3.3, 1.0, 0.02, par=1.02, perr=0.05)
+    add("losnr_nopar_12", 2048, 12, 12, 0.7, 3.1, 2.0, 0.15,
+        par=np.nan, perr=np.nan)
+    add("masked_band_8", 512, 8, 13, 0.4, 3.4, 0.5, 0.03, par=2.1, perr=0.3,
+        mask_band=2)
+    add("neg_flux_8", 512, 8, 14, 2.0, 3.0, 3.0, 0.2, par=np.nan, perr=np.nan,
+        neg_band=0)
+    add("av_zero_clamp_6", 512, 6, 15, 0.0, 3.32, 1.5, 0.04, par=0.6, perr=0.2)
+    add("av_only_6", 512, 6, 16, 1.0, 3.32, 0.8, 0.03, par=np.nan,
+        perr=np.nan, rvlim=(3.32, 3.32))
+    add("no_dim_prior_8", 2048, 8, 17, 1.7, 3.5, 0.3, 0.05, par=3.5, perr=0.4,
+        dim_prior=False)
+    add("rv_hi_clamp_12", 512, 12, 18, 2.2, 7.9, 1.0, 0.02, par=np.nan,
+        perr=np.nan, rv_gauss=(3.32, 5.0))
+    add("rv_lo_clamp_12", 512, 12, 19, 2.2, 1.0, 1.0, 0.02, par=1.0, perr=0.1,
+        rv_gauss=(3.32, 5.0))
+    add("av_max_clamp_8", 512, 8, 20, 2.0, 3.3, 1.0, 0.03, par=np.nan,
+        perr=np.nan, avlim=(0., 1.))
+    add("av_prior_6", 512, 6, 21, 0.6, 3.3, 1.0, 0.05, par=1.0, perr=0.3,
+        av_gauss=(0.5, 0.2))
+    add("par_none_8", 512, 8, 22, 0.9, 3.3, 1.0, 0.05, par=None, perr=None)
+    add("tight_tol_8", 512, 8, 23, 1.4, 3.6, 1.2, 0.04, par=0.8, perr=0.1,
+        ltol=3e-3, ltol_subthresh=1e-2, init_thresh=5e-3)
+    return cases
+
+
+def run_loglike_case(c):
+    calls = {"flux": 0, "nsel": None}
+    orig = F._optimize_fit_flux
+
+    def wrapped(*a, **k):
+        calls["flux"] += 1
+        if calls["nsel"] is None:
+            calls["nsel"] = a[2].shape[0]
+        return orig(*a, **k)
+
+    F._optimize_fit_flux = wrapped
+    try:
+        out = F.loglike(c["flux"].copy(), c["err"].copy(), c["mask"].copy(),
+                        c["models"].astype(np.float64),
+                        parallax=c["parallax"], parallax_err=c["parallax_err"],
+                        return_vals=True, **c["kw"])
+    finally:
+        F._optimize_fit_flux = orig
+    lnl, Ndim, chi2, scale, av, rv, icov = out
+    return dict(lnl=lnl, Ndim=int(Ndim), chi2=chi2, scale=scale, av=av, rv=rv,
+                icov=icov, K2=calls["flux"], nsel=calls["nsel"])
+
+
+def gen_loglike():
+    for c in loglike_cases():
+        r = run_loglike_case(c)
+        kw = c["kw"]
+        np.savez_compressed(
+            os.path.join(OUT, "loglike_%s.npz" % c["name"]),
+            models=c["models"], flux=c["flux"], err=c["err"], mask=c["mask"],
+            parallax=np.array(np.nan if c["parallax"] is None else c["parallax"]),
+            parallax_err=np.array(np.nan if c["parallax_err"] is None
+                                  else c["parallax_err"]),
+            parallax_is_none=np.array(c["parallax"] is None),
+            kw_keys=np.array(sorted(kw.keys())),
+            kw_vals=np.array([np.atleast_1d(np.asarray(kw[k], dtype=float))
+                              .tolist() + [np.nan] * (2 - np.size(kw[k]))
+                              for k in sorted(kw.keys())]).reshape(-1, 2),
+            **r)
+        print("loglike", c["name"], "Ndim", r["Ndim"], "K2", r["K2"], "nsel",
+              r["nsel"])
+
+
+def gen_fit():
+    """Per-star `_fit` yields (reference fitting.py:1980-2065) with one
+    `RandomState(1000 + i)` per star, so results do not depend on star order."""
+    models, labels, lmask = synth.make_grid(4000, 8, seed=31)
+    st = synth.make_stars(models, 12, seed=7)
+    # a few hand-made edge cases
+    st['mask'][1, 3] = False
+    st['flux'][2, 5] = -abs(st['flux'][2, 5])
+    st['parallax'][3] = np.nan
+    st['parallax_err'][3] = np.nan
+    st['mask'][4, [0, 1, 2]] = False   # 5 of 8 bands
+    BF = F.BruteForce(models.astype(np.float64), labels, lmask)
+    sp = BF._setup(st['flux'].copy(), st['err'].copy(), st['mask'].copy(),
+                   None, data_coords=st['coords'], lngalprior=galprior,
+                   parallax=st['parallax'], parallax_err=st['parallax_err'])
+    lnprior = sp[5]
+    mask_after_setup = np.array(sp[2])
+    res = {}
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(st['flux'])):
+        sl = slice(i, i + 1)
+        gen = BF._fit(st['flux'][sl].copy(), st['err'][sl].copy(),
+                      st['mask'][sl].copy(), parallax=st['parallax'][sl],
+                      parallax_err=st['parallax_err'][sl], Nmc_prior=50,
+                      lnprior=lnprior.copy(), lngalprior=galprior,
+                      data_coords=st['coords'][sl],
+                      rstate=np.random.RandomState(1000 + i), Ndraws=250)
+        r = next(gen)
+        for n, v in zip(names, r):
+            res.setdefault(n, []).append(np.asarray(v))
+        print("fit star", i, "Ndim", r[5], "levid", r[7], "chi2min", r[8])
+    np.savez_compressed(
+        os.path.join(OUT, "fit_synth.npz"), grid_nmodel=4000, grid_nfilt=8,
+        grid_seed=31, flux=st['flux'], err=st['err'], mask=st['mask'],
+        mask_after_setup=mask_after_setup, parallax=st['parallax'],
+        parallax_err=st['parallax_err'], coords=st['coords'], lnprior=lnprior,
+        seed0=1000, **{k: np.array(v) for k, v in res.items()})
+
+
+def gen_helpers():
+    rng = np.random.RandomState(5)
+    A = rng.normal(size=(64, 3, 3))
+    A = np.einsum('nij,nkj->nik', A, A) + 0.1 * np.eye(3)
+    x = np.concatenate([[-1., 0.], rng.uniform(0.01, 400., 62)])
+    mean = rng.normal(size=(7, 3))
+    cov = A[:7]
+    mvn = U.sample_multivariate_normal(mean, cov, size=11,
+                                       rstate=np.random.RandomState(9))
+    mgrid = np.array([0.05, 0.08, 0.0800001, 0.3, 0.5, 0.5000001, 1.0, 3.0])
+    scales = rng.uniform(0.1, 4., 50)
+    serrs = rng.uniform(0.01, 0.5, 50)
+    flux = rng.uniform(-1e-9, 1e-8, size=(5, 6))
+    ferr = rng.uniform(1e-11, 1e-9, size=(5, 6))
+    with np.errstate(all="ignore"):
+        mag, magerr = U.magnitude(flux, ferr)
+    np.savez_compressed(
+        os.path.join(OUT, "helpers.npz"),
+        inv3_in=A, inv3_out=U._inverse3(A),
+        chi2_x=x, chi2_df5=U._chisquare_logpdf(x.copy(), 5),
+        chi2_df9=U._chisquare_logpdf(x.copy(), 9),
+        mvn_mean=mean, mvn_cov=cov, mvn_out=mvn,
+        imf_m=mgrid, imf_out=P.imf_lnprior(mgrid),
+        sp_scales=scales, sp_serrs=serrs,
+        sp_hi=P.scale_parallax_lnprior(scales, serrs, 1.0, 0.1),
+        sp_lo=P.scale_parallax_lnprior(scales, serrs, 1.0, 0.3),
+        sp_nan=P.scale_parallax_lnprior(scales, serrs, np.nan, 0.3),
+        pl_out=P.parallax_lnprior(np.sqrt(scales), 1.1, 0.2),
+        pl_nan=P.parallax_lnprior(np.sqrt(scales), np.nan, 0.2),
+        p2s_hi=np.array(P.parallax_to_scale(1.0, 0.1)),
+        p2s_lo=np.array(P.parallax_to_scale(1.0, 0.3)),
+        mag_flux=flux, mag_ferr=ferr, mag_out=mag, magerr_out=magerr)
+    print("helpers done")
+
+
+def gen_setup():
+    """`BruteForce._setup` (reference fitting.py:1144-1424): band masking by
+    mag/magerr limits, photometric offsets, static prior, error for <4 bands."""
+    models, labels, lmask = synth.make_grid(2048, 6, seed=41)
+    st = synth.make_stars(models, 8, seed=11)
+    flux, err, mask = st['flux'].copy(), st['err'].copy(), st['mask'].copy()
+    flux[0, 1] = 10. ** (-0.4 * 51.)        # mag > mag_max
+    err[1, 2] = 0.5 * flux[1, 2]            # magerr > merr_max
+    flux[2, 3] = np.nan                     # non-finite flux
+    err[3, 4] = 0.                          # non-positive error
+    offs = np.array([1.0, 1.02, 0.97, 1.0, 1.05, 0.99])
+    BF = F.BruteForce(models.astype(np.float64), labels, lmask)
+    out = BF._setup(flux.copy(), err.copy(), mask.copy(), None,
+                    phot_offsets=offs, data_coords=st['coords'],
+                    lngalprior=galprior, parallax=st['parallax'],
+                    parallax_err=st['parallax_err'])
+    bad_mask = mask.copy()
+    bad_mask[5, :3] = False                 # 3 valid bands -> ValueError
+    try:
+        BF._setup(flux.copy(), err.copy(), bad_mask, None,
+                  data_coords=st['coords'], lngalprior=galprior)
+        raised = False
+    except ValueError:
+        raised = True
+    np.savez_compressed(
+        os.path.join(OUT, "setup.npz"), grid_nmodel=2048, grid_nfilt=6,
+        grid_seed=41, flux=flux, err=err, mask=mask, offsets=offs,
+        out_flux=out[0], out_err=out[1], out_mask=out[2], lnprior=out[5],
+        av_gauss=np.array(out[8], dtype=float), wt_thresh=out[9],
+        raised_3band=raised)
+    print("setup done; 3-band ValueError raised:", raised)
+
+
+if __name__ == "__main__":
+    os.makedirs(OUT, exist_ok=True)
+    which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup"]
+    if "helpers" in which:
+        gen_helpers()
+    if "setup" in which:
+        gen_setup()
+    if "loglike" in which:
+        gen_loglike()
+    if "fit" in which:
+        gen_fit()
