@@ -1,0 +1,242 @@
+#!/usr/bin/env python
+"""Benchmark of the per-star grid-likelihood hot path on MI355X.
+
+Contract (one JSON line on stdout from rank 0):
+    python bench.py --gpus N --steps K --warmup W
+For N > 1 it is launched by `python -m torch.distributed.run --nproc-per-node N`
+(one rank per GPU, RCCL over xGMI): rank 0 builds the synthetic grid, lays it
+out on its GPU and broadcasts the SoA tensor once; every rank then fits its own
+stars -- stars shard with no data-path collective (weak scaling).
+
+A "step" = one pass of the hot path (brutus_fit_batch: star vectors resident in
+HBM -> compact per-star survivor records in HBM) over one batch of `--batch`
+synthetic stars against the 750k-model x 12-band grid.  Workload = BASELINE.json
+configs[1] (Av-only: rvlim=(3.32, 3.32), no parallax); `--config 3` runs
+configs[2] (Av+Rv free, parallax prior).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=64, help="stars per step per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--nmodel", type=int, default=750000)
+    ap.add_argument("--nfilt", type=int, default=12)
+    ap.add_argument("--cpu-seconds", type=float, default=20.0,
+                    help="budget for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--no-kernel-timing", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(models, stars, cfg_kwargs, budget_s):
+    """Time the CPU restatement (oracle) on a bounded sample of the same
+    workload: rank 0, N=1 only.  Baseline, not the target."""
+    try:
+        from oracle import c_oracle
+        have_c = c_oracle.available()
+    except Exception:
+        have_c = False
+    n = 0
+    t0 = time.time()
+    if have_c:
+        from oracle import c_oracle
+        cores = c_oracle.num_threads()
+        # threads each take whole stars
+        while True:
+            take = cores
+            idx = [(n + j) % len(stars["flux"]) for j in range(take)]
+            c_oracle.loglike_many(stars["flux"][idx], stars["err"][idx],
+                                  stars["mask"][idx], models,
+                                  stars["parallax"][idx], stars["parallax_err"][idx],
+                                  **cfg_kwargs)
+            n += take
+            if time.time() - t0 > budget_s * 0.6:
+                break
+        kind_note = "C restatement oracle/loglike_ref.c, OpenMP over stars"
+    else:
+        from oracle import brutus_oracle as O
+        cores = 1
+        while True:
+            i = n % len(stars["flux"])
+            par = stars["parallax"][i]
+            O.loglike(stars["flux"][i], stars["err"][i], stars["mask"][i], models,
+                      parallax=None if not np.isfinite(par) else par,
+                      parallax_err=None if not np.isfinite(par) else stars["parallax_err"][i],
+                      **cfg_kwargs)
+            n += 1
+            if time.time() - t0 > budget_s * 0.6:
+                break
+        kind_note = "numpy restatement oracle/brutus_oracle.py"
+    dt = time.time() - t0
+    return {"value": n / dt, "unit": "stars/s", "cores": int(cores), "kind": "port",
+            "sample": "%d stars x %d models x %d bands in %.1f s (%s)"
+                      % (n, models.shape[0], models.shape[1], dt, kind_note)}
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+    from brutus_amd import _lib, fitting, synth
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world,
+                                device_id=dev)
+
+    L = _lib.lib()
+    nmodel, nfilt = args.nmodel, args.nfilt
+    # ---- grid: built once on rank 0, broadcast in kernel layout -------------
+    models = None
+    if rank == 0:
+        models, _, _ = synth.make_grid(nmodel, nfilt)
+        grid = fitting.DeviceGrid(models, device=dev)
+    if world > 1:
+        from brutus_amd import parallel
+        grid = parallel.broadcast_grid(grid if rank == 0 else None, nmodel,
+                                       nfilt, dev, src=0)
+    # ---- stars: every rank draws its own shard -------------------------------
+    if args.config == 2:
+        kw = dict(rvlim=(3.32, 3.32))
+        with_par = False
+    else:
+        kw = dict()
+        with_par = True
+    seed = {2: 1, 3: 2}[args.config]
+    if models is None:
+        # ranks > 0 need the f32 coefficients only to synthesise their stars
+        models, _, _ = synth.make_grid(nmodel, nfilt)
+    B = args.batch
+    nb_pool = max(1, min(4, args.steps))       # distinct batches cycled through
+    stars = synth.make_stars(models, B * nb_pool, seed=seed + 1000 * rank,
+                             with_parallax=with_par)
+    params = fitting._make_params(
+        (0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
+        3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    eng = fitting._Engine(grid, max_batch=B, mem_budget=64e9)
+    batches = []
+    for b in range(nb_pool):
+        sl = slice(b * B, (b + 1) * B)
+        batches.append(eng._upload(stars["flux"][sl], stars["err"][sl],
+                                   stars["mask"][sl],
+                                   stars["parallax"][sl] if with_par else None,
+                                   stars["parallax_err"][sl] if with_par else None))
+    cap = 32 << 20
+    sel_bufs = (torch.empty(cap, dtype=torch.int32, device=dev),
+                torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
+
+    def step(i):
+        f, e, m, p, pe, hp = batches[i % nb_pool]
+        return eng.fit_batch_device(f, e, m, p, pe, hp, params,
+                                    sel_buffers=sel_bufs)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        out = step(i)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = step(i)
+    fence()
+    dt = time.perf_counter() - t0
+    nsel_total = int(out[2][-1].item())
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # ---- per-kernel durations (HIP events on the launch stream), after the
+    # timed region so that the events do not perturb `value` --------------------
+    roofline = None
+    ktimes = {}
+    if rank == 0 and not args.no_kernel_timing:
+        import ctypes as C
+        L.brutus_enable_timing(1)
+        reps = max(2, min(5, args.steps))
+        for i in range(reps):
+            step(i)
+            n = C.c_int(0)
+            names = (C.c_char_p * 16)()
+            ms = (C.c_float * 16)()
+            L.brutus_last_timing(C.byref(n), names, ms, 16)
+            for j in range(n.value):
+                ktimes.setdefault(names[j].decode(), []).append(float(ms[j]))
+        L.brutus_enable_timing(0)
+        avg = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        dom = max(avg, key=avg.get)
+        bytes_per_star = nmodel * nfilt * 3 * 4      # one f32 grid read
+        achieved = B * bytes_per_star / (avg[dom] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved,
+                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "avg_launch_ms": avg[dom],
+                    "all_kernels_ms": avg,
+                    "algorithmic_bytes_per_launch": B * bytes_per_star}
+
+    if world > 1:
+        dist.barrier()
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    stars_per_s = world * args.steps * B / dt
+    line = {
+        "metric": "stars/sec at 750k-model x 12-band grid; achieved HBM GB/s vs peak",
+        "value": stars_per_s, "unit": "stars/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": ("configs[1]: 750k-model x 12-band grid, Av-only solve "
+                                "(rvlim=(3.32,3.32)), no parallax" if args.config == 2
+                                else "configs[2]: 750k-model x 12-band grid, Av+Rv free, "
+                                     "parallax prior"),
+                   "nmodel": nmodel, "nfilt": nfilt, "stars_per_step_per_gpu": B,
+                   "timed_region": "brutus_fit_batch: device-resident star vectors -> "
+                                   "device-resident compact survivor records",
+                   "selected_models_last_batch": nsel_total,
+                   "parallelism": "stars sharded, %d rank(s)" % world},
+        "hbm_algorithmic_frac_whole_job":
+            stars_per_s / world * nmodel * nfilt * 12 / 1e9 / HBM_PEAK_GBS,
+    }
+    if roofline is not None:
+        line["roofline"] = roofline
+    if world == 1 and args.cpu_seconds > 0:
+        cpu_kw = dict(kw)
+        line["cpu_baseline"] = cpu_baseline(models, stars, cpu_kw, args.cpu_seconds)
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,86 @@
+"""ctypes binding of the C ABI in include/brutus_amd.h (libbrutus_amd.so).
+
+The shared library is built in-tree by `__graft_entry__.build()` (hipcc,
+--offload-arch=gfx950).  There is NO CPU fallback: if the library is missing or
+no GPU is visible, every compute entry point raises.
+"""
+import ctypes as C
+import os
+
+__all__ = ["lib", "Params", "check", "LIB_PATH", "BrutusError", "NVALS",
+           "MAX_BATCH", "MAX_FILT"]
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
+                        "libbrutus_amd.so")
+NVALS = 11
+MAX_BATCH = 256
+MAX_FILT = 32
+
+_lib = None
+
+
+class BrutusError(RuntimeError):
+    pass
+
+
+class Params(C.Structure):
+    """struct brutus_params (include/brutus_amd.h)."""
+    _fields_ = [("avlim", C.c_double * 2), ("av_gauss", C.c_double * 2),
+                ("rvlim", C.c_double * 2), ("rv_gauss", C.c_double * 2),
+                ("ltol", C.c_double), ("ltol_subthresh", C.c_double),
+                ("init_thresh", C.c_double), ("wt_thresh", C.c_double),
+                ("dim_prior", C.c_int32), ("max_iter", C.c_int32)]
+
+
+_vp, _i64, _i32, _sz, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double
+
+# name -> (restype, argtypes); mirrors include/brutus_amd.h one to one
+SIGNATURES = {
+    "brutus_abi_version": (C.c_int, []),
+    "brutus_last_error": (C.c_char_p, []),
+    "brutus_padded_filters": (C.c_int, [_i32]),
+    "brutus_grid_soa_bytes": (_sz, [_i64, _i32]),
+    "brutus_grid_relayout": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "brutus_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "brutus_loglike_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
+                                       _vp, _i32, C.POINTER(Params), _vp, _sz,
+                                       _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                       _vp, _vp]),
+    "brutus_fit_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
+                                   _i32, C.POINTER(Params), _vp, _sz, _i64, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp]),
+    "brutus_fit_gather": (C.c_int, [_i64, _i32, _i32, _vp, _sz, _dbl, _i64, _vp,
+                                    _vp, _vp, _vp]),
+    "brutus_last_timing": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_char_p),
+                                     C.POINTER(C.c_float), C.c_int]),
+    "brutus_enable_timing": (None, [C.c_int]),
+}
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BrutusError(
+            "brutus_amd: HIP library %s not found. Build it with "
+            "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
+            "There is no CPU fallback." % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(L, name)   # AttributeError if the .so is stale
+        fn.restype = res
+        fn.argtypes = args
+    if L.brutus_abi_version() != 1:
+        raise BrutusError("brutus_amd: ABI version mismatch")
+    _lib = L
+    return L
+
+
+def check(rc):
+    if rc != 0:
+        msg = lib().brutus_last_error().decode("utf-8", "replace")
+        if rc == -1:
+            raise ValueError(msg)
+        raise BrutusError("brutus_amd error %d: %s" % (rc, msg))

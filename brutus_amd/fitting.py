@@ -1,0 +1,877 @@
+"""Brute-force photometric fitter, MI355X-native.
+
+Host-side mirror of the reference's `brutus/fitting.py` public surface for the
+per-star grid-likelihood path:
+
+    loglike(...)            reference fitting.py:579-820
+    lnpost(...)             reference fitting.py:823-1107
+    BruteForce              reference fitting.py:1110-2065
+        .__init__(models, models_labels, labels_mask)
+        ._setup(...), .fit(...), ._fit(...)
+
+The grid scan (everything that touches all Nmodel models: the magnitude-space
+and flux-space optimisation of (scale, Av, Rv), chi2 / log-likelihood, the
+dimensionality prior, the parallax clip and the first `wt_thresh` cut) runs in
+the hand-written HIP kernels of `csrc/brutus_kernels.hip`, reached through the
+C ABI of `include/brutus_amd.h`.  The host keeps what the reference's plugin
+contract forces onto the host -- the user-supplied `lngalprior` / `lndustprior`
+Python callables and the legacy `numpy.random.RandomState` stream -- and only
+ever sees the models that survived the device-side cut.
+
+There is no CPU fallback: without the HIP library or a GPU these functions raise.
+"""
+import sys
+import time
+import warnings
+
+import numpy as np
+
+from . import _lib
+from .pdf import (imf_lnprior, parallax_lnprior, ps1_MrLF_lnprior,
+                  scale_parallax_lnprior)
+from .utils import _inverse3, magnitude, sample_multivariate_normal
+
+try:
+    from scipy.special import logsumexp
+except ImportError:  # pragma: no cover
+    from scipy.misc import logsumexp
+
+__all__ = ["loglike", "lnpost", "BruteForce", "DeviceGrid", "loglike_batch"]
+
+
+def _torch():
+    import torch
+    if not torch.cuda.is_available():
+        raise _lib.BrutusError(
+            "brutus_amd: no GPU visible (torch.cuda.is_available() is False); "
+            "the grid likelihood only runs on the HIP path, there is no CPU "
+            "fallback.")
+    return torch
+
+
+def _stream_ptr(torch):
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol, ltol_subthresh,
+                 init_thresh, dim_prior, wt_thresh=1e-3, max_iter=0):
+    if init_thresh is None:
+        # the reference evaluates log(init_thresh) unconditionally
+        # (fitting.py:150), so `None` never worked there either
+        raise TypeError("init_thresh=None is not supported (the reference "
+                        "raises TypeError at fitting.py:150)")
+    if init_thresh > ltol_subthresh:          # fitting.py:691-693
+        raise ValueError("The initial threshold must be smaller than or equal "
+                         "to the final threshold applied to be useful!")
+    if av_gauss is None:                      # fitting.py:695-696
+        av_gauss = (0., 1e6)
+    p = _lib.Params()
+    p.avlim[:] = [float(avlim[0]), float(avlim[1])]
+    p.av_gauss[:] = [float(av_gauss[0]), float(av_gauss[1])]
+    p.rvlim[:] = [float(rvlim[0]), float(rvlim[1])]
+    p.rv_gauss[:] = [float(rv_gauss[0]), float(rv_gauss[1])]
+    p.ltol = float(ltol)
+    p.ltol_subthresh = float(ltol_subthresh)
+    p.init_thresh = float(init_thresh)
+    p.wt_thresh = float(wt_thresh) if wt_thresh is not None and wt_thresh > 0 else 0.
+    p.dim_prior = 1 if dim_prior else 0
+    p.max_iter = int(max_iter)
+    return p
+
+
+class DeviceGrid(object):
+    """The model grid resident in HBM in the kernels' band-major SoA layout.
+
+    `models` is the `(Nmodel, Nfilt, 3)` array `utils.load_models` returns
+    (reference utils.py:588-591; any float dtype, rounded to float32 like the
+    grid files store it).  Build it once and reuse it for every batch.
+    """
+
+    def __init__(self, models, device=None):
+        torch = _torch()
+        L = _lib.lib()
+        if isinstance(models, DeviceGrid):
+            self.__dict__.update(models.__dict__)
+            return
+        self.device = torch.device(device if device is not None
+                                   else "cuda:%d" % torch.cuda.current_device())
+        if torch.is_tensor(models):
+            aos = models.to(device=self.device, dtype=torch.float32).contiguous()
+        else:
+            models = np.ascontiguousarray(models, dtype=np.float32)
+            aos = torch.from_numpy(models).to(self.device)
+        if aos.dim() != 3 or aos.shape[2] != 3:
+            raise ValueError("models must have shape (Nmodel, Nfilt, 3)")
+        self.nmodel, self.nfilt = int(aos.shape[0]), int(aos.shape[1])
+        if L.brutus_padded_filters(self.nfilt) < 0:
+            raise ValueError("at most %d filters per fit are supported; "
+                             "sub-select the bands you fit" % _lib.MAX_FILT)
+        nbytes = L.brutus_grid_soa_bytes(self.nmodel, self.nfilt)
+        self.soa = torch.empty(nbytes // 4, dtype=torch.float32,
+                               device=self.device)
+        with torch.cuda.device(self.device):
+            _lib.check(L.brutus_grid_relayout(aos.data_ptr(), self.nmodel,
+                                              self.nfilt, self.soa.data_ptr(),
+                                              _stream_ptr(torch)))
+            torch.cuda.current_stream().synchronize()
+
+    @classmethod
+    def from_soa(cls, soa, nmodel, nfilt):
+        """Wrap an already laid-out SoA tensor (e.g. received by broadcast)."""
+        self = cls.__new__(cls)
+        self.device = soa.device
+        self.soa = soa
+        self.nmodel, self.nfilt = int(nmodel), int(nfilt)
+        return self
+
+
+class _Engine(object):
+    """Owns the device workspace and drives the *_batch entry points."""
+
+    def __init__(self, grid, max_batch=None, mem_budget=12e9):
+        self.torch = _torch()
+        self.L = _lib.lib()
+        self.grid = grid
+        per_star = 13 * 8 * grid.nmodel + 4096
+        nb = int(max(1, min(_lib.MAX_BATCH, mem_budget // per_star)))
+        if max_batch is not None:
+            nb = max(1, min(nb, int(max_batch)))
+        self.batch = nb
+        self._ws = None
+        self._ws_batch = 0
+
+    def _workspace(self, nstar):
+        torch = self.torch
+        if self._ws is None or self._ws_batch < nstar:
+            nbytes = self.L.brutus_workspace_bytes(self.grid.nmodel,
+                                                   self.grid.nfilt, nstar)
+            self._ws = torch.empty(nbytes, dtype=torch.uint8,
+                                   device=self.grid.device)
+            self._ws_batch = nstar
+        return self._ws
+
+    def _upload(self, flux, err, mask, parallax, parallax_err):
+        torch = self.torch
+        dev = self.grid.device
+        S, F = flux.shape
+        if F != self.grid.nfilt:
+            raise ValueError("data has %d bands but the grid has %d"
+                             % (F, self.grid.nfilt))
+        f = torch.from_numpy(np.ascontiguousarray(flux, dtype=np.float64)).to(dev)
+        e = torch.from_numpy(np.ascontiguousarray(err, dtype=np.float64)).to(dev)
+        m = torch.from_numpy(np.ascontiguousarray(mask).astype(np.uint8)).to(dev)
+        if parallax is None or parallax_err is None:
+            has_par, p, pe = 0, None, None
+        else:
+            has_par = 1
+            p = torch.from_numpy(np.ascontiguousarray(parallax, dtype=np.float64)).to(dev)
+            pe = torch.from_numpy(np.ascontiguousarray(parallax_err, dtype=np.float64)).to(dev)
+        return f, e, m, p, pe, has_par
+
+    def loglike_batch(self, flux, err, mask, parallax, parallax_err, params):
+        """Full-grid outputs for a batch of stars (host numpy in/out)."""
+        torch, L, g = self.torch, self.L, self.grid
+        S = flux.shape[0]
+        with torch.cuda.device(g.device):
+            f, e, m, p, pe, has_par = self._upload(flux, err, mask, parallax,
+                                                   parallax_err)
+            ws = self._workspace(S)
+            kw = dict(dtype=torch.float64, device=g.device)
+            lnl = torch.empty((S, g.nmodel), **kw)
+            chi2 = torch.empty((S, g.nmodel), **kw)
+            scale = torch.empty((S, g.nmodel), **kw)
+            av = torch.empty((S, g.nmodel), **kw)
+            rv = torch.empty((S, g.nmodel), **kw)
+            icov = torch.empty((6, S, g.nmodel), **kw)
+            ndim = torch.empty(S, dtype=torch.int32, device=g.device)
+            k1 = np.zeros(S, dtype=np.int32)
+            k2 = np.zeros(S, dtype=np.int32)
+            _lib.check(L.brutus_loglike_batch(
+                g.soa.data_ptr(), g.nmodel, g.nfilt, S, f.data_ptr(),
+                e.data_ptr(), m.data_ptr(),
+                p.data_ptr() if p is not None else None,
+                pe.data_ptr() if pe is not None else None, has_par, params,
+                ws.data_ptr(), ws.numel(), lnl.data_ptr(), chi2.data_ptr(),
+                scale.data_ptr(), av.data_ptr(), rv.data_ptr(), icov.data_ptr(),
+                ndim.data_ptr(), k1.ctypes.data, k2.ctypes.data,
+                _stream_ptr(torch)))
+            out = dict(lnl=lnl.cpu().numpy(), chi2=chi2.cpu().numpy(),
+                       scale=scale.cpu().numpy(), av=av.cpu().numpy(),
+                       rv=rv.cpu().numpy(), icov6=icov.cpu().numpy(),
+                       ndim=ndim.cpu().numpy(), k1=k1, k2=k2)
+        return out
+
+    def fit_batch_device(self, f, e, m, p, pe, has_par, params, capacity=None,
+                         sel_buffers=None):
+        """Device-resident inputs -> device-resident compact records.
+        Returns (sel_idx, sel_vals, sel_off, ndim, k1, k2) tensors."""
+        torch, L, g = self.torch, self.L, self.grid
+        S = f.shape[0]
+        ws = self._workspace(S)
+        if capacity is None:
+            capacity = max(1 << 20, 4 * S * 4096)
+        if sel_buffers is None or sel_buffers[0].numel() < capacity:
+            sel_idx = torch.empty(capacity, dtype=torch.int32, device=g.device)
+            sel_vals = torch.empty((_lib.NVALS, capacity), dtype=torch.float64,
+                                   device=g.device)
+        else:
+            sel_idx, sel_vals = sel_buffers
+            capacity = sel_idx.numel()
+        sel_off = torch.empty(S + 1, dtype=torch.int64, device=g.device)
+        ndim = torch.empty(S, dtype=torch.int32, device=g.device)
+        k1 = np.zeros(S, dtype=np.int32)
+        k2 = np.zeros(S, dtype=np.int32)
+        _lib.check(L.brutus_fit_batch(
+            g.soa.data_ptr(), g.nmodel, g.nfilt, S, f.data_ptr(), e.data_ptr(),
+            m.data_ptr(), p.data_ptr() if p is not None else None,
+            pe.data_ptr() if pe is not None else None, has_par, params,
+            ws.data_ptr(), ws.numel(), capacity, sel_idx.data_ptr(),
+            sel_vals.data_ptr(), sel_off.data_ptr(), ndim.data_ptr(),
+            k1.ctypes.data, k2.ctypes.data, _stream_ptr(torch)))
+        return sel_idx, sel_vals, sel_off, ndim, k1, k2
+
+    def fit_batch(self, flux, err, mask, parallax, parallax_err, params):
+        """Host numpy in -> list of per-star compact record dicts."""
+        torch, L, g = self.torch, self.L, self.grid
+        S = flux.shape[0]
+        with torch.cuda.device(g.device):
+            f, e, m, p, pe, has_par = self._upload(flux, err, mask, parallax,
+                                                   parallax_err)
+            bufs = getattr(self, "_sel_bufs", None)
+            sel_idx, sel_vals, sel_off, ndim, k1, k2 = self.fit_batch_device(
+                f, e, m, p, pe, has_par, params, sel_buffers=bufs)
+            off = sel_off.cpu().numpy()
+            total = int(off[-1])
+            cap = sel_idx.numel()
+            if total > cap:
+                cap = int(total * 1.25) + 1024
+                sel_idx = torch.empty(cap, dtype=torch.int32, device=g.device)
+                sel_vals = torch.empty((_lib.NVALS, cap), dtype=torch.float64,
+                                       device=g.device)
+                ws = self._workspace(S)
+                _lib.check(L.brutus_fit_gather(
+                    g.nmodel, g.nfilt, S, ws.data_ptr(), ws.numel(),
+                    params.wt_thresh, cap, sel_idx.data_ptr(),
+                    sel_vals.data_ptr(), sel_off.data_ptr(), _stream_ptr(torch)))
+            self._sel_bufs = (sel_idx, sel_vals)
+            idx = sel_idx[:total].cpu().numpy()
+            vals = sel_vals[:, :total].cpu().numpy()
+            ndim = ndim.cpu().numpy()
+        out = []
+        for s in range(S):
+            a, b = int(off[s]), int(off[s + 1])
+            icov = np.empty((b - a, 3, 3))
+            icov[:, 0, 0] = vals[5, a:b]
+            icov[:, 0, 1] = icov[:, 1, 0] = vals[6, a:b]
+            icov[:, 0, 2] = icov[:, 2, 0] = vals[7, a:b]
+            icov[:, 1, 1] = vals[8, a:b]
+            icov[:, 1, 2] = icov[:, 2, 1] = vals[9, a:b]
+            icov[:, 2, 2] = vals[10, a:b]
+            out.append(dict(sel=idx[a:b].astype(np.int64), lnlike=vals[0, a:b],
+                            chi2=vals[1, a:b], scale=vals[2, a:b],
+                            av=vals[3, a:b], rv=vals[4, a:b], icov=icov,
+                            Ndim=int(ndim[s]), K1=int(k1[s]), K2=int(k2[s])))
+        return out
+
+
+def _icov_from6(icov6):
+    """(6, N) -> (N, 3, 3) symmetric precision matrices (fitting.py:563-574)."""
+    N = icov6.shape[1]
+    icov = np.empty((N, 3, 3))
+    icov[:, 0, 0] = icov6[0]
+    icov[:, 0, 1] = icov[:, 1, 0] = icov6[1]
+    icov[:, 0, 2] = icov[:, 2, 0] = icov6[2]
+    icov[:, 1, 1] = icov6[3]
+    icov[:, 1, 2] = icov[:, 2, 1] = icov6[4]
+    icov[:, 2, 2] = icov6[5]
+    return icov
+
+
+def loglike_batch(data, data_err, data_mask, mag_coeffs,
+                  avlim=(0., 20.), av_gauss=(0., 1e6),
+                  rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
+                  dim_prior=True, ltol=3e-2, ltol_subthresh=1e-2,
+                  init_thresh=5e-3, parallax=None, parallax_err=None,
+                  max_batch=None):
+    """`loglike` for many stars at once: `data`, `data_err`, `data_mask` are
+    `(Nstar, Nfilt)`, `parallax`/`parallax_err` `(Nstar,)` or None.  Returns a
+    dict of full-grid arrays `(Nstar, Nmodel)` plus `ndim`, `k1`, `k2`."""
+    grid = mag_coeffs if isinstance(mag_coeffs, DeviceGrid) else DeviceGrid(mag_coeffs)
+    params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
+                          ltol_subthresh, init_thresh, dim_prior)
+    eng = _Engine(grid, max_batch=max_batch, mem_budget=4e9)
+    data = np.atleast_2d(np.asarray(data, dtype=np.float64))
+    data_err = np.atleast_2d(np.asarray(data_err, dtype=np.float64))
+    data_mask = np.atleast_2d(np.asarray(data_mask))
+    outs = []
+    for a in range(0, data.shape[0], eng.batch):
+        b = min(data.shape[0], a + eng.batch)
+        outs.append(eng.loglike_batch(
+            data[a:b], data_err[a:b], data_mask[a:b],
+            None if parallax is None else np.asarray(parallax)[a:b],
+            None if parallax_err is None else np.asarray(parallax_err)[a:b],
+            params))
+    res = {}
+    for k in outs[0]:
+        ax = 1 if k == "icov6" else 0
+        res[k] = np.concatenate([o[k] for o in outs], axis=ax)
+    return res
+
+
+def loglike(data, data_err, data_mask, mag_coeffs,
+            avlim=(0., 20.), av_gauss=(0., 1e6),
+            rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
+            av_init=None, rv_init=None,
+            dim_prior=True, ltol=3e-2, ltol_subthresh=1e-2, init_thresh=5e-3,
+            parallax=None, parallax_err=None, return_vals=False,
+            *args, **kwargs):
+    """Log-likelihood of one object against every model of the grid, optimised
+    over (scale, Av, Rv) per model.  Same signature, semantics and return
+    values as reference `fitting.loglike` (fitting.py:579-820).
+
+    `mag_coeffs` is `(Nmodel, Nfilt, 3)` (numpy, any float dtype) or a
+    `DeviceGrid` already resident on the GPU.  Unlike the reference the inputs
+    are not modified in place.
+    """
+    if av_init is not None or rv_init is not None:
+        raise NotImplementedError("per-model av_init/rv_init are not supported; "
+                                  "the reference never passes them")
+    one = lambda x: None if x is None else np.array([x], dtype=np.float64)
+    if parallax is not None and parallax_err is None:
+        parallax = None
+    res = loglike_batch(np.asarray(data)[None, :], np.asarray(data_err)[None, :],
+                        np.asarray(data_mask)[None, :], mag_coeffs, avlim=avlim,
+                        av_gauss=av_gauss, rvlim=rvlim, rv_gauss=rv_gauss,
+                        dim_prior=dim_prior, ltol=ltol,
+                        ltol_subthresh=ltol_subthresh, init_thresh=init_thresh,
+                        parallax=one(parallax), parallax_err=one(parallax_err),
+                        max_batch=1)
+    lnl, Ndim, chi2 = res["lnl"][0], int(res["ndim"][0]), res["chi2"][0]
+    if return_vals:
+        return (lnl, Ndim, chi2, res["scale"][0], res["av"][0], res["rv"][0],
+                _icov_from6(res["icov6"][:, 0, :]))
+    return lnl, Ndim, chi2
+
+
+# ---------------------------------------------------------------------------
+# lnpost: host stage on the selected models
+# ---------------------------------------------------------------------------
+def _default_rstate(rstate):
+    if rstate is None:          # fitting.py:937-944
+        rstate = getattr(np, "random_intel", np.random)
+    return rstate
+
+
+def _psd_repair(cov, icov, scale):
+    """Regularise non-PSD covariances by adding a growing diagonal Gaussian
+    prior to the precision (reference fitting.py:1042-1065)."""
+    def bad_of(c):
+        with np.errstate(all="ignore"):
+            return ~np.all(np.linalg.eigvals(c) > 0, axis=1)
+    bad = np.where(bad_of(cov))[0]
+    width, count = 0.02, 1
+    while bad.size:
+        sub = cov[bad]
+        neg = [sub[:, k, k] <= 0 for k in range(3)]
+        # a parameter is regularised if its variance is non-positive, or if
+        # all three variances are positive (then everything is)
+        flag = [neg[0] | (~neg[1] & ~neg[2]),
+                neg[1] | (~neg[0] & ~neg[2]),
+                neg[2] | (~neg[0] & ~neg[1])]
+        sf = scale[bad] * width
+        icov[bad, 0, 0] += count / sf ** 2 * flag[0]
+        icov[bad, 1, 1] += count / width ** 2 * flag[1]
+        icov[bad, 2, 2] += count / width ** 2 * flag[2]
+        cov[bad] = _inverse3(icov[bad])
+        bad = bad[bad_of(cov[bad])]
+        count *= 2
+    return cov
+
+
+def _lnpost_selected(sel, lnlike, scales, avs, rvs, icovs, lnprior, parallax,
+                     parallax_err, coord, Nmc_prior, wt_thresh, cdf_thresh,
+                     lngalprior, lndustprior, dustfile, dlabels, avlim, rvlim,
+                     rstate, apply_av_prior, mem_lim, lnprob_first):
+    """Everything in reference `lnpost` after the first cut
+    (fitting.py:1000-1107).  All array arguments are aligned with `sel`
+    (the first-cut model indices, ascending)."""
+    mvn = sample_multivariate_normal
+    Nsel_max = int(mem_lim / Nmc_prior / 4.0e-4) if Nmc_prior > 0 else None
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        lnp = lnlike + lnprior[sel]
+        dist = 1. / np.sqrt(scales)
+        lnp = lnp + lngalprior(dist, coord,
+                               labels=None if dlabels is None else dlabels[sel])
+        if apply_av_prior:
+            lnp = lnp + lndustprior(dist, coord, avs, dustfile=dustfile)
+        # second cut (fitting.py:1013-1022)
+        if wt_thresh is not None:
+            keep = np.where(lnp > np.log(wt_thresh) + np.max(lnp))[0]
+        else:
+            order = np.argsort(lnp)
+            prob = np.exp(lnp - logsumexp(lnp))
+            keep = order[np.cumsum(prob[order]) <= (1. - cdf_thresh)]
+        sel = sel[keep]
+        lnlike, scale, av, rv = lnlike[keep], scales[keep], avs[keep], rvs[keep]
+        icov = np.array(icovs[keep])
+        lnprob_first = lnprob_first[keep]
+        lnp = lnlike + lnprior[sel]                        # fitting.py:1023
+        if Nsel_max is not None and len(sel) > Nsel_max:   # fitting.py:1029-1036
+            top = np.argsort(lnp)[::-1][:Nsel_max]
+            sel, lnp, scale, av, rv = sel[top], lnp[top], scale[top], av[top], rv[top]
+            icov, lnprob_first = icov[top], lnprob_first[top]
+        Nsel = len(sel)
+
+        cov = _inverse3(icov)
+        cov = _psd_repair(cov, icov, scale)
+
+        if Nmc_prior > 0:
+            s_mc, a_mc, r_mc = mvn(np.transpose([scale, av, rv]), cov,
+                                   size=Nmc_prior, rstate=rstate)
+            if dlabels is not None:
+                dl_mc = np.tile(dlabels[sel], Nmc_prior).reshape(-1, Nsel)
+            else:
+                dl_mc = None
+            par_mc = np.sqrt(s_mc)
+            dist_mc = 1. / par_mc
+            lnp_mc = np.array(lngalprior(dist_mc, coord, labels=dl_mc),
+                              dtype=np.float64)
+            if apply_av_prior:
+                lnp_mc = lnp_mc + lndustprior(dist_mc, coord, a_mc,
+                                              dustfile=dustfile)
+            if parallax is not None and parallax_err is not None:
+                lnp_mc = lnp_mc + parallax_lnprior(par_mc, parallax, parallax_err)
+            inb = ((s_mc >= 1e-20) & (a_mc >= avlim[0]) & (a_mc <= avlim[1])
+                   & (r_mc >= rvlim[0]) & (r_mc <= rvlim[1]))
+            lnp_mc[~inb] = -1e300
+            lnp = lnp + (logsumexp(lnp_mc, axis=0) - np.log(np.sum(inb, axis=0)))
+        else:
+            # the reference's Nmc_prior=0 branch is unreachable (ZeroDivision at
+            # fitting.py:970, then undefined dist_mc at :1107); implement the
+            # evident intent: keep the MLE-point posterior, no draws.
+            lnp = lnprob_first
+            dist_mc = a_mc = r_mc = lnp_mc = np.zeros((0, Nsel))
+        lnp = np.where(np.isfinite(lnp), lnp, -1e300)
+    return sel, cov, lnp, dist_mc.T, a_mc.T, r_mc.T, lnp_mc.T
+
+
+def _resolve_hooks(lngalprior, lndustprior, coord, apply_av_prior):
+    if lngalprior is None and coord is None:
+        raise ValueError("`coord` must be provided if using the "
+                         "default Galactic model prior.")
+    if lndustprior is None and coord is None and apply_av_prior:
+        raise ValueError("`coord` must be provided if using the "
+                         "default dust prior.")
+    if lngalprior is None:
+        from .galprior import gal_lnprior
+        lngalprior = gal_lnprior
+    if lndustprior is None and apply_av_prior:
+        raise NotImplementedError(
+            "the default 3-D dust-map prior needs the Bayestar map and healpy, "
+            "which are outside this package's scope; pass `lndustprior=` or an "
+            "`av_gauss` prior")
+    return lngalprior, lndustprior
+
+
+def lnpost(results, parallax=None, parallax_err=None, coord=None,
+           Nmc_prior=100, lnprior=None, wt_thresh=1e-3, cdf_thresh=2e-3,
+           lngalprior=None, lndustprior=None, dustfile=None, dlabels=None,
+           avlim=(0., 20.), rvlim=(1., 8.), rstate=None,
+           apply_av_prior=True, mem_lim=8000., *args, **kwargs):
+    """Log-posteriors of the selected models from full-grid `loglike` results.
+    Same signature and return values as reference `fitting.lnpost`
+    (fitting.py:823-1107): `(sel, cov_sar, lnp, dist_mc, av_mc, rv_mc, lnp_mc)`.
+
+    This entry point takes host arrays (the reference's calling convention);
+    `BruteForce.fit` does not go through it -- there the first cut runs on the
+    device and only the selected models ever reach the host.
+    """
+    if wt_thresh is None and cdf_thresh is None:
+        wt_thresh = -np.inf
+    rstate = _default_rstate(rstate)
+    if parallax is not None and parallax_err is None:
+        raise ValueError("Must provide both `parallax` and `parallax_err`.")
+    lngalprior, lndustprior = _resolve_hooks(lngalprior, lndustprior, coord,
+                                             apply_av_prior)
+    if coord is None:
+        coord = np.zeros(2)
+    lnlike, Ndim, chi2, scales, avs, rvs, icovs_sar = results
+    if lnprior is None:
+        lnprior = np.zeros(len(lnlike))
+    lnprior = np.asarray(lnprior, dtype=np.float64)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        if parallax is not None and parallax_err is not None:
+            serr = 1. / np.sqrt(np.abs(icovs_sar[:, 0, 0]))
+            lnprob = lnlike + scale_parallax_lnprior(scales, serr, parallax,
+                                                     parallax_err)
+        else:
+            lnprob = np.array(lnlike)
+        lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+        if parallax is None or parallax_err is None:
+            lnlike = lnprob       # the reference aliases them (fitting.py:982)
+        if wt_thresh is not None:
+            sel = np.where(lnprob > np.log(wt_thresh) + np.max(lnprob))[0]
+        else:
+            order = np.argsort(lnprob)
+            prob = np.exp(lnprob - logsumexp(lnprob))
+            sel = order[np.cumsum(prob[order]) <= (1. - cdf_thresh)]
+    return _lnpost_selected(sel, lnlike[sel], scales[sel], avs[sel], rvs[sel],
+                            icovs_sar[sel], lnprior, parallax, parallax_err,
+                            coord, Nmc_prior, wt_thresh, cdf_thresh, lngalprior,
+                            lndustprior, dustfile, dlabels, avlim, rvlim, rstate,
+                            apply_av_prior, mem_lim, lnprob[sel])
+
+
+# ---------------------------------------------------------------------------
+# BruteForce
+# ---------------------------------------------------------------------------
+class BruteForce(object):
+    """Fits data with a pre-computed model grid by brute force; drop-in for
+    reference `fitting.BruteForce` (fitting.py:1110-2065) with the grid scan on
+    the GPU."""
+
+    def __init__(self, models, models_labels, labels_mask):
+        """`models` `(Nmodel, Nfilt, 3)` magnitude coefficients, `models_labels`
+        structured array of per-model labels, `labels_mask` structured `(1,)`
+        bool array flagging the labels the grid was built over
+        (reference fitting.py:1117-1142)."""
+        self.NMODEL, self.NDIM, self.NCOEF = models.shape
+        self.models = models
+        self.models_labels = models_labels
+        self.labels_mask = labels_mask
+        self.NLABELS = len(models_labels[0])
+        self._grid = None
+        self._engine_obj = None
+        #: stars per device batch (None = sized from the memory budget)
+        self.batch_size = None
+
+    # -- device state -------------------------------------------------------
+    def _engine(self):
+        if self._engine_obj is None:
+            if self._grid is None:
+                self._grid = DeviceGrid(self.models)
+            self._engine_obj = _Engine(self._grid, max_batch=self.batch_size)
+        return self._engine_obj
+
+    def use_device_grid(self, grid):
+        """Adopt a `DeviceGrid` that is already resident (e.g. broadcast)."""
+        self._grid = grid
+        self._engine_obj = None
+
+    # -- set-up (reference fitting.py:1144-1424) ------------------------------
+    def _setup(self, data, data_err, data_mask, data_labels,
+               phot_offsets=None, parallax=None, parallax_err=None,
+               av_gauss=None, lnprior=None,
+               wt_thresh=1e-3, cdf_thresh=2e-3,
+               apply_agewt=True, apply_grad=True,
+               lngalprior=None, lndustprior=None, dustfile=None,
+               data_coords=None, ltol_subthresh=1e-2,
+               logl_initthresh=5e-3, mag_max=50., merr_max=0.25, rstate=None):
+        data = np.array(data, dtype=np.float64)
+        data_err = np.array(data_err, dtype=np.float64)
+        data_mask = np.array(data_mask, dtype=bool)
+        Ndata, Nfilt = data.shape
+
+        if logl_initthresh > ltol_subthresh:
+            raise ValueError("The initial threshold must be smaller than "
+                             "or equal to the convergence threshold in order "
+                             "to be useful!")
+        if wt_thresh is None and cdf_thresh is None:
+            wt_thresh = -np.inf
+        rstate = _default_rstate(rstate)
+        if parallax is not None and parallax_err is None:
+            raise ValueError("Must provide both `parallax` and "
+                             "`parallax_err`.")
+        if phot_offsets is None:
+            phot_offsets = np.ones(Nfilt)
+
+        # static prior over the grid
+        names = self.models_labels.dtype.names
+        if lnprior is None:
+            if 'mini' in names:
+                lnprior = imf_lnprior(self.models_labels['mini'])
+            else:
+                lnprior = ps1_MrLF_lnprior(self.models_labels['Mr'])
+        lnprior = np.array(lnprior, dtype=np.float64)
+        if apply_agewt and 'agewt' in names:
+            with np.errstate(all="ignore"):
+                lnprior = lnprior + np.log(np.abs(self.models_labels['agewt']))
+        if apply_grad:
+            for name in names:
+                if not self.labels_mask[name][0]:
+                    continue
+                label = self.models_labels[name]
+                nodes = np.unique(label)
+                if len(nodes) > 1:
+                    lnprior = lnprior + np.interp(label, nodes,
+                                                  np.log(np.gradient(nodes)))
+
+        if lngalprior is None and data_coords is None:
+            raise ValueError("`data_coords` must be provided if using the "
+                             "default Galactic model prior.")
+        if lngalprior is None:
+            from .galprior import gal_lnprior
+            lngalprior = gal_lnprior
+        if lndustprior is None and dustfile is not None:
+            raise NotImplementedError(
+                "the Bayestar dust-map prior (`dustfile=`) is outside this "
+                "package's scope; pass your own `lndustprior` callable")
+        elif lndustprior is None and av_gauss is None:
+            av_gauss = (0, 1e6)                       # fitting.py:1396-1398
+        if data_coords is None:
+            data_coords = np.zeros((Ndata, 2))
+
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            mag, err = magnitude(data, data_err)
+            bad_mag = (mag > mag_max) | (err > merr_max)
+            clean = np.isfinite(data) & np.isfinite(data_err) & (data_err > 0.)
+            data_mask = data_mask & clean & ~bad_mag
+
+        Nbmin = 4
+        if np.any(np.sum(data_mask, axis=1) < Nbmin):
+            raise ValueError("Objects with fewer than {0} bands of "
+                             "acceptable photometry are currently included in "
+                             "the dataset. These objects give degenerate fits "
+                             "and cannot be properly modeled. Please remove "
+                             "these objects or modify `mag_max` or `merr_max`."
+                             .format(Nbmin))
+
+        return (data * phot_offsets, data_err * phot_offsets, data_mask,
+                data_labels, data_coords, lnprior, lngalprior, lndustprior,
+                av_gauss, wt_thresh, rstate)
+
+    # -- fit (reference fitting.py:1426-1801) ---------------------------------
+    def fit(self, data, data_err, data_mask, data_labels, save_file,
+            phot_offsets=None, parallax=None, parallax_err=None,
+            Nmc_prior=50, avlim=(0., 20.), av_gauss=None,
+            rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
+            lnprior=None, lnprior_ext=None,
+            wt_thresh=1e-3, cdf_thresh=2e-3, Ndraws=250,
+            apply_agewt=True, apply_grad=True,
+            lngalprior=None, lndustprior=None, dustfile=None,
+            apply_dlabels=True, data_coords=None, logl_dim_prior=True,
+            ltol=3e-2, ltol_subthresh=1e-2, logl_initthresh=5e-3,
+            mag_max=50., merr_max=0.25, rstate=None, save_dar_draws=True,
+            running_io=True, mem_lim=8000., verbose=True):
+        """Fit every object and write `{save_file}.h5` in the reference's
+        layout (fitting.py:1632-1662, 1734-1748).  Keyword arguments, units and
+        defaults are the reference's.  Returns None."""
+        from . import h5io
+        (data, data_err, data_mask, data_labels, data_coords,
+         lnprior, lngalprior, lndustprior, av_gauss, wt_thresh,
+         rstate) = self._setup(data, data_err, data_mask, data_labels,
+                               phot_offsets=phot_offsets, parallax=parallax,
+                               parallax_err=parallax_err, av_gauss=av_gauss,
+                               lnprior=lnprior, wt_thresh=wt_thresh,
+                               cdf_thresh=cdf_thresh, apply_agewt=apply_agewt,
+                               apply_grad=apply_grad, lngalprior=lngalprior,
+                               lndustprior=lndustprior, dustfile=dustfile,
+                               data_coords=data_coords,
+                               ltol_subthresh=ltol_subthresh,
+                               logl_initthresh=logl_initthresh,
+                               mag_max=mag_max, merr_max=merr_max,
+                               rstate=rstate)
+        Ndata, Nfilt = data.shape
+
+        out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
+                               data_labels, save_dar_draws,
+                               running_io=running_io)
+        try:
+            t0 = time.time()
+            if verbose:
+                sys.stderr.write('\rFitting object {0}/{1}  '.format(1, Ndata))
+                sys.stderr.flush()
+            gen = self._fit(data, data_err, data_mask, parallax=parallax,
+                            parallax_err=parallax_err, avlim=avlim,
+                            rvlim=rvlim, av_gauss=av_gauss, rv_gauss=rv_gauss,
+                            Nmc_prior=Nmc_prior, lnprior=lnprior,
+                            lnprior_ext=lnprior_ext, wt_thresh=wt_thresh,
+                            cdf_thresh=cdf_thresh, Ndraws=Ndraws,
+                            rstate=rstate, lngalprior=lngalprior,
+                            lndustprior=lndustprior, dustfile=dustfile,
+                            apply_dlabels=apply_dlabels,
+                            data_coords=data_coords,
+                            return_distreds=save_dar_draws,
+                            ltol_subthresh=ltol_subthresh,
+                            logl_dim_prior=logl_dim_prior,
+                            logl_initthresh=logl_initthresh, ltol=ltol,
+                            mem_lim=mem_lim)
+            for i, results in enumerate(gen):
+                out.write_row(i, results)
+                if verbose:
+                    t_avg = (time.time() - t0) / (i + 1)
+                    t_est = t_avg * (Ndata - i - 1)
+                    sys.stderr.write('\rFitting object {:d}/{:d} '
+                                     '[chi2/n: {:2.1f}/{:d}] '
+                                     '(mean time: {:2.3f} s/obj, '
+                                     'est. remaining: {:10.3f} s)    '
+                                     .format(min(i + 2, Ndata), Ndata,
+                                             results[8], results[5],
+                                             t_avg, t_est))
+                    sys.stderr.flush()
+            if verbose:
+                sys.stderr.write('\n')
+                sys.stderr.flush()
+        finally:
+            out.close()
+
+    # -- per-star generator (reference fitting.py:1803-2065) ------------------
+    def _fit(self, data, data_err, data_mask,
+             parallax=None, parallax_err=None, Nmc_prior=100,
+             avlim=(0., 20.), av_gauss=None,
+             rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
+             lnprior=None, lnprior_ext=None,
+             wt_thresh=1e-3, cdf_thresh=2e-3, Ndraws=250,
+             lngalprior=None, lndustprior=None, dustfile=None,
+             apply_dlabels=True, data_coords=None,
+             return_distreds=True, logl_dim_prior=True, ltol=3e-2,
+             ltol_subthresh=1e-2, logl_initthresh=5e-3, mem_lim=8000.,
+             rstate=None):
+        """Generator yielding, per object and in input order, the tuple
+        `(model_idx, scales, avs, rvs, cov_sar, Ndim, lnprob, levid, chi2min
+        [, dists, reds, dreds, logwts])` of reference fitting.py:2059-2065.
+
+        The grid scan runs on the device for a batch of objects at a time; the
+        yields still arrive one object at a time and consume `rstate` in the
+        reference's order, so a seeded run reproduces the reference's draws.
+        """
+        if Nmc_prior <= 0:
+            raise ValueError("Nmc_prior must be positive (the reference "
+                             "divides by it, fitting.py:970)")
+        if wt_thresh is None and cdf_thresh is not None:
+            raise NotImplementedError(
+                "CDF thresholding (wt_thresh=None) discards the best models in "
+                "the reference (ascending sort, fitting.py:993-997); it is not "
+                "reproduced -- use wt_thresh")
+        (data, data_err, data_mask, _, data_coords,
+         lnprior, lngalprior, lndustprior, av_gauss, wt_thresh,
+         rstate) = self._setup(data, data_err, data_mask, data_labels=None,
+                               phot_offsets=None, parallax=parallax,
+                               parallax_err=parallax_err, av_gauss=av_gauss,
+                               lnprior=lnprior, wt_thresh=wt_thresh,
+                               cdf_thresh=cdf_thresh, apply_agewt=False,
+                               apply_grad=False, lngalprior=lngalprior,
+                               lndustprior=lndustprior, dustfile=dustfile,
+                               data_coords=data_coords,
+                               ltol_subthresh=ltol_subthresh,
+                               logl_initthresh=logl_initthresh,
+                               mag_max=np.inf, merr_max=np.inf, rstate=rstate)
+        apply_av_prior = av_gauss is None
+        dlabels = self.models_labels if apply_dlabels else None
+        if lnprior_ext is not None:
+            for k in lnprior_ext.keys():
+                if k not in self.models_labels.dtype.names:
+                    raise ValueError("Provided `lnprior_ext` has keys which "
+                                     "do not match the underlying model "
+                                     "labels.")
+        Ndata, Nfilt = data.shape
+        # `parallax=None` (the documented default) crashes the reference at
+        # fitting.py:1989; treat it as "no parallax for any object".
+        if parallax is None:
+            parallax = np.full(Ndata, np.nan)
+            parallax_err = np.full(Ndata, np.nan)
+        parallax = np.asarray(parallax, dtype=np.float64)
+        parallax_err = np.asarray(parallax_err, dtype=np.float64)
+
+        eng = self._engine()
+        params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
+                              ltol_subthresh, logl_initthresh, logl_dim_prior,
+                              wt_thresh=wt_thresh)
+        step = eng.batch if lnprior_ext is None else max(1, min(eng.batch, 8))
+        for a in range(0, Ndata, step):
+            b = min(Ndata, a + step)
+            if lnprior_ext is None:
+                recs = eng.fit_batch(data[a:b], data_err[a:b], data_mask[a:b],
+                                     parallax[a:b], parallax_err[a:b], params)
+            else:
+                recs = self._first_cut_with_ext(eng, data[a:b], data_err[a:b],
+                                                data_mask[a:b], parallax[a:b],
+                                                parallax_err[a:b], params,
+                                                lnprior_ext, a, wt_thresh)
+            for i, rec in zip(range(a, b), recs):
+                yield self._finish_star(rec, parallax[i], parallax_err[i],
+                                        data_coords[i], Nmc_prior, lnprior,
+                                        wt_thresh, cdf_thresh, lngalprior,
+                                        lndustprior, dustfile, dlabels, avlim,
+                                        rvlim, mem_lim, rstate, apply_av_prior,
+                                        Ndraws, return_distreds)
+
+    def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
+                            lnprior_ext, offset, wt_thresh):
+        """External per-object Gaussian label constraints modify lnlike over
+        the whole grid before the first cut (fitting.py:1995-2009); this rare
+        option uses the full-grid device outputs and cuts on the host."""
+        res = eng.loglike_batch(data, err, mask, par, perr, params)
+        recs = []
+        for s in range(data.shape[0]):
+            lnl = res["lnl"][s].copy()
+            for k in lnprior_ext.keys():
+                mean, std = lnprior_ext[k][offset + s]
+                if np.isfinite(mean) and std > 0:
+                    chi2e = (self.models_labels[k] - mean) ** 2 / std ** 2
+                    lnl += -0.5 * (chi2e + np.log(2. * np.pi * std ** 2))
+            icov00 = res["icov6"][0, s]
+            with np.errstate(all="ignore"):
+                lnprob = lnl + scale_parallax_lnprior(
+                    res["scale"][s], 1. / np.sqrt(np.abs(icov00)), par[s], perr[s])
+            lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+            sel = np.where(lnprob > np.log(wt_thresh) + np.max(lnprob))[0]
+            recs.append(dict(sel=sel, lnlike=lnl[sel], chi2=res["chi2"][s][sel],
+                             scale=res["scale"][s][sel], av=res["av"][s][sel],
+                             rv=res["rv"][s][sel],
+                             icov=_icov_from6(res["icov6"][:, s, :][:, sel]),
+                             Ndim=int(res["ndim"][s])))
+        return recs
+
+    @staticmethod
+    def _finish_star(rec, parallax, parallax_err, coord, Nmc_prior, lnprior,
+                     wt_thresh, cdf_thresh, lngalprior, lndustprior, dustfile,
+                     dlabels, avlim, rvlim, mem_lim, rstate, apply_av_prior,
+                     Ndraws, return_distreds):
+        """lnpost's host stage + evidence + resampling for one object
+        (reference fitting.py:2012-2065)."""
+        sel0 = rec["sel"]
+        Ndim = rec["Ndim"]
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            # lnprob of the first cut is only consumed by the Nmc_prior=0 branch
+            (sel, cov_sar, lnprob, dists, reds, dreds,
+             logwts) = _lnpost_selected(
+                sel0, rec["lnlike"], rec["scale"], rec["av"], rec["rv"],
+                rec["icov"], lnprior, parallax, parallax_err, coord, Nmc_prior,
+                wt_thresh, cdf_thresh, lngalprior, lndustprior, dustfile,
+                dlabels, avlim, rvlim, rstate, apply_av_prior, mem_lim,
+                rec["lnlike"])
+            Nsel = len(sel)
+            # position of the final selection inside the first-cut records
+            pos = np.searchsorted(sel0, sel)
+            chi2 = rec["chi2"][pos]
+            scales_sel, avs_sel, rvs_sel = (rec["scale"][pos], rec["av"][pos],
+                                            rec["rv"][pos])
+            if np.isfinite(parallax) and np.isfinite(parallax_err):
+                chi2 = chi2 + ((np.sqrt(scales_sel) - parallax) ** 2
+                               / parallax_err ** 2)         # fitting.py:2025-2030
+                Ndim += 1
+            levid = logsumexp(lnprob)
+            chi2min = np.min(chi2)
+            wt = np.exp(lnprob - levid)
+            wt /= wt.sum()
+            idxs = rstate.choice(Nsel, size=Ndraws, p=wt)
+            sidxs = sel[idxs]
+            scales, avs, rvs = scales_sel[idxs], avs_sel[idxs], rvs_sel[idxs]
+            cov_sar = cov_sar[idxs]
+            lnprob = lnprob[idxs]
+            if not return_distreds:
+                return (sidxs, scales, avs, rvs, cov_sar, Ndim, lnprob, levid,
+                        chi2min)
+            imc = np.zeros(Ndraws, dtype='int')
+            for j, idx in enumerate(idxs):
+                w = np.exp(logwts[idx] - logsumexp(logwts[idx]))
+                w /= w.sum()
+                imc[j] = rstate.choice(Nmc_prior, p=w)
+            return (sidxs, scales, avs, rvs, cov_sar, Ndim, lnprob, levid,
+                    chi2min, dists[idxs, imc], reds[idxs, imc],
+                    dreds[idxs, imc], logwts[idxs, imc])

@@ -1,0 +1,423 @@
+"""Minimal HDF5 reader/writer over the libhdf5 C API (ctypes).
+
+`h5py` is not available in this image, but libhdf5 (1.10) is.  This module
+covers what the fit() path needs:
+
+  * `ResultsFile` -- writes `{save_file}.h5` in the reference's layout
+    (reference fitting.py:1632-1662 dataset names/dtypes/fill values, rows
+    written per object as in fitting.py:1734-1748; `"w-"` semantics: refuse to
+    overwrite);
+  * `read_dataset` / `list_datasets` -- read back plain and compound datasets
+    (used by the tests and to load input catalogues such as the reference's
+    `demos/Orion_l204.7_b-19.2.h5`).
+"""
+import ctypes as C
+import ctypes.util
+import os
+
+import numpy as np
+
+__all__ = ["ResultsFile", "read_dataset", "list_datasets", "write_datasets",
+           "hdf5_available"]
+
+hid_t = C.c_int64
+hsize_t = C.c_uint64
+herr_t = C.c_int
+
+H5F_ACC_RDONLY, H5F_ACC_RDWR, H5F_ACC_TRUNC, H5F_ACC_EXCL = 0, 1, 2, 4
+H5P_DEFAULT, H5S_ALL, H5S_SELECT_SET = 0, 0, 0
+(H5T_INTEGER, H5T_FLOAT, H5T_STRING, H5T_COMPOUND, H5T_ENUM,
+ H5T_ARRAY) = 0, 1, 3, 6, 8, 10
+
+_h5 = None
+
+
+def _candidates():
+    env = os.environ.get("BRUTUS_AMD_HDF5_LIB")
+    if env:
+        yield env
+    for p in ("/opt/conda/lib/libhdf5.so", "/opt/conda/lib/libhdf5.so.103",
+              "/usr/lib/x86_64-linux-gnu/libhdf5_serial.so",
+              "/usr/lib/x86_64-linux-gnu/hdf5/serial/libhdf5.so"):
+        yield p
+    found = ctypes.util.find_library("hdf5")
+    if found:
+        yield found
+
+
+def _lib():
+    global _h5
+    if _h5 is not None:
+        return _h5
+    err = None
+    for cand in _candidates():
+        try:
+            L = C.CDLL(cand)
+            break
+        except OSError as e:  # try the next location
+            err = e
+    else:
+        raise OSError("libhdf5 not found (set BRUTUS_AMD_HDF5_LIB): %s" % err)
+    sig = {
+        "H5open": (herr_t, []),
+        "H5Eset_auto2": (herr_t, [hid_t, C.c_void_p, C.c_void_p]),
+        "H5Fcreate": (hid_t, [C.c_char_p, C.c_uint, hid_t, hid_t]),
+        "H5Fopen": (hid_t, [C.c_char_p, C.c_uint, hid_t]),
+        "H5Fclose": (herr_t, [hid_t]),
+        "H5Fflush": (herr_t, [hid_t, C.c_int]),
+        "H5Screate_simple": (hid_t, [C.c_int, C.POINTER(hsize_t), C.POINTER(hsize_t)]),
+        "H5Sclose": (herr_t, [hid_t]),
+        "H5Sselect_hyperslab": (herr_t, [hid_t, C.c_int, C.POINTER(hsize_t),
+                                         C.POINTER(hsize_t), C.POINTER(hsize_t),
+                                         C.POINTER(hsize_t)]),
+        "H5Sget_simple_extent_ndims": (C.c_int, [hid_t]),
+        "H5Sget_simple_extent_dims": (C.c_int, [hid_t, C.POINTER(hsize_t),
+                                                C.POINTER(hsize_t)]),
+        "H5Dcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t, hid_t, hid_t]),
+        "H5Dopen2": (hid_t, [hid_t, C.c_char_p, hid_t]),
+        "H5Dwrite": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
+        "H5Dread": (herr_t, [hid_t, hid_t, hid_t, hid_t, hid_t, C.c_void_p]),
+        "H5Dget_space": (hid_t, [hid_t]),
+        "H5Dget_type": (hid_t, [hid_t]),
+        "H5Dclose": (herr_t, [hid_t]),
+        "H5Tcreate": (hid_t, [C.c_int, C.c_size_t]),
+        "H5Tinsert": (herr_t, [hid_t, C.c_char_p, C.c_size_t, hid_t]),
+        "H5Tarray_create2": (hid_t, [hid_t, C.c_uint, C.POINTER(hsize_t)]),
+        "H5Tcopy": (hid_t, [hid_t]),
+        "H5Tset_size": (herr_t, [hid_t, C.c_size_t]),
+        "H5Tclose": (herr_t, [hid_t]),
+        "H5Tget_class": (C.c_int, [hid_t]),
+        "H5Tget_size": (C.c_size_t, [hid_t]),
+        "H5Tget_sign": (C.c_int, [hid_t]),
+        "H5Tget_nmembers": (C.c_int, [hid_t]),
+        "H5Tget_member_name": (C.c_void_p, [hid_t, C.c_uint]),
+        "H5Tget_member_offset": (C.c_size_t, [hid_t, C.c_uint]),
+        "H5Tget_member_type": (hid_t, [hid_t, C.c_uint]),
+        "H5Tget_array_ndims": (C.c_int, [hid_t]),
+        "H5Tget_array_dims2": (C.c_int, [hid_t, C.POINTER(hsize_t)]),
+        "H5Tget_super": (hid_t, [hid_t]),
+        "H5free_memory": (herr_t, [C.c_void_p]),
+        "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]),
+        "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
+        "H5Gclose": (herr_t, [hid_t]),
+        "H5Gget_num_objs": (herr_t, [hid_t, C.POINTER(hsize_t)]),
+        "H5Gget_objname_by_idx": (C.c_ssize_t, [hid_t, hsize_t, C.c_char_p, C.c_size_t]),
+        "H5Gget_objtype_by_idx": (C.c_int, [hid_t, hsize_t]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    L.H5open()
+    L.H5Eset_auto2(0, None, None)   # we raise Python exceptions instead
+    _h5 = L
+    return L
+
+
+def hdf5_available():
+    try:
+        _lib()
+        return True
+    except OSError:
+        return False
+
+
+def _native(name):
+    return hid_t.in_dll(_lib(), name).value
+
+
+_NP2H5 = {"f4": "H5T_NATIVE_FLOAT_g", "f8": "H5T_NATIVE_DOUBLE_g",
+          "i1": "H5T_NATIVE_INT8_g", "i2": "H5T_NATIVE_INT16_g",
+          "i4": "H5T_NATIVE_INT32_g", "i8": "H5T_NATIVE_INT64_g",
+          "u1": "H5T_NATIVE_UINT8_g", "u2": "H5T_NATIVE_UINT16_g",
+          "u4": "H5T_NATIVE_UINT32_g", "u8": "H5T_NATIVE_UINT64_g",
+          "b1": "H5T_NATIVE_INT8_g"}
+
+
+def _h5type(dt):
+    """numpy dtype -> (hid, must_close).  Structured dtypes become compounds,
+    sub-array fields become H5T_ARRAY, 'S' becomes fixed-length strings."""
+    L = _lib()
+    dt = np.dtype(dt)
+    if dt.names:
+        tid = L.H5Tcreate(H5T_COMPOUND, dt.itemsize)
+        for name in dt.names:
+            sub, off = dt.fields[name][:2]
+            mid, close = _h5type(sub)
+            L.H5Tinsert(tid, name.encode(), off, mid)
+            if close:
+                L.H5Tclose(mid)
+        return tid, True
+    if dt.subdtype is not None:
+        base, shape = dt.subdtype
+        bid, close = _h5type(base)
+        dims = (hsize_t * len(shape))(*shape)
+        tid = L.H5Tarray_create2(bid, len(shape), dims)
+        if close:
+            L.H5Tclose(bid)
+        return tid, True
+    if dt.kind == "S":
+        tid = L.H5Tcopy(_native("H5T_C_S1_g"))
+        L.H5Tset_size(tid, max(1, dt.itemsize))
+        return tid, True
+    key = dt.kind + str(dt.itemsize)
+    if key not in _NP2H5:
+        raise TypeError("unsupported dtype for HDF5: %r" % dt)
+    return _native(_NP2H5[key]), False
+
+
+def _nptype(tid):
+    """HDF5 datatype -> numpy dtype (native byte order)."""
+    L = _lib()
+    cls = L.H5Tget_class(tid)
+    size = L.H5Tget_size(tid)
+    if cls == H5T_INTEGER:
+        return np.dtype(("i" if L.H5Tget_sign(tid) else "u") + str(size))
+    if cls == H5T_FLOAT:
+        return np.dtype("f" + str(size))
+    if cls == H5T_STRING:
+        return np.dtype("S" + str(size))
+    if cls == H5T_ENUM:
+        sup = L.H5Tget_super(tid)
+        out = _nptype(sup)
+        L.H5Tclose(sup)
+        return out
+    if cls == H5T_ARRAY:
+        nd = L.H5Tget_array_ndims(tid)
+        dims = (hsize_t * nd)()
+        L.H5Tget_array_dims2(tid, dims)
+        sup = L.H5Tget_super(tid)
+        base = _nptype(sup)
+        L.H5Tclose(sup)
+        return np.dtype((base, tuple(int(d) for d in dims)))
+    if cls == H5T_COMPOUND:
+        names, formats, offsets = [], [], []
+        for i in range(L.H5Tget_nmembers(tid)):
+            p = L.H5Tget_member_name(tid, i)
+            names.append(C.string_at(p).decode())
+            L.H5free_memory(p)
+            mt = L.H5Tget_member_type(tid, i)
+            formats.append(_nptype(mt))
+            L.H5Tclose(mt)
+            offsets.append(L.H5Tget_member_offset(tid, i))
+        return np.dtype(dict(names=names, formats=formats, offsets=offsets,
+                             itemsize=size))
+    raise TypeError("unsupported HDF5 type class %d" % cls)
+
+
+def _check(h, what):
+    if h < 0:
+        raise OSError("HDF5 error in %s" % what)
+    return h
+
+
+class _File(object):
+    def __init__(self, path, mode):
+        L = _lib()
+        self.L = L
+        b = os.fsencode(path)
+        if mode == "r":
+            self.fid = L.H5Fopen(b, H5F_ACC_RDONLY, H5P_DEFAULT)
+        elif mode == "r+":
+            self.fid = L.H5Fopen(b, H5F_ACC_RDWR, H5P_DEFAULT)
+        elif mode == "w-":
+            if os.path.exists(path):
+                raise OSError("Unable to create file (file exists): %s" % path)
+            self.fid = L.H5Fcreate(b, H5F_ACC_EXCL, H5P_DEFAULT, H5P_DEFAULT)
+        elif mode == "w":
+            self.fid = L.H5Fcreate(b, H5F_ACC_TRUNC, H5P_DEFAULT, H5P_DEFAULT)
+        else:
+            raise ValueError(mode)
+        if self.fid < 0:
+            raise OSError("Unable to open %s (mode %s)" % (path, mode))
+        self._dsets = {}
+
+    def create_dataset(self, name, data):
+        L = self.L
+        data = np.ascontiguousarray(data)
+        tid, close = _h5type(data.dtype)
+        shape = data.shape if data.ndim else (1,)
+        dims = (hsize_t * len(shape))(*shape)
+        sid = _check(L.H5Screate_simple(len(shape), dims, None), "H5Screate_simple")
+        did = _check(L.H5Dcreate2(self.fid, name.encode(), tid, sid, H5P_DEFAULT,
+                                  H5P_DEFAULT, H5P_DEFAULT), "H5Dcreate2 " + name)
+        if data.size:
+            _check(L.H5Dwrite(did, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                              data.ctypes.data_as(C.c_void_p)), "H5Dwrite " + name)
+        L.H5Sclose(sid)
+        self._dsets[name] = (did, tid, close, tuple(shape), data.dtype)
+
+    def write_rows(self, name, start, rows):
+        """Overwrite rows [start, start+len(rows)) along axis 0."""
+        L = self.L
+        did, tid, _, shape, dt = self._dsets[name]
+        rows = np.ascontiguousarray(rows, dtype=dt)
+        n = rows.shape[0]
+        if n == 0:
+            return
+        fsp = L.H5Dget_space(did)
+        nd = len(shape)
+        st = (hsize_t * nd)(*([start] + [0] * (nd - 1)))
+        cnt = (hsize_t * nd)(*([n] + list(shape[1:])))
+        _check(L.H5Sselect_hyperslab(fsp, H5S_SELECT_SET, st, None, cnt, None),
+               "H5Sselect_hyperslab")
+        msp = L.H5Screate_simple(nd, cnt, None)
+        _check(L.H5Dwrite(did, tid, msp, fsp, H5P_DEFAULT,
+                          rows.ctypes.data_as(C.c_void_p)), "H5Dwrite rows " + name)
+        L.H5Sclose(msp)
+        L.H5Sclose(fsp)
+
+    def flush(self):
+        self.L.H5Fflush(self.fid, 1)
+
+    def close(self):
+        L = self.L
+        for did, tid, close, _, _ in self._dsets.values():
+            L.H5Dclose(did)
+            if close:
+                L.H5Tclose(tid)
+        self._dsets = {}
+        if self.fid is not None and self.fid >= 0:
+            L.H5Fclose(self.fid)
+        self.fid = None
+
+
+def write_datasets(path, arrays, mode="w"):
+    """Write a dict of arrays as root-level datasets (test/utility helper)."""
+    f = _File(path, mode)
+    try:
+        for k, v in arrays.items():
+            f.create_dataset(k, v)
+    finally:
+        f.close()
+
+
+def list_datasets(path, group="/"):
+    L = _lib()
+    f = _File(path, "r")
+    try:
+        gid = _check(L.H5Gopen2(f.fid, group.encode(), H5P_DEFAULT), "H5Gopen2")
+        n = hsize_t()
+        L.H5Gget_num_objs(gid, C.byref(n))
+        names = []
+        for i in range(n.value):
+            buf = C.create_string_buffer(1024)
+            L.H5Gget_objname_by_idx(gid, i, buf, 1024)
+            names.append(buf.value.decode())
+        L.H5Gclose(gid)
+        return names
+    finally:
+        f.close()
+
+
+def read_dataset(path, name):
+    """Read a whole dataset into a numpy array (compound -> structured)."""
+    L = _lib()
+    f = _File(path, "r")
+    try:
+        did = _check(L.H5Dopen2(f.fid, name.encode(), H5P_DEFAULT),
+                     "H5Dopen2 " + name)
+        ftid = L.H5Dget_type(did)
+        dt = _nptype(ftid)
+        sid = L.H5Dget_space(did)
+        nd = L.H5Sget_simple_extent_ndims(sid)
+        dims = (hsize_t * max(nd, 1))()
+        if nd > 0:
+            L.H5Sget_simple_extent_dims(sid, dims, None)
+        shape = tuple(int(d) for d in dims[:nd])
+        out = np.empty(shape, dtype=dt)
+        mtid, close = _h5type(dt)
+        if out.size:
+            _check(L.H5Dread(did, mtid, H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                             out.ctypes.data_as(C.c_void_p)), "H5Dread " + name)
+        if close:
+            L.H5Tclose(mtid)
+        L.H5Sclose(sid)
+        L.H5Tclose(ftid)
+        L.H5Dclose(did)
+        return out
+    finally:
+        f.close()
+
+
+class ResultsFile(object):
+    """The fit() output file, reference layout (fitting.py:1632-1662).
+
+    Rows are staged in RAM and written to disk every `flush_every` objects
+    (and on close), so an interrupted run keeps everything up to the last
+    flush -- the purpose of the reference's `running_io=True` -- without one
+    tiny HDF5 write per dataset per object.  With `running_io=False`
+    everything is written once at the end (fitting.py:1784-1798).
+    """
+
+    def __init__(self, path, Ndata, Ndraws, data_labels, save_dar_draws,
+                 running_io=True, flush_every=256):
+        self.file = _File(path, "w-")
+        self.Ndata, self.Ndraws = Ndata, Ndraws
+        self.running_io = running_io
+        self.flush_every = max(1, int(flush_every))
+        full = lambda shape, v, dt: np.full(shape, v, dtype=dt)
+        nd = (Ndata, Ndraws)
+        self.arrays = {
+            "model_idx": full(nd, -99, "int32"),
+            "ml_scale": full(nd, 1, "float32"),
+            "ml_av": full(nd, 0, "float32"),
+            "ml_rv": full(nd, 0, "float32"),
+            "ml_cov_sar": full(nd + (3, 3), 0, "float32"),
+            "obj_log_post": full(nd, 0, "float32"),
+            "obj_log_evid": full((Ndata,), 0, "float32"),
+            "obj_chi2min": full((Ndata,), 0, "float32"),
+            "obj_Nbands": full((Ndata,), 0, "int16"),
+        }
+        if save_dar_draws:
+            for k in ("samps_dist", "samps_red", "samps_dred", "samps_logp"):
+                self.arrays[k] = full(nd, 1, "float32")
+        self.save_dar_draws = save_dar_draws
+        if data_labels is not None:
+            self.file.create_dataset("labels", np.asarray(data_labels))
+        if running_io:
+            for k, v in self.arrays.items():
+                self.file.create_dataset(k, v)
+            self.file.flush()
+        self._lo = 0   # first row not yet on disk
+        self._hi = 0   # one past the last row staged
+
+    def write_row(self, i, results):
+        a = self.arrays
+        a["model_idx"][i] = results[0]
+        a["ml_scale"][i] = results[1]
+        a["ml_av"][i] = results[2]
+        a["ml_rv"][i] = results[3]
+        a["ml_cov_sar"][i] = results[4]
+        a["obj_Nbands"][i] = results[5]
+        a["obj_log_post"][i] = results[6]
+        a["obj_log_evid"][i] = results[7]
+        a["obj_chi2min"][i] = results[8]
+        if self.save_dar_draws:
+            a["samps_dist"][i] = results[9]
+            a["samps_red"][i] = results[10]
+            a["samps_dred"][i] = results[11]
+            a["samps_logp"][i] = results[12]
+        self._hi = max(self._hi, i + 1)
+        if self.running_io and self._hi - self._lo >= self.flush_every:
+            self._flush_rows()
+
+    def _flush_rows(self):
+        if self._hi > self._lo:
+            for k, v in self.arrays.items():
+                self.file.write_rows(k, self._lo, v[self._lo:self._hi])
+            self.file.flush()
+            self._lo = self._hi
+
+    def close(self):
+        if self.file is None:
+            return
+        try:
+            if self.running_io:
+                self._flush_rows()
+            else:
+                for k, v in self.arrays.items():
+                    self.file.create_dataset(k, v)
+        finally:
+            self.file.close()
+            self.file = None

@@ -1,0 +1,103 @@
+"""Host-side priors on the fit() path (numpy, float64).
+
+Counterparts of `brutus/pdf.py`: `imf_lnprior` (pdf.py:38-108),
+`ps1_MrLF_lnprior` (pdf.py:111-141), `parallax_lnprior` (pdf.py:144-175),
+`scale_parallax_lnprior` (pdf.py:178-222), `parallax_to_scale`
+(pdf.py:225-260).  The full-grid application of the scale-parallax term is
+done on the device (k_finalize); these host versions serve the public API and
+the Monte Carlo stage of `lnpost`, which acts on selected models only.
+"""
+import os
+
+import numpy as np
+
+__all__ = ["imf_lnprior", "ps1_MrLF_lnprior", "parallax_lnprior",
+           "scale_parallax_lnprior", "parallax_to_scale"]
+
+
+def _kroupa_segment(m, alpha_low, alpha_high, mass_break):
+    out = np.full(m.shape, -np.inf)
+    lo = (m > 0.08) & (m <= mass_break)
+    hi = m > mass_break
+    with np.errstate(all="ignore"):
+        out[lo] = -alpha_low * np.log(m[lo])
+        out[hi] = (-alpha_high * np.log(m[hi])
+                   + (alpha_high - alpha_low) * np.log(mass_break))
+    return out
+
+
+def imf_lnprior(mgrid, alpha_low=1.3, alpha_high=2.3, mass_break=0.5,
+                mgrid2=None):
+    """Kroupa broken-power-law ln prior over initial mass; -inf at or below
+    the hydrogen-burning limit 0.08 Msun (reference pdf.py:72-108)."""
+    m = np.asarray(mgrid, dtype=np.float64)
+    lnp = _kroupa_segment(m, alpha_low, alpha_high, mass_break)
+    n_low = mass_break ** (1. - alpha_low) / (alpha_high - 1.)
+    n_high = (0.08 ** (1. - alpha_low) - mass_break ** (1. - alpha_low)) \
+        / (alpha_low - 1.)
+    norm = n_low + n_high
+    if mgrid2 is not None:
+        lnp = lnp + _kroupa_segment(np.asarray(mgrid2, dtype=np.float64),
+                                    alpha_low, alpha_high, mass_break)
+        norm = n_low ** 2 + n_high ** 2 + 2 * n_low * n_high
+    return lnp - np.log(norm)
+
+
+_PS_TABLE = None
+
+
+def ps1_MrLF_lnprior(Mr):
+    """PS1 r-band luminosity-function prior: linear interpolation (with linear
+    extrapolation) of a two-column (M_r, ln LF) table (reference pdf.py:111-141).
+
+    The table is looked up at $BRUTUS_AMD_PSLF, else next to this file as
+    `PSMrLF_lnprior.dat` (the reference ships it as brutus/PSMrLF_lnprior.dat).
+    """
+    global _PS_TABLE
+    if _PS_TABLE is None:
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.environ.get("BRUTUS_AMD_PSLF",
+                              os.path.join(here, "PSMrLF_lnprior.dat"))
+        if not os.path.exists(path):
+            raise IOError("PS1 luminosity-function table not found at %s; copy "
+                          "brutus/PSMrLF_lnprior.dat there or set "
+                          "BRUTUS_AMD_PSLF" % path)
+        _PS_TABLE = np.loadtxt(path).T
+    gx, gy = _PS_TABLE
+    Mr = np.asarray(Mr, dtype=np.float64)
+    out = np.interp(Mr, gx, gy)
+    lo, hi = Mr < gx[0], Mr > gx[-1]
+    out = np.where(lo, gy[0] + (Mr - gx[0]) * (gy[1] - gy[0]) / (gx[1] - gx[0]), out)
+    out = np.where(hi, gy[-1] + (Mr - gx[-1]) * (gy[-1] - gy[-2]) / (gx[-1] - gx[-2]), out)
+    return out
+
+
+def parallax_lnprior(parallaxes, p_meas, p_err):
+    """Gaussian ln prior in parallax; flat when no measurement (pdf.py:166-173)."""
+    parallaxes = np.asarray(parallaxes, dtype=np.float64)
+    if not (np.isfinite(p_meas) and np.isfinite(p_err)):
+        return np.zeros_like(parallaxes)
+    with np.errstate(all="ignore"):
+        return -0.5 * ((parallaxes - p_meas) ** 2 / p_err ** 2
+                       + np.log(2. * np.pi * p_err ** 2))
+
+
+def parallax_to_scale(p_meas, p_err, snr_lim=4.):
+    """Moments of s = p^2 for a Normal parallax (pdf.py:249-258)."""
+    if p_meas / p_err > snr_lim:
+        pm = max(0., p_meas)
+        return pm ** 2 + p_err ** 2, np.sqrt(2 * p_err ** 4 + 4 * pm ** 2 * p_err ** 2)
+    return 1e-20, 1e20
+
+
+def scale_parallax_lnprior(scales, scale_errs, p_meas, p_err, snr_lim=4.):
+    """Gaussian ln prior in scale s ~ p^2, applied only for S/N > snr_lim
+    (pdf.py:209-220)."""
+    scales = np.asarray(scales, dtype=np.float64)
+    if not (np.isfinite(p_meas) and np.isfinite(p_err)
+            and p_meas / p_err > snr_lim):
+        return np.zeros_like(scales)
+    s_mean, s_std = parallax_to_scale(p_meas, p_err, snr_lim=snr_lim)
+    with np.errstate(all="ignore"):
+        var = s_std ** 2 + np.asarray(scale_errs, dtype=np.float64) ** 2
+        return -0.5 * ((scales - s_mean) ** 2 / var + np.log(2. * np.pi * var))

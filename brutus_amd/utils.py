@@ -1,0 +1,80 @@
+"""Host-side helpers on the fit() path (numpy, float64).
+
+Counterparts of the small utilities the reference keeps in `brutus/utils.py`:
+`_inverse3` (utils.py:71-114), `_chisquare_logpdf` (utils.py:130-176),
+`sample_multivariate_normal` (utils.py:845-905), `magnitude` (utils.py:908-940).
+They act on the few hundred-to-thousand models that survive the device-side
+cuts, never on the full grid.
+"""
+from math import lgamma, log
+
+import numpy as np
+
+__all__ = ["_inverse3", "_chisquare_logpdf", "sample_multivariate_normal",
+           "magnitude", "inv_magnitude"]
+
+
+def _inverse3(A):
+    """Inverse of a stack of 3x3 matrices (..., 3, 3) by the adjugate.
+
+    Rows of the adjugate-transpose are cross products of the other two rows;
+    the determinant is taken as the mean of the three row.cofactor-row dots
+    (same estimator as reference utils.py:96-105, so results agree to rounding).
+    """
+    A = np.asarray(A, dtype=np.float64)
+    r0, r1, r2 = A[..., 0, :], A[..., 1, :], A[..., 2, :]
+    c0 = np.cross(r1, r2)
+    c1 = np.cross(r2, r0)
+    c2 = np.cross(r0, r1)
+    det = ((c0 * r0).sum(-1) + (c1 * r1).sum(-1) + (c2 * r2).sum(-1)) / 3.
+    with np.errstate(all="ignore"):
+        # inverse = cofactor^T / det: cofactor rows become columns
+        return np.stack([c0, c1, c2], axis=-1) / det[..., None, None]
+
+
+def _chisquare_logpdf(x, df, loc=0, scale=1):
+    """ln pdf of a chi-square variate with `df` degrees of freedom; -inf for
+    arguments <= 0 (reference utils.py:161-176)."""
+    y = (np.asarray(x, dtype=np.float64) - loc) / scale
+    half = df / 2.
+    norm = half * log(2.) + lgamma(half)
+    with np.errstate(all="ignore"):
+        out = (half - 1.) * np.log(np.where(y > 0, y, 1.)) - y / 2. - norm - log(scale)
+    out = np.where(y > 0, out, -np.inf)
+    return float(out) if out.ndim == 0 else out
+
+
+def sample_multivariate_normal(mean, cov, size=1, eps=1e-30, rstate=None):
+    """Draw `size` samples from each of N trivariate normals.
+
+    Returns (dim, size, N) like reference utils.py:845-905.  The standard
+    normals are consumed from `rstate` in the reference's order
+    (`normal(size=dim*size*N).reshape(N, dim, size)`), which is what makes
+    seeded runs reproduce the reference draw for draw.
+    """
+    if rstate is None:
+        rstate = np.random
+    mean = np.asarray(mean, dtype=np.float64)
+    if mean.ndim == 1:
+        return rstate.multivariate_normal(mean, cov, size=size)
+    N, d = mean.shape
+    chol = np.linalg.cholesky(cov + eps * np.eye(d)[None, :, :])
+    z = rstate.normal(loc=0, scale=1, size=d * size * N).reshape(N, d, size)
+    draws = mean[:, :, None] + np.matmul(chol, z)        # (N, d, size)
+    return np.transpose(draws, (1, 2, 0))
+
+
+def magnitude(phot, err, zeropoints=1.):
+    """Flux densities -> AB magnitudes and errors (reference utils.py:908-940)."""
+    phot = np.asarray(phot, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        mag = -2.5 * np.log10(phot / zeropoints)
+        mag_err = 2.5 / np.log(10.) * np.asarray(err) / phot
+    return mag, mag_err
+
+
+def inv_magnitude(mag, err, zeropoints=1.):
+    """AB magnitudes -> flux densities (reference utils.py:943-975)."""
+    phot = 10. ** (-0.4 * np.asarray(mag, dtype=np.float64)) * zeropoints
+    phot_err = np.asarray(err) * 0.4 * np.log(10.) * phot
+    return phot, phot_err

@@ -1,0 +1,136 @@
+/*
+ * brutus_amd.h -- C ABI of the MI355X (gfx950) brute-force photometric fitter.
+ *
+ * The upstream reference (joshspeagle/brutus) is pure Python; its "native" layer
+ * is four numba-jitted loops.  This library replaces exactly that layer plus
+ * the full-grid part of `loglike`/`lnpost`:
+ *
+ *   brutus/utils.py:286-347     _get_seds
+ *   brutus/fitting.py:34-271    _optimize_fit_mag
+ *   brutus/fitting.py:274-427   _optimize_fit_flux
+ *   brutus/fitting.py:430-576   _get_sed_mle
+ *   brutus/fitting.py:579-820   loglike            (whole function)
+ *   brutus/fitting.py:976-991   lnpost: parallax clip + first `wt_thresh` cut
+ *   brutus/utils.py:130-176     _chisquare_logpdf
+ *   brutus/cluster.py:336-414   isochrone_loglike hot block (see brutus_cluster_*)
+ *
+ * Conventions
+ *   - every pointer prefixed d_ is a DEVICE pointer (HBM), h_ is a host pointer;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *   - all functions return 0 on success, a negative BRUTUS_E* code on failure;
+ *     brutus_last_error() returns a human-readable message for the calling thread;
+ *   - no allocation happens inside the hot calls: the caller owns every buffer
+ *     (sizes from the *_bytes() queries) -- PyTorch tensors in the Python host.
+ *
+ * The Python host (brutus_amd/fitting.py) binds these with ctypes; see
+ * INTEGRATION.md for the stub a maintainer of the reference would add.
+ */
+#ifndef BRUTUS_AMD_H
+#define BRUTUS_AMD_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BRUTUS_ABI_VERSION 1
+#define BRUTUS_MAX_FILT 32   /* bands per fit (device register budget)            */
+#define BRUTUS_MAX_BATCH 256 /* stars per brutus_*_batch call                     */
+#define BRUTUS_NVALS 11      /* lnlike, chi2, scale, av, rv, icov[00,01,02,11,12,22] */
+
+#define BRUTUS_OK 0
+#define BRUTUS_EINVAL (-1)    /* bad argument                                      */
+#define BRUTUS_ENOMEM (-2)    /* workspace / record buffer too small               */
+#define BRUTUS_EHIP (-3)      /* HIP runtime error (message in brutus_last_error)  */
+#define BRUTUS_ENOCONV (-4)   /* iteration cap hit (the reference would spin)      */
+
+/* Keyword arguments of fitting.loglike (fitting.py:579-585) plus lnpost's
+ * wt_thresh (fitting.py:823-827).  av_gauss=None maps to (0, 1e6) on the host
+ * exactly like fitting.py:695-696. */
+typedef struct brutus_params {
+    double avlim[2];
+    double av_gauss[2];
+    double rvlim[2];
+    double rv_gauss[2];
+    double ltol;           /* flux-phase tolerance; mag-phase tol = 2.5*ltol     */
+    double ltol_subthresh;
+    double init_thresh;    /* logl_initthresh                                     */
+    double wt_thresh;      /* lnpost first cut; only used by brutus_fit_batch     */
+    int32_t dim_prior;     /* logl_dim_prior                                      */
+    int32_t max_iter;      /* safety cap on mag sweeps / flux iterations (0=256)  */
+} brutus_params;
+
+int brutus_abi_version(void);
+const char *brutus_last_error(void);
+
+/* ---- model grid ------------------------------------------------------------
+ * `utils.load_models` (utils.py:588-591) returns models as (Nmodel, Nfilt, 3)
+ * float32 = (mag, R, dR/dRv) per band.  The kernels stream a band-major
+ * structure-of-arrays copy: [nfilt_pad][3][nmodel_pad] float32 with
+ * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters) and
+ * nmodel_pad = nmodel rounded up to 256.  Padded entries are zero. */
+int brutus_padded_filters(int nfilt);              /* <0 if nfilt unsupported     */
+size_t brutus_grid_soa_bytes(int64_t nmodel, int nfilt);
+int brutus_grid_relayout(const float *d_models_aos, int64_t nmodel, int nfilt,
+                         float *d_grid_soa, void *stream);
+
+/* ---- per-star grid likelihood ---------------------------------------------
+ * Inputs for a batch of `nstar` stars (row-major, C order):
+ *   d_flux, d_err  (nstar, nfilt) float64 maggies;  d_mask (nstar, nfilt) uint8;
+ *   d_parallax, d_parallax_err (nstar,) float64 mas, NaN = no measurement
+ *   (the notebooks' convention; `None` in the Python API maps to NaN with
+ *   has_parallax=0, see fitting.py:749-756 vs :976-982).
+ */
+size_t brutus_workspace_bytes(int64_t nmodel, int nfilt, int nstar);
+
+/* fitting.loglike(..., return_vals=True) for every star of the batch, full-grid
+ * outputs, each plane (nstar, nmodel) float64; d_icov is (6, nstar, nmodel)
+ * holding the unique entries [00, 01, 02, 11, 12, 22] of icov_sar
+ * (fitting.py:563-574).  d_ndim (nstar,) int32.  h_k1/h_k2 (optional, host,
+ * (nstar,) int32) receive the number of magnitude sweeps / flux iterations. */
+int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
+                         int nstar, const double *d_flux, const double *d_err,
+                         const uint8_t *d_mask, const double *d_parallax,
+                         const double *d_parallax_err, int has_parallax,
+                         const brutus_params *params, void *d_workspace,
+                         size_t workspace_bytes, double *d_lnl, double *d_chi2,
+                         double *d_scale, double *d_av, double *d_rv,
+                         double *d_icov, int32_t *d_ndim, int32_t *h_k1,
+                         int32_t *h_k2, void *stream);
+
+/* The fit() hot path: loglike + lnpost's parallax clip + first wt_thresh cut
+ * (fitting.py:976-991), emitting only the selected models, in ascending model
+ * order per star (= np.where order):
+ *   d_sel_idx  (capacity,) int32   model index
+ *   d_sel_vals (BRUTUS_NVALS, capacity) float64
+ *   d_sel_off  (nstar + 1,) int64  record range of star s is [off[s], off[s+1])
+ * Records beyond `capacity` are dropped; off[nstar] always holds the true
+ * total so the caller can re-run brutus_fit_gather with a larger buffer. */
+int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
+                     int nstar, const double *d_flux, const double *d_err,
+                     const uint8_t *d_mask, const double *d_parallax,
+                     const double *d_parallax_err, int has_parallax,
+                     const brutus_params *params, void *d_workspace,
+                     size_t workspace_bytes, int64_t capacity,
+                     int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
+                     int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
+                     void *stream);
+
+/* Re-emit the selection of the last brutus_fit_batch on this workspace. */
+int brutus_fit_gather(int64_t nmodel, int nfilt, int nstar, void *d_workspace,
+                      size_t workspace_bytes, double wt_thresh,
+                      int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
+                      int64_t *d_sel_off, void *stream);
+
+/* Name and average duration (HIP events on `stream`) of the kernels launched
+ * by the last *_batch call; used by bench.py for the roofline line. */
+int brutus_last_timing(int *n_entries, const char **names, float *ms,
+                       int max_entries);
+void brutus_enable_timing(int on);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRUTUS_AMD_H */

@@ -1,0 +1,60 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares
+(no compute calls -- there is no GPU here)."""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, "include", "brutus_amd.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(brutus_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_exports_every_declared_symbol():
+    import ctypes
+    from brutus_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        import __graft_entry__
+        __graft_entry__.build_hip()
+    L = ctypes.CDLL(_lib.LIB_PATH)
+    names = _declared()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(L, n), n
+    # the ctypes table mirrors the header one to one
+    assert sorted(_lib.SIGNATURES) == names
+
+
+def test_abi_version_and_queries():
+    from brutus_amd import _lib
+    L = _lib.lib()
+    assert L.brutus_abi_version() == 1
+    assert L.brutus_padded_filters(6) == 8
+    assert L.brutus_padded_filters(12) == 12
+    assert L.brutus_padded_filters(33) < 0
+    assert L.brutus_grid_soa_bytes(1000, 12) == 12 * 3 * 1024 * 4
+    assert L.brutus_workspace_bytes(750000, 12, 64) > 13 * 8 * 750000 * 64
+    assert L.brutus_workspace_bytes(750000, 40, 64) == 0
+
+
+def test_product_refuses_to_run_without_gpu():
+    import numpy as np
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from brutus_amd import fitting, _lib
+    with pytest.raises(_lib.BrutusError):
+        fitting.loglike(np.ones(6), np.ones(6), np.ones(6, bool),
+                        np.zeros((10, 6, 3), np.float32))
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "brutus_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert "oracle" not in src.replace("no CPU fallback", ""), fn
