@@ -89,3 +89,54 @@ def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
     return dict(flux=flux, err=err, mask=mask, parallax=par, parallax_err=perr,
                 coords=coords, true_idx=idx, true_av=av, true_rv=rv,
                 true_dist=dist)
+
+
+def make_mist_like_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
+    """A lattice-ordered synthetic grid that mimics the structure of the real
+    MIST grid files (reference seds.py:754-765: `mini` x `eep` x `feh`
+    lattice, 61 x 220 x 61 = 818 620 points before invalid models are
+    dropped, ~750k kept): models are ORDERED along the lattice, luminosity and
+    effective temperature vary smoothly with (mini, eep), metallicity nudges
+    the colours, and the SED shape responds to temperature differently from
+    how it responds to extinction -- so, as with real grids, a star's
+    posterior occupies compact runs of the index space instead of the whole
+    grid.  Shapes, dtype and value ranges match `utils.load_models`
+    (reference utils.py:588-591).
+    """
+    rng = np.random.RandomState(seed)
+    n_mini, n_feh = 61, 61
+    n_eep = int(np.ceil(nmodel / float(n_mini * n_feh)))
+    mini = np.linspace(0.5, 2.0, n_mini)
+    eep = np.linspace(202., 808., n_eep)
+    feh = np.linspace(-3., 0.5, n_feh)
+    mm, ee, ff = np.meshgrid(mini, eep, feh, indexing="ij")
+    mm, ee, ff = mm.ravel()[:nmodel], ee.ravel()[:nmodel], ff.ravel()[:nmodel]
+    x = (ee - 202.) / 606.                       # 0 = ZAMS ... 1 = tip of the RGB
+    ms = x < 0.42                                # main sequence up to EEP ~454
+    # log-temperature proxy t in ~[0, 1] (0 = cool, 1 = hot) and absolute mag M
+    t_ms = 0.25 + 0.45 * (mm - 0.5) / 1.5 - 0.08 * (x / 0.42) ** 2
+    t_pm = t_ms - 0.55 * ((x - 0.42) / 0.58) ** 0.7
+    t = np.where(ms, t_ms, t_pm) - 0.04 * (ff + 1.)
+    M_ms = 7.5 - 4.8 * (mm - 0.5) / 1.5 - 0.9 * (x / 0.42)
+    M_pm = M_ms - 5.5 * ((x - 0.42) / 0.58) ** 1.3
+    M = np.where(ms, M_ms, M_pm) + 0.25 * (ff + 1.)
+    lam = np.linspace(0., 1., nfilt)             # 0 = bluest band, 1 = reddest
+    # colour vs temperature: blackbody-like (steep in the blue, flat in the red)
+    colour = (1. - t)[:, None] * (3.2 * (1. - lam) ** 1.6 - 0.9)[None, :]
+    colour += 0.15 * (ff + 1.)[:, None] * (np.exp(-6. * lam))[None, :]   # line blanketing
+    mag = M[:, None] + colour + rng.normal(0., 0.004, size=(nmodel, nfilt))
+    r0 = (1.25 - 1.13 * lam ** 0.8)[None, :] * (1. + 0.03 * (t - 0.4))[:, None]
+    dr = (0.06 - 0.07 * lam)[None, :] * (1. + 0.05 * (t - 0.4))[:, None]
+    models = np.stack([mag, r0, dr], axis=-1).astype(np.float32)
+
+    ltype = np.dtype([('mini', 'f8'), ('eep', 'f8'), ('feh', 'f8'),
+                      ('loga', 'f8'), ('agewt', 'f8')])
+    labels = np.zeros(nmodel, dtype=ltype)
+    labels['mini'], labels['eep'], labels['feh'] = mm, ee, ff
+    labels['loga'] = 10.1 - 2.5 * np.log10(mm) + 0.4 * x
+    labels['agewt'] = 0.05 + np.abs(np.gradient(labels['loga']))
+    mtype = np.dtype([(n, '?') for n in ltype.names])
+    labels_mask = np.zeros(1, dtype=mtype)
+    for n in ('mini', 'eep', 'feh'):
+        labels_mask[n] = True
+    return models, labels, labels_mask

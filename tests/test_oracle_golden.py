@@ -69,3 +69,21 @@ def test_helpers_match_reference():
     mag, magerr = O.magnitude(z["mag_flux"], z["mag_ferr"])
     assert relerr(z["mag_out"], mag) < 1e-15
     assert relerr(z["magerr_out"], magerr) < 1e-15
+
+
+@pytest.mark.parametrize("path", loglike_golden_files(),
+                         ids=lambda p: os.path.basename(p)[8:-4])
+def test_c_oracle_matches_reference(path):
+    """oracle/loglike_ref.c (the CPU-baseline port) against the same vectors."""
+    import __graft_entry__
+    from oracle import c_oracle
+    __graft_entry__.build_oracle()
+    z, kw, par, perr = load_loglike_case(path)
+    tr = {}
+    out = c_oracle.loglike(z["flux"], z["err"], z["mask"], z["models"],
+                           parallax=par, parallax_err=perr, trace=tr, **kw)
+    assert out[1] == int(z["Ndim"])
+    assert tr["K2"] == int(z["K2"]) and tr["nsel"] == int(z["nsel"])
+    for name, got in (("lnl", out[0]), ("chi2", out[2]), ("scale", out[3]),
+                      ("av", out[4]), ("rv", out[5]), ("icov", out[6])):
+        assert relerr(z[name], got) < 1e-11, name
