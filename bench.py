@@ -113,7 +113,7 @@ def main():
     # ---- grid: built once on rank 0, broadcast in kernel layout -------------
     models = None
     if rank == 0:
-        models, _, _ = synth.make_grid(nmodel, nfilt)
+        models, _, _ = synth.make_mist_like_grid(nmodel, nfilt)
         grid = fitting.DeviceGrid(models, device=dev)
     if world > 1:
         from brutus_amd import parallel
@@ -129,7 +129,7 @@ def main():
     seed = {2: 1, 3: 2}[args.config]
     if models is None:
         # ranks > 0 need the f32 coefficients only to synthesise their stars
-        models, _, _ = synth.make_grid(nmodel, nfilt)
+        models, _, _ = synth.make_mist_like_grid(nmodel, nfilt)
     B = args.batch
     nb_pool = max(1, min(4, args.steps))       # distinct batches cycled through
     stars = synth.make_stars(models, B * nb_pool, seed=seed + 1000 * rank,

@@ -49,8 +49,8 @@ SIGNATURES = {
     "brutus_fit_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                                    _i32, C.POINTER(Params), _vp, _sz, _i64, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp]),
-    "brutus_fit_gather": (C.c_int, [_i64, _i32, _i32, _vp, _sz, _dbl, _i64, _vp,
-                                    _vp, _vp, _vp]),
+    "brutus_fit_gather": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(Params), _vp,
+                                    _sz, _i64, _vp, _vp, _vp, _vp]),
     "brutus_last_timing": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                      C.POINTER(C.c_float), C.c_int]),
     "brutus_enable_timing": (None, [C.c_int]),

@@ -132,7 +132,7 @@ class _Engine(object):
         self.torch = _torch()
         self.L = _lib.lib()
         self.grid = grid
-        per_star = 13 * 8 * grid.nmodel + 4096
+        per_star = (14 * 8 + 4) * grid.nmodel + 65536
         nb = int(max(1, min(_lib.MAX_BATCH, mem_budget // per_star)))
         if max_batch is not None:
             nb = max(1, min(nb, int(max_batch)))
@@ -250,8 +250,8 @@ class _Engine(object):
                                        device=g.device)
                 ws = self._workspace(S)
                 _lib.check(L.brutus_fit_gather(
-                    g.nmodel, g.nfilt, S, ws.data_ptr(), ws.numel(),
-                    params.wt_thresh, cap, sel_idx.data_ptr(),
+                    g.soa.data_ptr(), g.nmodel, g.nfilt, S, params,
+                    ws.data_ptr(), ws.numel(), cap, sel_idx.data_ptr(),
                     sel_vals.data_ptr(), sel_off.data_ptr(), _stream_ptr(torch)))
             self._sel_bufs = (sel_idx, sel_vals)
             idx = sel_idx[:total].cpu().numpy()

@@ -115,10 +115,11 @@ def make_mist_like_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
     ms = x < 0.42                                # main sequence up to EEP ~454
     # log-temperature proxy t in ~[0, 1] (0 = cool, 1 = hot) and absolute mag M
     t_ms = 0.25 + 0.45 * (mm - 0.5) / 1.5 - 0.08 * (x / 0.42) ** 2
-    t_pm = t_ms - 0.55 * ((x - 0.42) / 0.58) ** 0.7
+    xp = np.clip((x - 0.42) / 0.58, 0., None)
+    t_pm = t_ms - 0.55 * xp ** 0.7
     t = np.where(ms, t_ms, t_pm) - 0.04 * (ff + 1.)
     M_ms = 7.5 - 4.8 * (mm - 0.5) / 1.5 - 0.9 * (x / 0.42)
-    M_pm = M_ms - 5.5 * ((x - 0.42) / 0.58) ** 1.3
+    M_pm = M_ms - 5.5 * xp ** 1.3
     M = np.where(ms, M_ms, M_pm) + 0.25 * (ff + 1.)
     lam = np.linspace(0., 1., nfilt)             # 0 = bluest band, 1 = reddest
     # colour vs temperature: blackbody-like (steep in the blue, flat in the red)

@@ -67,9 +67,11 @@ const char *brutus_last_error(void);
 
 /* ---- model grid ------------------------------------------------------------
  * `utils.load_models` (utils.py:588-591) returns models as (Nmodel, Nfilt, 3)
- * float32 = (mag, R, dR/dRv) per band.  The kernels stream a band-major
- * structure-of-arrays copy: [nfilt_pad][3][nmodel_pad] float32 with
- * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters) and
+ * float32 = (mag, R, dR/dRv) per band.  The device grid blob holds two copies:
+ * a band-major structure-of-arrays [nfilt_pad][3][nmodel_pad] that the
+ * full-grid scans stream with coalesced loads, followed by a model-major
+ * [nmodel_pad][nfilt_pad][3] copy for the kernels that gather single models.
+ * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters),
  * nmodel_pad = nmodel rounded up to 256.  Padded entries are zero. */
 int brutus_padded_filters(int nfilt);              /* <0 if nfilt unsupported     */
 size_t brutus_grid_soa_bytes(int64_t nmodel, int nfilt);
@@ -118,11 +120,13 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                      int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
                      void *stream);
 
-/* Re-emit the selection of the last brutus_fit_batch on this workspace. */
-int brutus_fit_gather(int64_t nmodel, int nfilt, int nstar, void *d_workspace,
-                      size_t workspace_bytes, double wt_thresh,
-                      int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
-                      int64_t *d_sel_off, void *stream);
+/* Re-emit the selection of the last brutus_fit_batch on this workspace (same
+ * grid, params and nstar) into a larger record buffer. */
+int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
+                      int nstar, const brutus_params *params, void *d_workspace,
+                      size_t workspace_bytes, int64_t capacity,
+                      int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
+                      void *stream);
 
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */
