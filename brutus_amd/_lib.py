@@ -54,6 +54,7 @@ SIGNATURES = {
     "brutus_last_timing": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                      C.POINTER(C.c_float), C.c_int]),
     "brutus_enable_timing": (None, [C.c_int]),
+    "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
 }
 
 

@@ -739,6 +739,14 @@ k_scatter(int64_t nmodel, int ntile, Planes pl, const double *__restrict__ pmax,
     }
 }
 
+// PMC calibration stream with the fused scan's access widths: 4-byte loads and
+// 8-byte stores per lane, a known byte count (see tools/pmc_traffic.py).
+__global__ void k_calib_stream(const float *__restrict__ in, double *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = (double)in[i];
+}
+
 __global__ void k_set_i32(int32_t *p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -1931,6 +1939,13 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
     HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);
     tm.collect();
+    return 0;
+}
+
+int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *stream) {
+    if (!d_in || !d_out || n <= 0) return fail(BRUTUS_EINVAL, "bad calibration arguments");
+    hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(TILE), 0, (hipStream_t)stream, d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

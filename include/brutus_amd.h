@@ -128,6 +128,13 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
                       int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
                       void *stream);
 
+/* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
+ * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
+ * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated
+ * on a known byte count (MI355X_MICROARCH.md, HBM section). */
+int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
+                             void *stream);
+
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */
 int brutus_last_timing(int *n_entries, const char **names, float *ms,
