@@ -729,7 +729,7 @@ class BruteForce(object):
              apply_dlabels=True, data_coords=None,
              return_distreds=True, logl_dim_prior=True, ltol=3e-2,
              ltol_subthresh=1e-2, logl_initthresh=5e-3, mem_lim=8000.,
-             rstate=None):
+             rstate=None, rstate_per_object=None):
         """Generator yielding, per object and in input order, the tuple
         `(model_idx, scales, avs, rvs, cov_sar, Ndim, lnprob, levid, chi2min
         [, dists, reds, dreds, logwts])` of reference fitting.py:2059-2065.
@@ -737,6 +737,10 @@ class BruteForce(object):
         The grid scan runs on the device for a batch of objects at a time; the
         yields still arrive one object at a time and consume `rstate` in the
         reference's order, so a seeded run reproduces the reference's draws.
+
+        `rstate_per_object` (extension, default None): a callable `i ->
+        RandomState` giving every object its own stream; results then do not
+        depend on object order or on how a catalogue is sharded over GPUs.
         """
         if Nmc_prior <= 0:
             raise ValueError("Nmc_prior must be positive (the reference "
@@ -792,11 +796,12 @@ class BruteForce(object):
                                                 parallax_err[a:b], params,
                                                 lnprior_ext, a, wt_thresh)
             for i, rec in zip(range(a, b), recs):
+                rs = rstate if rstate_per_object is None else rstate_per_object(i)
                 yield self._finish_star(rec, parallax[i], parallax_err[i],
                                         data_coords[i], Nmc_prior, lnprior,
                                         wt_thresh, cdf_thresh, lngalprior,
                                         lndustprior, dustfile, dlabels, avlim,
-                                        rvlim, mem_lim, rstate, apply_av_prior,
+                                        rvlim, mem_lim, rs, apply_av_prior,
                                         Ndraws, return_distreds)
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,

@@ -71,3 +71,69 @@ def gather_rows(local_rows, dst=0):
     for part in out:
         rows.extend(part)
     return rows
+
+
+def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
+                seed0=0, **fit_kwargs):
+    """`BruteForce.fit` over all ranks of the default process group.
+
+    Every rank fits the contiguous shard `shard_range(Ndata, rank, world)` on
+    its own GPU (no collective on the data path); rank 0 gathers the per-object
+    rows in rank order and writes `{save_file}.h5` in the reference layout.
+    Object `i` draws from `RandomState(seed0 + i)`, so the file is identical
+    for any number of ranks (the reference's single sequential stream,
+    fitting.py:2039-2053, would make results depend on the sharding).
+
+    `fit_kwargs` are `BruteForce.fit` keyword arguments.  Returns the number of
+    objects this rank fitted.
+    """
+    import torch.distributed as dist
+    from . import h5io
+    rank, world = dist.get_rank(), dist.get_world_size()
+    kw = dict(fit_kwargs)
+    Ndraws = kw.pop("Ndraws", 250)
+    save_dar_draws = kw.pop("save_dar_draws", True)
+    running_io = kw.pop("running_io", True)
+    kw.pop("verbose", None)
+    kw.pop("rstate", None)
+    setup_keys = ("phot_offsets", "parallax", "parallax_err", "av_gauss",
+                  "lnprior", "wt_thresh", "cdf_thresh", "apply_agewt",
+                  "apply_grad", "lngalprior", "lndustprior", "dustfile",
+                  "data_coords", "ltol_subthresh", "logl_initthresh", "mag_max",
+                  "merr_max")
+    skw = {k: kw[k] for k in setup_keys if k in kw}
+    (data, data_err, data_mask, data_labels, data_coords, lnprior, lngalprior,
+     lndustprior, av_gauss, wt_thresh, _) = bf._setup(
+        data, data_err, data_mask, data_labels, **skw)
+    Ndata = data.shape[0]
+    lo, hi = shard_range(Ndata, rank, world)
+    fkw = {k: v for k, v in kw.items()
+           if k not in ("phot_offsets", "apply_agewt", "apply_grad", "mag_max",
+                        "merr_max", "parallax", "parallax_err", "data_coords",
+                        "lnprior", "lngalprior", "lndustprior", "av_gauss",
+                        "wt_thresh")}
+    if "logl_dim_prior" not in fkw:
+        fkw["logl_dim_prior"] = True
+    par = kw.get("parallax")
+    perr = kw.get("parallax_err")
+    rows = list(bf._fit(
+        data[lo:hi], data_err[lo:hi], data_mask[lo:hi],
+        parallax=None if par is None else np.asarray(par)[lo:hi],
+        parallax_err=None if perr is None else np.asarray(perr)[lo:hi],
+        lnprior=lnprior, lngalprior=lngalprior, lndustprior=lndustprior,
+        av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[lo:hi],
+        Ndraws=Ndraws, return_distreds=save_dar_draws,
+        rstate_per_object=lambda i: np.random.RandomState(seed0 + lo + i),
+        **fkw))
+    allrows = gather_rows(rows, dst=0)
+    if rank == 0:
+        out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
+                               data_labels, save_dar_draws,
+                               running_io=running_io)
+        try:
+            for i, r in enumerate(allrows):
+                out.write_row(i, r)
+        finally:
+            out.close()
+    dist.barrier()
+    return hi - lo

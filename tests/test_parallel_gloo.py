@@ -1,0 +1,86 @@
+"""CPU, world_size 2, gloo: the star-sharding plumbing of brutus_amd.parallel
+(the N > 1 path of bench.py / fit_sharded).  The HIP engine itself cannot run
+here, so `_fit` is replaced by a deterministic stand-in; what is under test is
+the partition, the rank-ordered gather, the per-object seeding and the HDF5
+assembly."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def test_shard_range_partitions_everything():
+    from brutus_amd.parallel import shard_range
+    for n in (0, 1, 7, 10, 1000003):
+        for world in (1, 2, 3, 8):
+            edges = [shard_range(n, r, world) for r in range(world)]
+            assert edges[0][0] == 0 and edges[-1][1] == n
+            for (a, b), (c, d) in zip(edges[:-1], edges[1:]):
+                assert b == c and a <= b
+            sizes = [b - a for a, b in edges]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from brutus_amd import fitting, parallel, synth
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    models, labels, lmask = synth.make_grid(64, 6, seed=1)
+    st = synth.make_stars(models, 11, seed=2)
+
+    class Stub(fitting.BruteForce):
+        def _fit(self, data, data_err, data_mask, parallax=None, Ndraws=250,
+                 rstate_per_object=None, return_distreds=True, **kw):
+            for i in range(data.shape[0]):
+                rs = rstate_per_object(i)
+                idx = rs.randint(0, 64, size=Ndraws)
+                val = np.full(Ndraws, float(np.sum(data[i])))
+                yield (idx, val, val, val, np.zeros((Ndraws, 3, 3)), 6, val,
+                       float(rs.uniform()), 1.5, val, val, val, val)
+
+    bf = Stub(models, labels, lmask)
+    # broadcast_array: only rank 0 knows the payload
+    arr = parallel.broadcast_array(np.arange(12.).reshape(3, 4) if rank == 0 else None)
+    assert np.array_equal(arr, np.arange(12.).reshape(3, 4))
+    lab = np.zeros(11, dtype=[("id", "i8")])
+    lab["id"] = np.arange(11)
+    n = parallel.fit_sharded(bf, st["flux"], st["err"], st["mask"], lab,
+                             os.path.join(tmp, "out_w%d" % world), seed0=100,
+                             Ndraws=5, lngalprior=lambda *a, **k: 0.,
+                             parallax=st["parallax"],
+                             parallax_err=st["parallax_err"],
+                             data_coords=st["coords"])
+    lo, hi = parallel.shard_range(11, rank, world)
+    assert n == hi - lo
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_fit_sharded_gloo(tmp_path, world):
+    import torch.multiprocessing as mp
+    from brutus_amd import h5io
+    port = _free_port()
+    mp.spawn(_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    path = os.path.join(str(tmp_path), "out_w%d.h5" % world)
+    idx = h5io.read_dataset(path, "model_idx")
+    assert idx.shape == (11, 5) and idx.dtype == np.int32
+    # object i always draws from RandomState(100 + i), whatever the sharding
+    for i in range(11):
+        rs = np.random.RandomState(100 + i)
+        assert np.array_equal(idx[i], rs.randint(0, 64, size=5))
+    assert np.array_equal(h5io.read_dataset(path, "labels")["id"], np.arange(11))
+    assert np.all(h5io.read_dataset(path, "obj_Nbands") == 6)

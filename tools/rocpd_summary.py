@@ -37,15 +37,24 @@ def main(path):
         print("%-44s %7d %12.1f %11.2f %11.2f %11.2f %6.1f"
               % (k, a[0], a[1], a[1] / a[0], a[2], a[3], 100 * a[1] / tot))
     try:
-        pm = c.execute("select k.name, p.counter_name, sum(p.value), count(*) "
-                       "from pmc_events p join kernels k on k.dispatch_id = p.dispatch_id "
-                       "group by k.name, p.counter_name").fetchall()
+        pm = c.execute("select name, counter_name, counter_value, duration "
+                       "from pmc_events").fetchall()
     except sqlite3.Error:
         pm = []
     if pm:
-        print("\n# PMC counters (sum over dispatches / per dispatch)")
-        for name, ctr, val, n in pm:
-            print("%-44s %-24s %16.1f %8d %16.2f" % (short(name), ctr, val, n, val / n))
+        acc = {}
+        for name, ctr, val, dur in pm:
+            a = acc.setdefault((short(name), ctr), [0, 0.0, 0.0, 0.0])
+            a[0] += 1
+            a[1] += val
+            a[2] = max(a[2], val)
+            a[3] += dur / 1e3
+        print("\n# PMC counters per dispatch (raw counter units; FETCH_SIZE/WRITE_SIZE are KiB)")
+        print("%-44s %-14s %7s %16s %16s %11s" % ("kernel", "counter", "calls",
+                                                   "avg/dispatch", "max/dispatch", "avg_us"))
+        for (k, ctr), a in sorted(acc.items(), key=lambda kv: -kv[1][1]):
+            print("%-44s %-14s %7d %16.1f %16.1f %11.2f"
+                  % (k, ctr, a[0], a[1] / a[0], a[2], a[3] / a[0]))
 
 
 if __name__ == "__main__":
