@@ -1,0 +1,134 @@
+"""Default Galactic prior hook (host side, numpy).
+
+Counterpart of reference `pdf.gal_lnprior` (pdf.py:476-749) and its pieces
+`logn_disk` (pdf.py:263-307), `logn_halo` (pdf.py:310-377), `logp_feh`
+(pdf.py:380-407), `logp_age_from_feh` (pdf.py:410-473): thin disk + thick disk
++ halo number densities times the r^2 volume factor, with per-component
+metallicity and age priors mixed by the component membership probabilities.
+
+The pieces are pinned against the reference (tests/golden/galprior_pieces.npz).
+The assembled prior is NOT pinned: the reference converts (l, b, d) to
+Galactocentric (R, Z) through astropy's `Galactocentric` frame, whose defaults
+(Sun-centre distance, solar height, Sgr A* position) depend on the installed
+astropy version and are not the `R_solar`/`Z_solar` the density model itself
+uses.  Here the geometry is self-consistent instead: the Sun sits
+at Galactocentric radius `R_solar`, height `Z_solar`, and l = 0 points at the
+Galactic centre.  Differences to the astropy route are at the per-cent level in
+(R, Z) for kpc-scale distances.
+"""
+from math import erf, log, sqrt
+
+import numpy as np
+
+try:
+    from scipy.special import logsumexp
+except ImportError:  # pragma: no cover
+    from scipy.misc import logsumexp
+
+__all__ = ["galactic_to_RZ", "logn_disk", "logn_halo", "logp_feh",
+           "logp_age_from_feh", "gal_lnprior"]
+
+
+def galactic_to_RZ(dists, coord, R_solar=8.2, Z_solar=0.025):
+    """Heliocentric Galactic (l, b) [deg] and distance [kpc] -> cylindrical
+    Galactocentric radius R and height Z [kpc]."""
+    ell, b = np.deg2rad(coord[0]), np.deg2rad(coord[1])
+    d = np.asarray(dists, dtype=np.float64)
+    x = R_solar - d * np.cos(b) * np.cos(ell)     # towards the Sun from the centre
+    y = d * np.cos(b) * np.sin(ell)
+    z = Z_solar + d * np.sin(b)
+    return np.hypot(x, y), z
+
+
+def logn_disk(R, Z, R_solar=8.2, Z_solar=0.025, R_scale=2.6, Z_scale=0.3,
+              R_smooth=2.0):
+    """Exponential disk, normalised to zero at the solar position."""
+    R_eff = np.sqrt(np.square(R) + R_smooth ** 2)
+    return -((R_eff - R_solar) / R_scale
+             + (np.abs(Z) - abs(Z_solar)) / Z_scale)
+
+
+def logn_halo(R, Z, R_solar=8.2, Z_solar=0.025, R_smooth=2.0, eta=4.2,
+              q_ctr=0.2, q_inf=0.8, r_q=6.):
+    """Power-law halo with radius-dependent oblateness, normalised at the Sun."""
+    def flattening(r2):
+        return q_inf - (q_inf - q_ctr) * np.exp(1. - np.sqrt(r2 + r_q ** 2) / r_q)
+
+    def r_eff(Rc, Zc):
+        q = flattening(np.square(Rc) + np.square(Zc))
+        return np.sqrt(np.square(Rc) + np.square(Zc / q) + R_smooth ** 2)
+
+    return -eta * np.log(r_eff(R, Z) / r_eff(R_solar, Z_solar))
+
+
+def logp_feh(feh, feh_mean=-0.2, feh_sigma=0.3):
+    """Gaussian ln pdf in [Fe/H]."""
+    return -0.5 * (np.square(feh_mean - feh) / feh_sigma ** 2
+                   + np.log(2. * np.pi * feh_sigma ** 2))
+
+
+def logp_age_from_feh(age, feh_mean=-0.2, max_age=13.8, min_age=0.,
+                      feh_age_ctr=-0.5, feh_age_scale=0.5,
+                      nsigma_from_max_age=2., max_sigma=4., min_sigma=1.):
+    """Truncated-normal ln pdf in age [Gyr] whose mean follows the component's
+    mean metallicity through a logistic age-metallicity relation."""
+    mean = ((max_age - min_age)
+            / (1. + np.exp((feh_mean - feh_age_ctr) / feh_age_scale)) + min_age)
+    sigma = min(max((max_age - mean) / nsigma_from_max_age, min_sigma), max_sigma)
+    age = np.asarray(age, dtype=np.float64)
+    lo, hi = (min_age - mean) / sigma, (max_age - mean) / sigma
+    lnnorm = log(sigma / 2.) + log(erf(hi / sqrt(2.)) - erf(lo / sqrt(2.)))
+    out = -log(sqrt(2. * np.pi)) - 0.5 * np.square((age - mean) / sigma) - lnnorm
+    outside = (age < min_age) | (age > max_age)
+    return np.where(outside, -np.inf, out)
+
+
+def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
+                R_thin=2.6, Z_thin=0.3, Rs_thin=2.0,
+                R_thick=2.0, Z_thick=0.9, f_thick=0.04, Rs_thick=2.0,
+                Rs_halo=2.0, q_halo_ctr=0.2, q_halo_inf=0.8, r_q_halo=6.0,
+                eta_halo=4.2, f_halo=0.005,
+                feh_thin=-0.2, feh_thin_sigma=0.3,
+                feh_thick=-0.7, feh_thick_sigma=0.4,
+                feh_halo=-1.6, feh_halo_sigma=0.5,
+                max_age=13.8, min_age=0., feh_age_ctr=-0.5, feh_age_scale=0.5,
+                nsigma_from_max_age=2., max_sigma=4., min_sigma=1.,
+                return_components=False):
+    """ln prior over distance (and, through `labels['feh']` / `labels['loga']`,
+    metallicity and age) for a sightline `coord = (l, b)` in degrees.  Same
+    signature, defaults and component model as reference pdf.py:476-749."""
+    dists = np.asarray(dists, dtype=np.float64)
+    with np.errstate(all="ignore"):
+        volume = 2. * np.log(dists + 1e-300)
+        R, Z = galactic_to_RZ(dists, coord, R_solar=R_solar, Z_solar=Z_solar)
+        comp = [
+            logn_disk(R, Z, R_solar, Z_solar, R_thin, Z_thin, Rs_thin) + volume,
+            logn_disk(R, Z, R_solar, Z_solar, R_thick, Z_thick, Rs_thick)
+            + volume + np.log(f_thick),
+            logn_halo(R, Z, R_solar, Z_solar, Rs_halo, eta_halo, q_halo_ctr,
+                      q_halo_inf, r_q_halo) + volume + np.log(f_halo),
+        ]
+        lnprior = logsumexp(comp, axis=0)
+        components = {"number_density": comp}
+        if labels is not None:
+            member = [c - lnprior for c in comp]   # ln P(component | position)
+            names = getattr(getattr(labels, "dtype", None), "names", None) or ()
+            if "feh" in names:
+                feh = labels["feh"]
+                parts = [logp_feh(feh, m, s) + w for (m, s), w in
+                         zip(((feh_thin, feh_thin_sigma),
+                              (feh_thick, feh_thick_sigma),
+                              (feh_halo, feh_halo_sigma)), member)]
+                lnprior = lnprior + logsumexp(parts, axis=0)
+                components["feh"] = parts
+            if "loga" in names:
+                age = 10. ** labels["loga"] / 1e9
+                parts = [logp_age_from_feh(age, m, max_age, min_age, feh_age_ctr,
+                                           feh_age_scale, nsigma_from_max_age,
+                                           max_sigma, min_sigma) + w
+                         for m, w in zip((feh_thin, feh_thick, feh_halo), member)]
+                lnprior = lnprior + logsumexp(parts, axis=0)
+                components["age"] = parts
+    if return_components:
+        return lnprior, components
+    return lnprior

@@ -247,9 +247,29 @@ def gen_setup():
     print("setup done; 3-band ValueError raised:", raised)
 
 
+def gen_galprior_pieces():
+    """Astropy-free pieces of `pdf.gal_lnprior` (reference pdf.py:263-473)."""
+    rng = np.random.RandomState(3)
+    R = rng.uniform(0., 20., 200)
+    Z = rng.uniform(-5., 5., 200)
+    feh = rng.uniform(-3., 0.6, 200)
+    age = rng.uniform(-0.5, 14.5, 200)
+    np.savez_compressed(
+        os.path.join(OUT, "galprior_pieces.npz"), R=R, Z=Z, feh=feh, age=age,
+        disk_thin=P.logn_disk(R, Z), disk_thick=P.logn_disk(R, Z, R_scale=2.0, Z_scale=0.9),
+        halo=P.logn_halo(R, Z),
+        feh_thin=P.logp_feh(feh), feh_halo=P.logp_feh(feh, feh_mean=-1.6, feh_sigma=0.5),
+        age_thin=P.logp_age_from_feh(age.copy(), feh_mean=-0.2),
+        age_thick=P.logp_age_from_feh(age.copy(), feh_mean=-0.7),
+        age_halo=P.logp_age_from_feh(age.copy(), feh_mean=-1.6))
+    print("galprior pieces done")
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup"]
+    which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior"]
+    if "galprior" in which:
+        gen_galprior_pieces()
     if "helpers" in which:
         gen_helpers()
     if "setup" in which:
@@ -258,3 +278,4 @@ if __name__ == "__main__":
         gen_loglike()
     if "fit" in which:
         gen_fit()
+
