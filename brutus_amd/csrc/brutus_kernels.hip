@@ -1391,6 +1391,87 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
     }
 }
 
+// ===========================================================================
+// cluster.isochrone_loglike hot block (reference cluster.py:336-414)
+// ===========================================================================
+// For every object o and every isochrone point c (all secondary-mass-fraction
+// slices concatenated): chi2 = nansum_b (phot_ob - flux_cb)^2 / err_ob^2 + chi2_p,
+// lnl = chi2-logpdf(chi2, n_o) or -(chi2 + lnorm_o)/2, then
+// lnl_o = logsumexp_c (lnl + lnw_c).  One lane = one object (its bands in
+// VGPRs), isochrone points are wave-uniform (scalar loads); the point axis is
+// split over blockIdx.y and merged by k_cluster_merge (online logsumexp).
+template <int NB>
+__global__ void __launch_bounds__(64)
+k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
+          const double *__restrict__ pts_lnw, const double *__restrict__ phot,
+          const double *__restrict__ ivar, const double *__restrict__ chi2_p,
+          const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
+          int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    const bool live = o < nobj;
+    const int oo = live ? o : 0;
+    double d[NB], iv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        d[b] = b < nb ? phot[(int64_t)oo * nb + b] : 0.;
+        iv[b] = b < nb ? ivar[(int64_t)oo * nb + b] : 0.;
+    }
+    const double cp = chi2_p[oo], ln0 = lnorm[oo];
+    const double k = (double)ndim[oo];
+    const double c0 = -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.);
+    const double c1 = k / 2. - 1.;
+    const int p0 = blockIdx.y * pts_per_block;
+    const int p1 = min(npts, p0 + pts_per_block);
+    double m = -INFINITY, ssum = 0.;
+    for (int c = p0; c < p1; ++c) {
+        const double *f = pts_flux + (int64_t)c * nb;
+        double chi2 = 0.;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb) {
+                const double t = d[b] - f[b];
+                const double term = t * t * iv[b];
+                if (term == term) chi2 += term;          // nansum (cluster.py:381)
+            }
+        }
+        chi2 += cp;
+        double lnl;
+        if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
+            lnl = c0 + (c1 == 0. ? 0. : c1 * log(chi2)) - chi2 / 2.;
+        else
+            lnl = -0.5 * (chi2 + ln0);
+        if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
+        const double x = lnl + pts_lnw[c];
+        if (x > m) {
+            ssum = ssum * exp(m - x) + 1.;
+            m = x;
+        } else if (x > -INFINITY) {
+            ssum += exp(x - m);
+        }
+    }
+    if (live) {
+        part_m[(int64_t)blockIdx.y * nobj + o] = m;
+        part_s[(int64_t)blockIdx.y * nobj + o] = ssum;
+    }
+}
+
+__global__ void k_cluster_merge(int nobj, int nchunk, const double *__restrict__ part_m,
+                                const double *__restrict__ part_s, double *__restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nobj) return;
+    double m = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        const double x = part_m[(int64_t)c * nobj + o];
+        m = x > m ? x : m;
+    }
+    double ssum = 0.;
+    for (int c = 0; c < nchunk; ++c) {
+        const double x = part_m[(int64_t)c * nobj + o];
+        if (x > -INFINITY) ssum += part_s[(int64_t)c * nobj + o] * exp(x - m);
+    }
+    out[o] = m > -INFINITY ? m + log(ssum) : -INFINITY;
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -1939,6 +2020,53 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
     HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);
     tm.collect();
+    return 0;
+}
+
+constexpr int CLUSTER_CHUNKS = 64;
+
+size_t brutus_cluster_workspace_bytes(int nobj) {
+    if (nobj <= 0) return 0;
+    return 2 * align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS);
+}
+
+int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                       const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
+                       const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
+                       int dim_prior, void *d_workspace, size_t workspace_bytes, double *d_lnl,
+                       void *stream) {
+    const int nb = padded_nb(nfilt);
+    if (nobj <= 0 || npts <= 0 || nb < 0)
+        return fail(BRUTUS_EINVAL, "bad cluster dimensions (nobj=%d, npts=%d, nfilt=%d)", nobj,
+                    npts, nfilt);
+    if (!d_pts_flux || !d_pts_lnw || !d_phot || !d_ivar || !d_chi2_p || !d_lnorm || !d_ndim ||
+        !d_workspace || !d_lnl)
+        return fail(BRUTUS_EINVAL, "NULL device pointer");
+    if (workspace_bytes < brutus_cluster_workspace_bytes(nobj))
+        return fail(BRUTUS_ENOMEM, "cluster workspace too small");
+    double *pm = (double *)d_workspace;
+    double *ps = (double *)((char *)d_workspace + align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS));
+    hipStream_t st = (hipStream_t)stream;
+    const int ppb = (npts + CLUSTER_CHUNKS - 1) / CLUSTER_CHUNKS;
+    const int nchunk = (npts + ppb - 1) / ppb;
+    const dim3 g((nobj + 63) / 64, nchunk);
+#define BRUTUS_CL(N)                                                                              \
+    case N:                                                                                       \
+        hipLaunchKernelGGL(k_cluster<N>, g, dim3(64), 0, st, nobj, nfilt, npts, d_pts_flux,       \
+                           d_pts_lnw, d_phot, d_ivar, d_chi2_p, d_lnorm, d_ndim, dim_prior, ppb,  \
+                           pm, ps);                                                               \
+        break;
+    switch (nb) {
+        BRUTUS_CL(8)
+        BRUTUS_CL(12)
+        BRUTUS_CL(16)
+        BRUTUS_CL(24)
+        BRUTUS_CL(32)
+    }
+#undef BRUTUS_CL
+    hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + 255) / 256), dim3(256), 0, st, nobj, nchunk, pm,
+                       ps, d_lnl);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

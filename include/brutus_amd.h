@@ -12,7 +12,7 @@
  *   brutus/fitting.py:579-820   loglike            (whole function)
  *   brutus/fitting.py:976-991   lnpost: parallax clip + first `wt_thresh` cut
  *   brutus/utils.py:130-176     _chisquare_logpdf
- *   brutus/cluster.py:336-414   isochrone_loglike hot block (see brutus_cluster_*)
+ *   brutus/cluster.py:336-414   isochrone_loglike hot block (brutus_cluster_lnl)
  *
  * Conventions
  *   - every pointer prefixed d_ is a DEVICE pointer (HBM), h_ is a host pointer;
@@ -127,6 +127,25 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
                       size_t workspace_bytes, int64_t capacity,
                       int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
                       void *stream);
+
+/* ---- cluster mode ------------------------------------------------------------
+ * Hot block of cluster.isochrone_loglike (cluster.py:336-414): for nobj objects
+ * and npts isochrone points (all secondary-mass-fraction slices concatenated,
+ * masked points removed by the caller),
+ *   d_pts_flux (npts, nfilt) f64  model fluxes 10^(-0.4 cmd_sed), NaN = no model
+ *   d_pts_lnw  (npts,)       f64  ln(grad_mini) + ln(grad_smf)   (cluster.py:397-403)
+ *   d_phot, d_ivar (nobj, nfilt)  offset-scaled fluxes and 1/err^2 (0 for missing bands)
+ *   d_chi2_p, d_lnorm (nobj,)     parallax chi2; ln-normalisation (dim_prior == 0)
+ *   d_ndim (nobj,) i32            phot_n, the chi-square degrees of freedom
+ * writes d_lnl (nobj,) = logsumexp over points of (lnl + lnw), i.e. the
+ * `lnl` of cluster.py:407 before the outlier mixture. */
+size_t brutus_cluster_workspace_bytes(int nobj);
+int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                       const double *d_pts_lnw, const double *d_phot,
+                       const double *d_ivar, const double *d_chi2_p,
+                       const double *d_lnorm, const int32_t *d_ndim,
+                       int dim_prior, void *d_workspace, size_t workspace_bytes,
+                       double *d_lnl, void *stream);
 
 /* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
  * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the

@@ -644,3 +644,109 @@ def fit_star(data, data_err, data_mask, models, lnprior, labels, coord,
         logwts = logwts[idxs, imc]
     return (sidxs, scales, avs, rvs, cov_sar, Ndim, lnprob, levid, chi2min,
             dists, reds, dreds, logwts)
+
+
+# ---------------------------------------------------------------------------
+# cluster.py
+# ---------------------------------------------------------------------------
+def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
+                      offsets='fixed', corr_params='fixed', mini_bound=0.08,
+                      eep_binary_max=480., smf_grid=None, eep_grid=None,
+                      parallax=None, parallax_err=None, cluster_prob=0.95,
+                      dim_prior=True, return_lnls=False):
+    """cluster.py:170-419 (`isochrone_loglike`), numpy restatement that keeps
+    the reference's (Ncmd, Nobj, Nb) broadcast and scipy calls."""
+    from scipy.stats import chi2 as chisquare
+    Nobjs, Nbands = phot.shape
+    phot_mask = np.isfinite(phot) & np.isfinite(err)            # :179
+    phot_n = np.sum(phot_mask, axis=1)
+    if smf_grid is None:                                        # :184-187
+        smf_grid = np.array([0., 0.2, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65,
+                             0.7, 0.75, 0.8, 0.85, 0.9, 0.95, 1.0])
+    grad_smf = np.gradient(smf_grid) if len(smf_grid) > 1 else np.array([1.])
+    if eep_grid is None:
+        eep_grid = np.linspace(202., 808., 2000)                # :198
+
+    def take(pos, spec, n):
+        out = np.zeros(n)
+        for i in range(n):
+            if (isinstance(spec, str) and spec == 'free') or spec[i] is None:
+                out[i] = theta[pos]
+                pos += 1
+            else:
+                out[i] = spec[i]
+        return out, pos
+
+    pos = 0
+    (feh, loga, av, rv, dist, fout), pos = take(pos, cluster_params, 6)  # :231-248
+    fout = max(min(1. - 1e-10, fout), 1e-10)
+    if isinstance(offsets, str) and offsets == 'fixed':         # :251-270
+        Xb = np.ones(Nbands)
+        pos += Nbands
+    else:
+        Xb, pos = take(pos, offsets, Nbands)
+    if isinstance(corr_params, str) and corr_params == 'fixed':  # :273-290
+        corr_coef = None
+    else:
+        corr_coef, pos = take(pos, corr_params, 4)
+
+    chi2_p = np.zeros(Nobjs)                                    # :292-301
+    lnorm_p = np.zeros(Nobjs)
+    if parallax is not None and parallax_err is not None:
+        pm = np.isfinite(parallax) & np.isfinite(parallax_err)
+        chi2_p[pm] += (parallax[pm] - 1e3 / dist) ** 2 / parallax_err[pm] ** 2
+        lnorm_p[pm] += np.log(2. * np.pi * parallax_err[pm] ** 2)
+        phot_n = phot_n + pm
+    with np.errstate(all="ignore"):
+        if dim_prior:                                           # :304-307
+            lnl_outlier = chisquare.logpdf(chisquare.ppf(1. - 1e-5, phot_n), phot_n)
+        else:                                                   # :308-321
+            omax = np.nanmax(phot + 3. * err, axis=0)
+            omin = np.nanmin(phot - 3. * err, axis=0)
+            osize = (6. * err) / (omax - omin)
+            osize[~phot_mask] = 1.
+            ovol = np.prod(osize * phot_mask + 1. * ~phot_mask, axis=1)
+            if parallax is not None and parallax_err is not None:
+                p_max = np.nanmax((parallax + 3. * parallax_err)[pm])
+                p_min = np.nanmin((parallax - 3. * parallax_err)[pm])
+                ovol[pm] *= (6. * parallax_err[pm]) / (p_max - p_min)
+            lnl_outlier = np.log(1. / ovol)
+        ln_fin = np.log(cluster_prob * (1. - fout))             # :324-325
+        ln_fout = np.log(1. - cluster_prob * (1. - fout))
+        lnls = np.full((len(smf_grid), Nobjs), -np.inf)
+        done_first = False
+        for i, smf in enumerate(smf_grid):                      # :336-404
+            cmd_sed, params1, _ = isochrone.get_seds(
+                feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, smf=smf,
+                dist=dist, mini_bound=mini_bound,
+                eep_binary_max=eep_binary_max, corr_params=corr_coef)
+            cmd_mini = params1['mini']
+            grad_mini = np.gradient(cmd_mini)
+            ok = np.any(np.isfinite(cmd_sed), axis=1) & (grad_mini > 0.)
+            if done_first:
+                ok &= eep_grid <= eep_binary_max
+            done_first = True
+            cmd_mask = np.where(ok)[0]
+            if len(cmd_mask) == 0:
+                continue
+            cmd_sed, grad_mini = cmd_sed[cmd_mask], grad_mini[cmd_mask]
+            phot_t, err_t = phot * Xb, err * Xb
+            cmd_phot = 10 ** (-0.4 * cmd_sed)
+            chi2_cmd = np.nansum((phot_t - cmd_phot[:, None]) ** 2 / err_t ** 2,
+                                 axis=-1)
+            lnorm_cmd = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=-1)
+            chi2 = chi2_cmd + chi2_p
+            lnorm = lnorm_cmd + lnorm_p
+            if dim_prior:
+                lnl_cmd = chisquare.logpdf(chi2, phot_n)
+            else:
+                lnl_cmd = -0.5 * (chi2 + lnorm)
+            lnl_cmd[~np.isfinite(lnl_cmd)] = -np.inf
+            lnprior = np.log(grad_mini) + np.log(grad_smf[i])
+            lnls[i] = logsumexp(lnl_cmd + lnprior[:, None], axis=0)
+        lnl = logsumexp(lnls, axis=0)                           # :407
+        lnl_mix = np.logaddexp(lnl + ln_fin, lnl_outlier + ln_fout)  # :410-411
+    lnl_tot = np.sum(lnl_mix)
+    if return_lnls:
+        return lnl_tot, lnl_mix
+    return lnl_tot

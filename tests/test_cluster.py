@@ -1,0 +1,79 @@
+"""cluster.isochrone_loglike: oracle vs reference golden (CPU) and HIP vs both
+(GPU).  Float tolerance 1e-9 relative on per-object mixture log-likelihoods."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, make_cluster_data, relerr
+
+CASES = (("a", 200, 6, 1), ("b", 300, 8, 2))
+THETA = np.array([-0.1, 9.6, 0.2, 3.3, 850., 0.05])
+
+
+def _run(fn, tag, nobj, nb, seed):
+    iso, phot, err, par, perr = make_cluster_data(nobj, nb, seed)
+    out = {}
+    for dp in (True, False):
+        out["dp%d" % dp] = fn(THETA, iso, phot.copy(), err.copy(),
+                              parallax=par.copy(), parallax_err=perr.copy(),
+                              dim_prior=dp, return_lnls=True)
+    theta2 = np.concatenate([THETA, np.linspace(0.97, 1.03, nb - 1), [0.5]])
+    out["free"] = fn(theta2, iso, phot.copy(), err.copy(),
+                     offsets=[1.0] + [None] * (nb - 1),
+                     corr_params=[None, 0., 0., 1.], return_lnls=True)
+    return out
+
+
+def _check(out, z, tag, tol):
+    for key in ("dp1", "dp0", "free"):
+        tot, mix = out[key]
+        assert relerr(z["%s_%s_mix" % (tag, key)], mix) < tol, (tag, key)
+        assert abs(tot - float(z["%s_%s_tot" % (tag, key)])) < tol * abs(tot) * 10
+
+
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_oracle_matches_reference(case):
+    from oracle import brutus_oracle as O
+    z = np.load(os.path.join(GOLDEN, "cluster.npz"))
+    _check(_run(O.isochrone_loglike, *case), z, case[0], 1e-12)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c[0])
+def test_hip_matches_reference(case):
+    from brutus_amd import cluster
+    z = np.load(os.path.join(GOLDEN, "cluster.npz"))
+    _check(_run(cluster.isochrone_loglike, *case), z, case[0], 1e-9)
+
+
+@pytest.mark.gpu
+def test_hip_config5_size_vs_oracle():
+    """BASELINE configs[4]: 5k objects, 12 bands, 15 x 2000 isochrone table."""
+    from brutus_amd import cluster
+    from oracle import brutus_oracle as O
+    iso, phot, err, par, perr = make_cluster_data(5000, 12, 5)
+    a = cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par,
+                                  parallax_err=perr, return_lnls=True)
+    eep = np.linspace(202., 808., 400)     # oracle on a thinner table (memory)
+    b = cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par,
+                                  parallax_err=perr, return_lnls=True, eep_grid=eep)
+    c = O.isochrone_loglike(THETA, iso, phot, err, parallax=par,
+                            parallax_err=perr, return_lnls=True, eep_grid=eep)
+    assert relerr(c[1], b[1]) < 1e-9
+    assert np.isfinite(a[0]) and a[1].shape == (5000,)
+
+
+def test_errors_match_reference_messages():
+    from brutus_amd import cluster
+    iso, phot, err, par, perr = make_cluster_data(20, 6, 3)
+    with pytest.raises(ValueError, match="photometry must be provided"):
+        cluster.isochrone_loglike(THETA, iso, None, err)
+    with pytest.raises(ValueError, match="degeneracy"):
+        cluster.isochrone_loglike(THETA, iso, phot, err, offsets='free')
+    with pytest.raises(ValueError, match="parallax errors"):
+        cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par)
+    bad = phot.copy()
+    bad[3] = np.nan
+    with pytest.raises(ValueError, match="no valid data"):
+        cluster.isochrone_loglike(THETA, iso, bad, err)

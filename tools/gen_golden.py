@@ -265,9 +265,39 @@ def gen_galprior_pieces():
     print("galprior pieces done")
 
 
+def gen_cluster():
+    """`cluster.isochrone_loglike` (reference cluster.py:23-419) with the fake
+    isochrone of tests/helpers.py."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import make_cluster_data
+    res = {}
+    for tag, nobj, nb, seed in (("a", 200, 6, 1), ("b", 300, 8, 2)):
+        iso, phot, err, par, perr = make_cluster_data(nobj, nb, seed)
+        theta = np.array([-0.1, 9.6, 0.2, 3.3, 850., 0.05])
+        for dp in (True, False):
+            tot, mix = C.isochrone_loglike(theta, iso, phot.copy(), err.copy(),
+                                           parallax=par.copy(), parallax_err=perr.copy(),
+                                           dim_prior=dp, return_lnls=True)
+            res["%s_dp%d_tot" % (tag, dp)] = tot
+            res["%s_dp%d_mix" % (tag, dp)] = mix
+        # free offsets + correction parameters, no parallax
+        theta2 = np.concatenate([theta, np.linspace(0.97, 1.03, nb - 1), [0.5]])
+        tot, mix = C.isochrone_loglike(theta2, iso, phot.copy(), err.copy(),
+                                       offsets=[1.0] + [None] * (nb - 1),
+                                       corr_params=[None, 0., 0., 1.],
+                                       return_lnls=True)
+        res["%s_free_tot" % tag] = tot
+        res["%s_free_mix" % tag] = mix
+        print("cluster", tag, res["%s_dp1_tot" % tag], res["%s_dp0_tot" % tag], tot)
+    np.savez_compressed(os.path.join(OUT, "cluster.npz"), **res)
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
-    which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior"]
+    which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
+                             "cluster"]
+    if "cluster" in which:
+        gen_cluster()
     if "galprior" in which:
         gen_galprior_pieces()
     if "helpers" in which:
