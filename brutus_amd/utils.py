@@ -78,3 +78,94 @@ def inv_magnitude(mag, err, zeropoints=1.):
     phot = 10. ** (-0.4 * np.asarray(mag, dtype=np.float64)) * zeropoints
     phot_err = np.asarray(err) * 0.4 * np.log(10.) * phot
     return phot, phot_err
+
+
+# ---------------------------------------------------------------------------
+# grid / offsets loaders (reference utils.py:520-715)
+# ---------------------------------------------------------------------------
+def load_models(filepath, filters=None, labels=None, include_ms=True,
+                include_postms=True, include_binaries=False, verbose=True):
+    """Read a model-grid HDF5 file into `(models, labels, label_mask)`.
+
+    Same contract as reference `utils.load_models` (utils.py:520-662):
+    `models` is `(Nmodel, Nfilt, 3)` float32 magnitude coefficients for the
+    requested `filters` (all-zero / absent filters dropped), `labels` a
+    structured float array of the requested label fields that exist in the
+    file (`labels` dataset = grid inputs, `parameters` dataset = predictions),
+    `label_mask` a structured `(1,)` bool array flagging the grid inputs.
+    Main-sequence / post-main-sequence (EEP 454 split) and binary (`smf`)
+    cuts as in the reference.  Reads through libhdf5 (`brutus_amd.h5io`).
+    """
+    import sys
+    from . import h5io
+    from .filters import FILTERS
+    if filters is None:
+        filters = FILTERS
+    if labels is None:
+        labels = ['mini', 'feh', 'eep', 'smf', 'loga', 'logl', 'logt', 'logg',
+                  'Mr', 'agewt']
+    if not include_ms and not include_postms:
+        raise ValueError("If you don't include the Main Sequence and "
+                         "Post-Main Sequence models you have nothing left!")
+    coeffs = h5io.read_dataset(filepath, "mag_coeffs")
+    have = coeffs.dtype.names or ()
+    ncoef = coeffs.dtype[have[0]].shape[0] if have else 3
+    models = np.zeros((len(coeffs), len(filters), ncoef), dtype='float32')
+    for j, filt in enumerate(filters):
+        if filt in have:
+            models[:, j] = coeffs[filt]
+            if verbose:
+                sys.stderr.write('\rReading filter {}           '.format(filt))
+                sys.stderr.flush()
+    if verbose:
+        sys.stderr.write('\n')
+    models = models[:, ~np.all(models == 0., axis=(0, 2)), :]
+
+    present = set(h5io.list_datasets(filepath))
+    combined = np.full(len(models), np.nan,
+                       dtype=np.dtype([(n, np.float64) for n in labels]))
+    label_mask = np.zeros(1, dtype=np.dtype([(n, np.bool_) for n in labels]))
+    if "labels" in present:
+        tab = h5io.read_dataset(filepath, "labels")
+        for n in tab.dtype.names:
+            if n in labels:
+                combined[n] = tab[n]
+                label_mask[n] = True
+    if "parameters" in present:
+        tab = h5io.read_dataset(filepath, "parameters")
+        for n in tab.dtype.names:
+            if n in labels:
+                combined[n] = tab[n]
+    kept = [n for n in labels if not np.isnan(combined[n][0])]
+
+    sel = np.ones(len(combined), dtype=bool)
+    if 'eep' in kept and not (include_ms and include_postms):
+        sel = combined['eep'] > 454. if include_postms else combined['eep'] <= 454.
+    if not include_binaries and 'smf' in kept:
+        sel = sel & (combined['smf'] == 0.)
+        kept = [n for n in kept if n != 'smf']
+    return models[sel], combined[kept][sel], label_mask[kept]
+
+
+def load_offsets(filepath, filters=None, verbose=True):
+    """Multiplicative photometric offsets per filter from a two-column text
+    file `(filter name, value)`; filters without an entry get 1
+    (reference utils.py:665-715)."""
+    import sys
+    from .filters import FILTERS
+    if filters is None:
+        filters = FILTERS
+    names, vals = np.loadtxt(filepath, dtype='str').T
+    vals = vals.astype(float)
+    offsets = np.ones(len(filters))
+    for j, filt in enumerate(filters):
+        hit = np.where(names == filt)[0]
+        if len(hit) > 1:
+            raise ValueError("Something went wrong when extracting "
+                             "offsets for filter {}.".format(filt))
+        if len(hit) == 1:
+            offsets[j] = vals[hit[0]]
+    if verbose:
+        for filt, zp in zip(filters, offsets):
+            sys.stderr.write('{0} ({1:3.2}%)\n'.format(filt, 100 * (zp - 1.)))
+    return offsets

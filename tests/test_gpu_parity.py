@@ -257,3 +257,52 @@ def test_fit_records_vs_oracle_all_cases():
                           / (d[:, :, None] * d[:, None, :])) < RTOL
             k1s.add(tr["K1"])
         assert 2 in k1s
+
+
+def test_fit_end_to_end_hdf5(tmp_path):
+    """BASELINE configs[0]-shaped run through the public API: 100 stars,
+    10k-model grid, 6 bands -> {save_file}.h5 in the reference layout
+    (fitting.py:1635-1662), checked row by row against the oracle driven by
+    the same sequential RandomState."""
+    from brutus_amd import fitting, h5io, synth
+    from oracle import brutus_oracle as O
+    models, labels, lmask = synth.make_grid(10000, 6, seed=1)
+    st = synth.make_stars(models, 100, seed=2)
+    objid = np.zeros(100, dtype=[("id", "i8"), ("l", "f8"), ("b", "f8")])
+    objid["id"] = np.arange(100)
+    objid["l"], objid["b"] = st["coords"][:, 0], st["coords"][:, 1]
+    BF = fitting.BruteForce(models, labels, lmask)
+    BF.batch_size = 32
+    path = os.path.join(str(tmp_path), "cfg1")
+    BF.fit(st["flux"], st["err"], st["mask"], objid, path,
+           parallax=st["parallax"], parallax_err=st["parallax_err"],
+           data_coords=st["coords"], lngalprior=galprior, Nmc_prior=25,
+           Ndraws=60, rstate=np.random.RandomState(862), verbose=False)
+    with pytest.raises(OSError):        # "w-": never overwrite
+        BF.fit(st["flux"], st["err"], st["mask"], objid, path,
+               parallax=st["parallax"], parallax_err=st["parallax_err"],
+               data_coords=st["coords"], lngalprior=galprior, verbose=False)
+    f = path + ".h5"
+    names = set(h5io.list_datasets(f))
+    assert names == {"labels", "model_idx", "ml_scale", "ml_av", "ml_rv",
+                     "ml_cov_sar", "obj_log_post", "obj_log_evid",
+                     "obj_chi2min", "obj_Nbands", "samps_dist", "samps_red",
+                     "samps_dred", "samps_logp"}
+    idx = h5io.read_dataset(f, "model_idx")
+    assert idx.dtype == np.int32 and idx.shape == (100, 60) and idx.min() >= 0
+    assert h5io.read_dataset(f, "ml_cov_sar").shape == (100, 60, 3, 3)
+    assert h5io.read_dataset(f, "obj_Nbands").dtype == np.int16
+    assert np.array_equal(h5io.read_dataset(f, "labels")["id"], np.arange(100))
+    # oracle with the same single sequential stream
+    lnprior = O.static_lnprior(labels, lmask)
+    rs = np.random.RandomState(862)
+    evid = h5io.read_dataset(f, "obj_log_evid")
+    dist = h5io.read_dataset(f, "samps_dist")
+    for i in range(100):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models,
+                         lnprior, labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], rs, galprior, Nmc_prior=25,
+                         Ndraws=60)
+        assert np.array_equal(idx[i], ref[0]), i
+        assert abs(evid[i] - np.float32(ref[7])) <= 1e-5 * abs(ref[7]) + 1e-6
+        assert relerr(ref[9].astype(np.float32), dist[i]) < 1e-5

@@ -1,0 +1,98 @@
+"""CPU: grid-file / offsets loaders and the libhdf5 binding (h5io)."""
+import os
+
+import numpy as np
+import pytest
+
+from brutus_amd import h5io, utils
+
+
+def _write_grid(path, n=50):
+    rng = np.random.RandomState(0)
+    ctype = np.dtype([("PS_g", "f4", (3,)), ("PS_r", "f4", (3,)),
+                      ("2MASS_J", "f4", (3,)), ("WISE_W1", "f4", (3,))])
+    coeffs = np.zeros(n, dtype=ctype)
+    for name in ("PS_g", "PS_r", "2MASS_J"):       # WISE_W1 stays all-zero
+        coeffs[name] = rng.normal(size=(n, 3))
+    labels = np.zeros(n, dtype=[("mini", "f8"), ("eep", "f8"), ("feh", "f8"),
+                                ("smf", "f8")])
+    labels["mini"] = rng.uniform(0.5, 2, n)
+    labels["eep"] = np.linspace(300, 600, n)
+    labels["feh"] = rng.uniform(-2, 0.5, n)
+    labels["smf"] = np.where(np.arange(n) % 5 == 0, 0.5, 0.)
+    params = np.zeros(n, dtype=[("loga", "f8"), ("agewt", "f8"), ("junk", "f8")])
+    params["loga"] = rng.uniform(8, 10, n)
+    params["agewt"] = rng.uniform(0.1, 1, n)
+    h5io.write_datasets(path, {"mag_coeffs": coeffs, "labels": labels,
+                               "parameters": params})
+    return coeffs, labels, params
+
+
+def test_load_models_roundtrip(tmp_path):
+    path = os.path.join(str(tmp_path), "grid.h5")
+    coeffs, labels, params = _write_grid(path)
+    models, lab, lmask = utils.load_models(path, verbose=False)
+    single = labels["smf"] == 0.
+    assert models.dtype == np.float32 and models.shape == (single.sum(), 3, 3)
+    # band order follows FILTERS: PS_g, PS_r, ..., 2MASS_J; all-zero WISE_W1 dropped
+    assert np.array_equal(models[:, 0], coeffs["PS_g"][single])
+    assert np.array_equal(models[:, 2], coeffs["2MASS_J"][single])
+    assert lab.dtype.names == ("mini", "feh", "eep", "loga", "agewt")
+    assert np.array_equal(lab["loga"], params["loga"][single])
+    assert bool(lmask["mini"][0]) and not bool(lmask["loga"][0])
+    m2, l2, _ = utils.load_models(path, filters=["2MASS_J", "PS_g"],
+                                  include_postms=False, include_binaries=True,
+                                  verbose=False)
+    ms = labels["eep"] <= 454.
+    assert m2.shape == (ms.sum(), 2, 3) and "smf" in l2.dtype.names
+    assert np.array_equal(m2[:, 0], coeffs["2MASS_J"][ms])
+    with pytest.raises(ValueError, match="nothing left"):
+        utils.load_models(path, include_ms=False, include_postms=False)
+
+
+def test_load_offsets(tmp_path):
+    path = os.path.join(str(tmp_path), "off.txt")
+    with open(path, "w") as f:
+        f.write("PS_g 1.02\n2MASS_J 0.97\n")
+    off = utils.load_offsets(path, filters=["PS_g", "PS_r", "2MASS_J"], verbose=False)
+    assert np.allclose(off, [1.02, 1.0, 0.97])
+
+
+def test_results_file_layout_and_wminus(tmp_path):
+    path = os.path.join(str(tmp_path), "res.h5")
+    lab = np.zeros(4, dtype=[("id", "i8")])
+    rf = h5io.ResultsFile(path, 4, 3, lab, True, flush_every=2)
+    # rows not written keep the reference's fill values (fitting.py:1635-1662)
+    rf.write_row(1, (np.array([5, 6, 7]), np.ones(3), np.ones(3), np.ones(3),
+                     np.ones((3, 3, 3)), 7, np.ones(3), -2.5, 3.5, np.ones(3),
+                     np.ones(3), np.ones(3), np.ones(3)))
+    rf.close()
+    idx = h5io.read_dataset(path, "model_idx")
+    assert idx.dtype == np.int32 and np.all(idx[0] == -99) and list(idx[1]) == [5, 6, 7]
+    assert np.all(h5io.read_dataset(path, "ml_scale")[0] == 1.)
+    assert np.all(h5io.read_dataset(path, "ml_av")[2] == 0.)
+    assert h5io.read_dataset(path, "obj_Nbands").dtype == np.int16
+    assert h5io.read_dataset(path, "samps_logp").dtype == np.float32
+    with pytest.raises(OSError):
+        h5io.ResultsFile(path, 4, 3, lab, True)
+    # running_io=False writes everything at close
+    p2 = os.path.join(str(tmp_path), "res2.h5")
+    rf = h5io.ResultsFile(p2, 2, 3, None, False, running_io=False)
+    rf.close()
+    assert "samps_dist" not in h5io.list_datasets(p2)
+    assert "model_idx" in h5io.list_datasets(p2)
+
+
+def test_read_reference_style_compound():
+    """Compound rows with sub-array members (the layout of the reference's
+    demo catalogue demos/Orion_l204.7_b-19.2.h5)."""
+    import tempfile
+    d = np.zeros(3, dtype=[("obj_id", "u8"), ("l", "f8"), ("mag", "f4", (8,)),
+                           ("parallax", "f4")])
+    d["mag"] = np.arange(24).reshape(3, 8)
+    with tempfile.TemporaryDirectory() as t:
+        p = os.path.join(t, "c.h5")
+        h5io.write_datasets(p, {"cat": d})
+        back = h5io.read_dataset(p, "cat")
+    assert back.dtype.names == d.dtype.names
+    assert np.array_equal(back["mag"], d["mag"])
