@@ -55,6 +55,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_float), C.c_int]),
     "brutus_enable_timing": (None, [C.c_int]),
     "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_cluster_workspace_bytes": (_sz, [_i32]),
     "brutus_cluster_lnl": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _i32, _vp, _sz, _vp, _vp]),

@@ -404,24 +404,103 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
     ndim_out[s] = ndim;
 }
 
-// AoS (nmodel, nfilt, 3) -> device grid blob; padded entries zero:
-//   [0, 3*NB*nmodel_pad)            band-major SoA [NB][3][nmodel_pad] for the
-//                                   full-grid scans (lane = model, coalesced),
-//   [3*NB*nmodel_pad, 2x that)      model-major [nmodel_pad][NB][3] for the
-//                                   kernels that gather individual models
-//                                   (one contiguous 12*NB-byte row per model).
+// AoS (nmodel, nfilt, 3) -> device grid blob; padded entries zero.  With
+// Np = nmodel_pad and offsets in 4-byte units:
+//   [0, 3*NB*Np)          f32 band-major SoA [NB][3][Np]   full-grid scans
+//   [3*NB*Np, 6*NB*Np)    f32 model-major   [Np][NB][3]    single-model gathers
+//   [6*NB*Np, 8*NB*Np)    f64 band-major    [NB][Np]       F0 = 10^(-0.4 mag)
+// F0 (the unreddened model flux, fitting.py:529) is star-independent, so it
+// is tabulated once here instead of 12 exponentials per tile of the full scan.
+// 2^(k/64), k = 0..63, correctly rounded.
+__constant__ double kExp2Tbl[64] = {
+    1, 1.0108892860517005, 1.0218971486541166, 1.0330248790212284,
+    1.0442737824274138, 1.0556451783605572, 1.0671404006768237, 1.0787607977571199,
+    1.0905077326652577, 1.1023825833078409, 1.1143867425958924, 1.1265216186082418,
+    1.1387886347566916, 1.1511892299529827, 1.1637248587775775, 1.1763969916502812,
+    1.189207115002721, 1.2021567314527031, 1.215247359980469, 1.22848053610687,
+    1.241857812073484, 1.2553807570246911, 1.2690509571917332, 1.2828700160787783,
+    1.2968395546510096, 1.3109612115247644, 1.3252366431597413, 1.3396675240533029,
+    1.3542555469368927, 1.3690024229745905, 1.383909881963832, 1.3989796725383112,
+    1.4142135623730951, 1.42961333839197, 1.4451808069770467, 1.460917794180647,
+    1.4768261459394993, 1.4929077282912648, 1.5091644275934228, 1.5255981507445384,
+    1.5422108254079407, 1.5590044002378369, 1.5759808451078865, 1.593142151342267,
+    1.6104903319492543, 1.6280274218573478, 1.6457554781539649, 1.6636765803267364,
+    1.681792830507429, 1.7001063537185235, 1.7186192981224779, 1.7373338352737062,
+    1.7562521603732995, 1.7753764925265212, 1.7947090750031072, 1.8142521755003989,
+    1.8340080864093424, 1.8539791250833855, 1.8741676341103, 1.8945759815869656,
+    1.9152065613971474, 1.9360617934922943, 1.9571441241754002, 1.9784560263879509};
+
+__device__ __forceinline__ double fast_exp10(double x, const double *__restrict__ tbl = kExp2Tbl) {
+    // `tbl`: the 64-entry table, by default the constant-memory copy; the hot
+    // kernels pass an LDS copy (stage_exp_table) so that the divergent look-up
+    // is a ds_read instead of a vector-memory load.
+    // 10^x = 2^e * 2^(k/64) * exp(t):  n = rint(64 x log2 10) = 64 e + k,
+    // t = (x - n log10(2)/64) ln 10, |t| <= ln(2)/128.  Two-term Cody-Waite
+    // reduction (the high part has 32 significant bits, so n*hi is exact), a
+    // degree-5 polynomial and one table look-up: ~13 f64 ops (ocml exp10: ~40),
+    // error < 1 ulp + table rounding on |x| < 300.
+    const double n = rint(x * 212.60339807279118);
+    double r = fma(-n, 0.0047035936804604717, x);
+    r = fma(-n, 1.7892345153159123e-12, r);
+    const double t = r * 2.3025850929940459;
+    double pl = 8.3333333333333332e-03;                    // 1/5!
+    pl = fma(pl, t, 4.1666666666666664e-02);               // 1/4!
+    pl = fma(pl, t, 1.6666666666666666e-01);               // 1/3!
+    pl = fma(pl, t, 0.5);
+    pl = fma(pl, t, 1.0);
+    pl = fma(pl, t, 1.0);
+    const int ni = (int)n;
+    return ldexp(tbl[ni & 63] * pl, ni >> 6);
+}
+
+// Table-free variant (degree-13 polynomial after the same kind of reduction,
+// 19 f64 ops, <= 1.5 ulp): used where VGPR pressure, not ALU, is the limit.
+__device__ __forceinline__ double poly_exp10(double x) {
+    const double n = rint(x * 3.3219280948873623);
+    double r = fma(-n, 3.01029995663839276e-01, x);
+    r = fma(-n, 1.42502325707809354e-17, r);
+    const double t = r * 2.3025850929940457;
+    double pl = 1.6059043836821613e-10;                    // 1/13!
+    pl = fma(pl, t, 2.08767569878681e-09);
+    pl = fma(pl, t, 2.505210838544172e-08);
+    pl = fma(pl, t, 2.755731922398589e-07);
+    pl = fma(pl, t, 2.7557319223985893e-06);
+    pl = fma(pl, t, 2.48015873015873e-05);
+    pl = fma(pl, t, 1.984126984126984e-04);
+    pl = fma(pl, t, 1.3888888888888889e-03);
+    pl = fma(pl, t, 8.333333333333333e-03);
+    pl = fma(pl, t, 4.1666666666666664e-02);
+    pl = fma(pl, t, 1.6666666666666666e-01);
+    pl = fma(pl, t, 0.5);
+    pl = fma(pl, t, 1.0);
+    pl = fma(pl, t, 1.0);
+    return ldexp(pl, (int)n);
+}
+
+// Copy the table to LDS; call from all threads of a >= 64-thread workgroup,
+// followed by __syncthreads().
+__device__ __forceinline__ void stage_exp_table(double *lds_tbl) {
+    if (threadIdx.x < 64) lds_tbl[threadIdx.x] = kExp2Tbl[threadIdx.x];
+}
+
 __global__ void k_relayout(const float *__restrict__ aos, int64_t nmodel, int nfilt, int nb,
                            int64_t nmodel_pad, float *__restrict__ blob) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= nmodel_pad) return;
     float *rows = blob + (int64_t)3 * nb * nmodel_pad;
-    for (int j = 0; j < nb; ++j)
+    double *f0_soa = reinterpret_cast<double *>(blob + (int64_t)6 * nb * nmodel_pad);
+    for (int j = 0; j < nb; ++j) {
+        float m = 0.f;
         for (int k = 0; k < 3; ++k) {
             float v = 0.f;
             if (i < nmodel && j < nfilt) v = aos[(i * nfilt + j) * 3 + k];
+            if (k == 0) m = v;
             blob[(int64_t)(3 * j + k) * nmodel_pad + i] = v;
             rows[(i * nb + j) * 3 + k] = v;
         }
+        const double f0 = fast_exp10(-0.4 * (double)m);
+        f0_soa[(int64_t)j * nmodel_pad + i] = f0;
+    }
 }
 
 // Phase 1: run `kmax` magnitude sweeps for every (star, model); emit per
@@ -747,6 +826,11 @@ __global__ void k_calib_stream(const float *__restrict__ in, double *__restrict_
         out[i] = (double)in[i];
 }
 
+__global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__ y, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = fast_exp10(x[i]);
+}
+
 __global__ void k_set_i32(int32_t *p, int n, int32_t v) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -768,31 +852,6 @@ __global__ void k_set_i32(int32_t *p, int n, int32_t v) {
 // statistic lnl_p and the "not a survivor" first-cut statistic lnprob_ns.
 // K1 = 2 for >90 % of stars; stars with a different K1 are re-run (a few
 // percent of the batch).  Only two full planes are written (16 B per pair).
-
-__device__ __forceinline__ double fast_exp10(double x) {
-    // 10^x = 2^n * e^t, n = rint(x log2 10), t = (x - n log10 2) ln 10, |t| <= 0.3466.
-    // Cody-Waite reduction + degree-13 Taylor polynomial: <= 1.5 ulp on [-300, 300];
-    // 19 f64 ops instead of ~40 for ocml's exp10.
-    const double n = rint(x * 3.3219280948873623);
-    double r = fma(-n, 3.01029995663839276e-01, x);       // log10(2) high part (exactly representable head)
-    r = fma(-n, 1.42502325707809354e-17, r);               // low part
-    const double t = r * 2.3025850929940457;
-    double pl = 1.6059043836821613e-10;                    // 1/13!
-    pl = fma(pl, t, 2.08767569878681e-09);                 // 1/12!
-    pl = fma(pl, t, 2.505210838544172e-08);                // 1/11!
-    pl = fma(pl, t, 2.755731922398589e-07);                // 1/10!
-    pl = fma(pl, t, 2.7557319223985893e-06);               // 1/9!
-    pl = fma(pl, t, 2.48015873015873e-05);                 // 1/8!
-    pl = fma(pl, t, 1.984126984126984e-04);                // 1/7!
-    pl = fma(pl, t, 1.3888888888888889e-03);               // 1/6!
-    pl = fma(pl, t, 8.333333333333333e-03);                // 1/5!
-    pl = fma(pl, t, 4.1666666666666664e-02);               // 1/4!
-    pl = fma(pl, t, 1.6666666666666666e-01);               // 1/3!
-    pl = fma(pl, t, 0.5);
-    pl = fma(pl, t, 1.0);
-    pl = fma(pl, t, 1.0);
-    return ldexp(pl, (int)n);
-}
 
 struct Gram {   // weighted inner products of {1, a=r0, b=dr, y}; weights 1/mags_var
     double ua, ub, uy, aa, ab, bb, ay, by, yy;
@@ -853,10 +912,10 @@ __device__ __forceinline__ void gram_sweep(const Gram &G, double S, const DevPar
 }
 
 // MLE quantities as mle_eval, with F = F0 * 10^(-0.4 av R) through fast_exp10.
-template <int NB>
+template <int NB, bool TBL>
 __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[NB],
                                          const StarPrep &sp, const DevParams &p, double av,
-                                         double rv, Mle &o) {
+                                         double rv, const double *__restrict__ tbl, Mle &o) {
     const double fac = -0.92103403719761827361;
     const double mav = -0.4 * av;
     double F[NB];
@@ -864,7 +923,7 @@ __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[N
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const double R = (double)c.r0[j] + rv * (double)c.dr[j];
-        const double f = F0[j] * fast_exp10(mav * R);
+        const double f = F0[j] * (TBL ? fast_exp10(mav * R, tbl) : poly_exp10(mav * R));
         F[j] = f;
         const double fw = f * sp.iV[j];
         s_num += sp.d[j] * fw;
@@ -917,10 +976,21 @@ __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[N
     o.i22 = r_den;
 }
 
+// F0 of model i from the band-major table (coalesced) / of one model from its row.
+template <int NB>
+__device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t nmodel_pad,
+                                        int64_t i, double (&F0)[NB]) {
+    const double *t = reinterpret_cast<const double *>(grid + (int64_t)6 * NB * nmodel_pad);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) F0[j] = t[(int64_t)j * nmodel_pad + i];
+}
+// The gather kernels are close to memory-bound and VGPR-limited, so they
+// recompute F0 with the table-free polynomial (<= 1 ulp from the tabulated
+// value) instead of reading 8*NB more bytes per model.
 template <int NB>
 __device__ __forceinline__ void compute_F0_fast(const Coef<NB> &c, double (&F0)[NB]) {
 #pragma unroll
-    for (int j = 0; j < NB; ++j) F0[j] = fast_exp10(-0.4 * (double)c.m[j]);
+    for (int j = 0; j < NB; ++j) F0[j] = poly_exp10(-0.4 * (double)c.m[j]);
 }
 
 // lnl as `loglike` returns it for a model the cull dropped / kept, and the
@@ -953,7 +1023,7 @@ __device__ __forceinline__ double first_cut_lnprob(const StarPrep &sp, double ln
 //   v = 2k, 2k+1 : L_k, T_k for sweep k < KS   (only sweeps <= kfix are run)
 //   v = 2KS      : max lnl_p;  v = 2KS+1 : max lnprob_ns
 template <int NB, int KS, int FS_G>
-__global__ void __launch_bounds__(TILE)
+__global__ void __launch_bounds__(TILE, 3)   // <=168 VGPRs: 3 waves/SIMD (LDS allows 3 blocks/CU)
 k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
         const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
         const int32_t *__restrict__ kfix, int tiles_per_block, int ntile, Planes pl,
@@ -961,6 +1031,9 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     constexpr int NV = 2 * KS + 2;
     extern __shared__ double smax[];   // [FS_G][NV][TILE]
     __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int g0 = blockIdx.y * FS_G;
     const int ng = min(FS_G, nrun - g0);
     for (int q = threadIdx.x; q < FS_G * NV * TILE; q += TILE) smax[q] = -INFINITY;
@@ -973,7 +1046,7 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         Coef<NB> c;
         load_coef<NB>(grid, nmodel_pad, i, c);
         double F0[NB];
-        compute_F0_fast<NB>(c, F0);
+        load_F0<NB>(grid, nmodel_pad, i, F0);
         for (int g = 0; g < ng; ++g) {
             const int s = star_ids[g0 + g];
             const StarPrep &sp = stars[s];
@@ -993,7 +1066,7 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 }
             }
             Mle m;
-            mle_fast<NB>(c, F0, sp, p, av, rv, m);
+            mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             const double lnl = -0.5 * m.chi2;
             double lnlp = lnl;
             if (sp.has_par) {
@@ -1202,7 +1275,7 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
 // and, per work item, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
 // M = max final lnprob.
 template <int NB>
-__global__ void __launch_bounds__(TILE)
+__global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
         const int32_t *__restrict__ k2state, int first, const int32_t *__restrict__ surv_idx,
@@ -1245,7 +1318,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = -0.5 * pl.chi2[o];
             }
             Mle m;
-            mle_fast<NB>(c, F0, sp, p, av, rv, m);
+            mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; it < niter; ++it) {
                 double dav = (m.a_num + (p.av_mean - av) * p.av_ivar) / (m.a_ss + p.av_ivar) * step;
@@ -1256,7 +1329,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 if (drv < p.rvmin - rv) drv = p.rvmin - rv;
                 if (drv > p.rvmax - rv) drv = p.rvmax - rv;
                 rv += drv;
-                mle_fast<NB>(c, F0, sp, p, av, rv, m);
+                mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
                 lnl_new = -0.5 * m.chi2;
                 dl = fabs(lnl_new - lnl_old);
                 if (lnl_new < lnl_old) step /= 1.2;
@@ -1336,7 +1409,7 @@ __global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
 // re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
 // full-grid scan write eleven planes.
 template <int NB>
-__global__ void __launch_bounds__(TILE)
+__global__ void __launch_bounds__(TILE, 2)
 k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
        const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
@@ -1373,7 +1446,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
                 gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
             }
             Mle m;
-            mle_fast<NB>(c, F0, sp, p, av, rv, m);
+            mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             rec[0] = final_lnl(sp, p, m.chi2, false);
             rec[1] = m.chi2;
             rec[2] = m.scale;
@@ -1914,7 +1987,8 @@ int brutus_padded_filters(int nfilt) { return padded_nb(nfilt); }
 size_t brutus_grid_soa_bytes(int64_t nmodel, int nfilt) {
     const int nb = padded_nb(nfilt);
     if (nb < 0 || nmodel <= 0) return 0;
-    return 2 * (size_t)nb * 3 * (size_t)pad_models(nmodel) * sizeof(float);   // SoA + model-major
+    // f32 coefficients (SoA + model-major) and the f64 F0 table (SoA)
+    return 8 * (size_t)nb * (size_t)pad_models(nmodel) * sizeof(float);
 }
 
 int brutus_grid_relayout(const float *d_models_aos, int64_t nmodel, int nfilt, float *d_grid_soa,
@@ -2073,6 +2147,14 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *stream) {
     if (!d_in || !d_out || n <= 0) return fail(BRUTUS_EINVAL, "bad calibration arguments");
     hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(TILE), 0, (hipStream_t)stream, d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream) {
+    if (!d_x || !d_y || n <= 0) return fail(BRUTUS_EINVAL, "bad arguments");
+    hipLaunchKernelGGL(k_debug_exp10, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, d_x, d_y, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

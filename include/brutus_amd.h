@@ -67,10 +67,12 @@ const char *brutus_last_error(void);
 
 /* ---- model grid ------------------------------------------------------------
  * `utils.load_models` (utils.py:588-591) returns models as (Nmodel, Nfilt, 3)
- * float32 = (mag, R, dR/dRv) per band.  The device grid blob holds two copies:
- * a band-major structure-of-arrays [nfilt_pad][3][nmodel_pad] that the
- * full-grid scans stream with coalesced loads, followed by a model-major
- * [nmodel_pad][nfilt_pad][3] copy for the kernels that gather single models.
+ * float32 = (mag, R, dR/dRv) per band.  The device grid blob holds the
+ * coefficients twice -- a band-major structure-of-arrays
+ * [nfilt_pad][3][nmodel_pad] that the full-grid scans stream with coalesced
+ * loads, and a model-major [nmodel_pad][nfilt_pad][3] copy for the kernels
+ * that gather single models -- followed by the band-major float64 table of
+ * unreddened model fluxes 10^(-0.4 mag) (fitting.py:529).
  * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters),
  * nmodel_pad = nmodel rounded up to 256.  Padded entries are zero. */
 int brutus_padded_filters(int nfilt);              /* <0 if nfilt unsupported     */
@@ -153,6 +155,9 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
  * on a known byte count (MI355X_MICROARCH.md, HBM section). */
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
                              void *stream);
+
+/* Test hook: y[i] = the kernels' 10^x (table + polynomial) for n inputs. */
+int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
 
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */

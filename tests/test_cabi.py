@@ -36,7 +36,7 @@ def test_abi_version_and_queries():
     assert L.brutus_padded_filters(6) == 8
     assert L.brutus_padded_filters(12) == 12
     assert L.brutus_padded_filters(33) < 0
-    assert L.brutus_grid_soa_bytes(1000, 12) == 2 * 12 * 3 * 1024 * 4
+    assert L.brutus_grid_soa_bytes(1000, 12) == 8 * 12 * 1024 * 4
     assert L.brutus_workspace_bytes(750000, 12, 64) > 13 * 8 * 750000 * 64
     assert L.brutus_workspace_bytes(750000, 40, 64) == 0
 

@@ -293,16 +293,41 @@ def test_fit_end_to_end_hdf5(tmp_path):
     assert h5io.read_dataset(f, "ml_cov_sar").shape == (100, 60, 3, 3)
     assert h5io.read_dataset(f, "obj_Nbands").dtype == np.int16
     assert np.array_equal(h5io.read_dataset(f, "labels")["id"], np.arange(100))
-    # oracle with the same single sequential stream
+    # oracle with the same single sequential stream; fit() first drops bands
+    # with magerr > merr_max = 0.25 (fitting.py:1405-1410, pinned by
+    # tests/test_setup_host.py), so the oracle gets the same band mask
     lnprior = O.static_lnprior(labels, lmask)
+    mask = BF._setup(st["flux"], st["err"], st["mask"], None,
+                     data_coords=st["coords"], lngalprior=galprior)[2]
+    assert not np.array_equal(mask, st["mask"])     # the case is exercised
     rs = np.random.RandomState(862)
     evid = h5io.read_dataset(f, "obj_log_evid")
     dist = h5io.read_dataset(f, "samps_dist")
     for i in range(100):
-        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models,
+        ref = O.fit_star(st["flux"][i], st["err"][i], mask[i], models,
                          lnprior, labels, st["coords"][i], st["parallax"][i],
                          st["parallax_err"][i], rs, galprior, Nmc_prior=25,
                          Ndraws=60)
         assert np.array_equal(idx[i], ref[0]), i
         assert abs(evid[i] - np.float32(ref[7])) <= 1e-5 * abs(ref[7]) + 1e-6
         assert relerr(ref[9].astype(np.float32), dist[i]) < 1e-5
+
+
+def test_device_exp10_accuracy():
+    """The kernels' own 10^x (Cody-Waite + 64-entry table + degree-5 polynomial)
+    against numpy over the range the path uses (fluxes of mag -5 ... 40 and
+    reddening factors down to 10^-11)."""
+    import torch
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(0)
+    x = np.concatenate([rng.uniform(-16., 2., 200000), rng.uniform(-300., 300., 20000),
+                        np.array([0., -0.0, 1e-300, -1e-17, 1., -1., 2.5, -7.25])])
+    tx = torch.from_numpy(x).cuda()
+    ty = torch.empty_like(tx)
+    _lib.check(L.brutus_debug_exp10(tx.data_ptr(), ty.data_ptr(), x.size, None))
+    torch.cuda.synchronize()
+    y = ty.cpu().numpy()
+    ref = 10. ** x
+    assert np.max(np.abs(y - ref) / ref) < 4.5e-16     # <= 2 ulp
+    assert y[x == 0.][0] == 1.0
