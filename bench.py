@@ -89,6 +89,25 @@ def cpu_baseline(models, stars, cfg_kwargs, budget_s):
                       % (n, models.shape[0], models.shape[1], dt, kind_note)}
 
 
+def measured_traffic(kernel, batch, config):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under
+    profiles/ (FETCH_SIZE and WRITE_SIZE in separate runs, corrected with the
+    calibration stream as MI355X_MICROARCH.md prescribes; see
+    profiles/README.md).  None when no measurement exists for this
+    kernel / batch / config."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+        for row in table["rows"]:
+            if (row["kernel"] == kernel and row["batch"] == batch
+                    and row["config"] == config):
+                return row["hbm_bytes_per_launch"]
+    except (IOError, ValueError, KeyError):
+        pass
+    return None
+
+
 def main():
     args = parse()
     import torch
@@ -145,7 +164,8 @@ def main():
                                    stars["mask"][sl],
                                    stars["parallax"][sl] if with_par else None,
                                    stars["parallax_err"][sl] if with_par else None))
-    cap = 32 << 20
+    # record buffer: the synthetic stars select up to ~500k models each
+    cap = max(32 << 20, B * 600000)
     sel_bufs = (torch.empty(cap, dtype=torch.int32, device=dev),
                 torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
 
@@ -168,6 +188,9 @@ def main():
     fence()
     dt = time.perf_counter() - t0
     nsel_total = int(out[2][-1].item())
+    if nsel_total > cap:
+        raise SystemExit("record buffer overflow (%d > %d): timing would be invalid"
+                         % (nsel_total, cap))
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -196,7 +219,8 @@ def main():
         achieved = B * bytes_per_star / (avg[dom] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved,
                     "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                    "frac": achieved / HBM_PEAK_GBS,
+                    "traffic": measured_traffic(dom, B, args.config),
                     "avg_launch_ms": avg[dom],
                     "all_kernels_ms": avg,
                     "algorithmic_bytes_per_launch": B * bytes_per_star}
