@@ -169,3 +169,72 @@ def load_offsets(filepath, filters=None, verbose=True):
         for filt, zp in zip(filters, offsets):
             sys.stderr.write('{0} ({1:3.2}%)\n'.format(filt, 100 * (zp - 1.)))
     return offsets
+
+
+# ---------------------------------------------------------------------------
+# consumers of the fit output: host-side, they act on the
+# Ndraws resampled models of one object, not on the grid
+# ---------------------------------------------------------------------------
+def get_seds(mag_coeffs, av=None, rv=None, return_flux=False,
+             return_rvec=False, return_drvec=False):
+    """Reddened SEDs `mag + Av (R0 + Rv dR/dRv)` (optionally as flux densities)
+    from `(Nmodel, Nband, 3)` magnitude coefficients; same call and returns
+    as reference `utils.get_seds` (utils.py:1089-1159, kernel utils.py:286-347).
+    Float32 coefficients are promoted to float64 first, like numba does."""
+    c = np.asarray(mag_coeffs, dtype=np.float64)
+    n = c.shape[0]
+    av = np.zeros(n) if av is None else np.broadcast_to(np.asarray(av, float), (n,))
+    rv = np.full(n, 3.3) if rv is None else np.broadcast_to(np.asarray(rv, float), (n,))
+    drvecs = c[:, :, 2].copy()
+    rvecs = c[:, :, 1] + rv[:, None] * drvecs
+    seds = c[:, :, 0] + av[:, None] * rvecs
+    if return_flux:
+        seds = 10. ** (-0.4 * seds)
+        scale = (-0.4 * log(10.)) * seds
+        rvecs = rvecs * scale
+        drvecs = drvecs * scale
+    out = (seds,)
+    if return_rvec:
+        out += (rvecs,)
+    if return_drvec:
+        out += (drvecs,)
+    return out if len(out) > 1 else seds
+
+
+def draw_sar(scales, avs, rvs, covs_sar, ndraws=500, avlim=(0., 6.),
+             rvlim=(1., 8.), rstate=None):
+    """`ndraws` in-bounds draws of (scale, Av, Rv) around each resampled model,
+    consuming `rstate.multivariate_normal` like reference utils.py:765-842
+    (redraw batches of `ndraws` until enough fall inside the bounds)."""
+    if rstate is None:
+        rstate = getattr(np, "random_intel", np.random)
+    n = len(scales)
+    out = np.zeros((3, n, ndraws))
+    for i in range(n):
+        kept = [np.empty((3, 0))]
+        have = 0
+        while have < ndraws:
+            d = rstate.multivariate_normal([scales[i], avs[i], rvs[i]],
+                                           covs_sar[i], size=ndraws).T
+            ok = ((d[0] >= 0.) & (d[1] >= avlim[0]) & (d[1] <= avlim[1])
+                  & (d[2] >= rvlim[0]) & (d[2] <= rvlim[1]))
+            kept.append(d[:, ok])
+            have += int(ok.sum())
+        out[:, i, :] = np.concatenate(kept, axis=1)[:, :ndraws]
+    return out[0], out[1], out[2]
+
+
+def phot_loglike(data, data_err, data_mask, models, dim_prior=True):
+    """ln-likelihood of noisy fluxes `data` against noiseless model fluxes
+    `models (Nmodel, Nfilt)` (reference utils.py:1162-1215): Gaussian, or the
+    chi-square-distribution form with `Ndim - 3` degrees of freedom."""
+    from scipy.special import gammaln, xlogy
+    mask = np.asarray(data_mask, dtype=bool)
+    flux, var = np.asarray(data)[mask], np.square(np.asarray(data_err)[mask])
+    ndim = int(mask.sum())
+    resid = flux - np.asarray(models)[:, mask]
+    chi2 = np.sum(np.square(resid) / var, axis=1)
+    if dim_prior:
+        a = 0.5 * (ndim - 3)
+        return xlogy(a - 1., chi2) - chi2 / 2. - gammaln(a) - np.log(2.) * a
+    return -0.5 * chi2 - 0.5 * (ndim * np.log(2. * np.pi) + np.sum(np.log(var)))
