@@ -32,61 +32,37 @@ HBM_PEAK_GBS = 8000.0   # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64, help="stars per step per GPU")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3))
     ap.add_argument("--nmodel", type=int, default=750000)
     ap.add_argument("--nfilt", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget for the CPU baseline sample (0 = skip)")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="host threads / HIP streams per GPU, each with its own "
+                         "workspace, taking the steps round-robin (kernels of "
+                         "consecutive batches overlap on the device)")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
 
-def cpu_baseline(models, stars, cfg_kwargs, budget_s):
-    """Time the CPU restatement (oracle) on a bounded sample of the same
-    workload: rank 0, N=1 only.  Baseline, not the target."""
+def cpu_baseline(config, nmodel, nfilt, budget_s):
+    """Time the CPU restatement (oracle/loglike_ref.c) on this host's cores for
+    a bounded sample of the same workload (rank 0, N=1 only), in a fresh
+    subprocess so that its worker pool never shares the GPU process.
+    Baseline, not the target."""
+    import subprocess
+    cmd = [sys.executable, "-m", "oracle.cpu_bench", "--config", str(config),
+           "--nmodel", str(nmodel), "--nfilt", str(nfilt), "--seconds", str(budget_s)]
     try:
-        from oracle import c_oracle
-        have_c = c_oracle.available()
-    except Exception:
-        have_c = False
-    n = 0
-    t0 = time.time()
-    if have_c:
-        from oracle import c_oracle
-        cores = c_oracle.num_threads()
-        # threads each take whole stars
-        while True:
-            take = cores
-            idx = [(n + j) % len(stars["flux"]) for j in range(take)]
-            c_oracle.loglike_many(stars["flux"][idx], stars["err"][idx],
-                                  stars["mask"][idx], models,
-                                  stars["parallax"][idx], stars["parallax_err"][idx],
-                                  **cfg_kwargs)
-            n += take
-            if time.time() - t0 > budget_s * 0.6:
-                break
-        kind_note = "C restatement oracle/loglike_ref.c, OpenMP over stars"
-    else:
-        from oracle import brutus_oracle as O
-        cores = 1
-        while True:
-            i = n % len(stars["flux"])
-            par = stars["parallax"][i]
-            O.loglike(stars["flux"][i], stars["err"][i], stars["mask"][i], models,
-                      parallax=None if not np.isfinite(par) else par,
-                      parallax_err=None if not np.isfinite(par) else stars["parallax_err"][i],
-                      **cfg_kwargs)
-            n += 1
-            if time.time() - t0 > budget_s * 0.6:
-                break
-        kind_note = "numpy restatement oracle/brutus_oracle.py"
-    dt = time.time() - t0
-    return {"value": n / dt, "unit": "stars/s", "cores": int(cores), "kind": "port",
-            "sample": "%d stars x %d models x %d bands in %.1f s (%s)"
-                      % (n, models.shape[0], models.shape[1], dt, kind_note)}
+        out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                             timeout=max(120., 10 * budget_s), check=True)
+        return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    except Exception as e:          # the GPU numbers stay valid without it
+        return {"value": None, "unit": "stars/s", "cores": 0, "kind": "port",
+                "sample": "cpu baseline failed: %r" % (e,)}
 
 
 def measured_traffic(kernel, batch, config):
@@ -156,7 +132,9 @@ def main():
     params = fitting._make_params(
         (0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
         3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
-    eng = fitting._Engine(grid, max_batch=B, mem_budget=64e9)
+    NS = max(1, args.streams)
+    engines = [fitting._Engine(grid, max_batch=B, mem_budget=64e9) for _ in range(NS)]
+    eng = engines[0]
     batches = []
     for b in range(nb_pool):
         sl = slice(b * B, (b + 1) * B)
@@ -166,25 +144,50 @@ def main():
                                    stars["parallax_err"][sl] if with_par else None))
     # record buffer: the synthetic stars select up to ~500k models each
     cap = max(32 << 20, B * 600000)
-    sel_bufs = (torch.empty(cap, dtype=torch.int32, device=dev),
-                torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
+    sel_bufs = [(torch.empty(cap, dtype=torch.int32, device=dev),
+                 torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
+                for _ in range(NS)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 
-    def step(i):
+    def step(i, j=0):
         f, e, m, p, pe, hp = batches[i % nb_pool]
-        return eng.fit_batch_device(f, e, m, p, pe, hp, params,
-                                    sel_buffers=sel_bufs)
+        return engines[j].fit_batch_device(f, e, m, p, pe, hp, params,
+                                           sel_buffers=sel_bufs[j])
+
+    def run_steps(n):
+        """n steps; with --streams > 1 the steps are dealt round-robin to NS
+        host threads, each driving its own HIP stream and workspace."""
+        if NS == 1:
+            out = None
+            for i in range(n):
+                out = step(i)
+            return out
+        import threading
+        outs = [None] * NS
+
+        def worker(j):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[j]):
+                for i in range(j, n, NS):
+                    outs[j] = step(i, j)
+                streams[j].synchronize()
+
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(NS)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        return next(o for o in outs if o is not None)
 
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        out = step(i)
+    run_steps(max(args.warmup, NS if args.warmup else 0))
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = step(i)
+    out = run_steps(args.steps)
     fence()
     dt = time.perf_counter() - t0
     nsel_total = int(out[2][-1].item())
@@ -248,6 +251,7 @@ def main():
                    "timed_region": "brutus_fit_batch: device-resident star vectors -> "
                                    "device-resident compact survivor records",
                    "selected_models_last_batch": nsel_total,
+                   "streams_per_gpu": NS,
                    "parallelism": "stars sharded, %d rank(s)" % world},
         "hbm_algorithmic_frac_whole_job":
             stars_per_s / world * nmodel * nfilt * 12 / 1e9 / HBM_PEAK_GBS,
@@ -255,8 +259,7 @@ def main():
     if roofline is not None:
         line["roofline"] = roofline
     if world == 1 and args.cpu_seconds > 0:
-        cpu_kw = dict(kw)
-        line["cpu_baseline"] = cpu_baseline(models, stars, cpu_kw, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(args.config, nmodel, nfilt, args.cpu_seconds)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -80,14 +80,26 @@ def loglike(data, data_err, data_mask, mag_coeffs, avlim=(0., 20.),
             out["rv"], icov)
 
 
-def loglike_many(flux, err, mask, models, parallax, parallax_err, **kw):
-    """Loop over stars (OpenMP parallelism is over models inside each star)."""
-    res = []
-    for i in range(len(flux)):
-        par = parallax[i] if parallax is not None else None
-        pe = parallax_err[i] if parallax_err is not None else None
-        if par is not None and not np.isfinite(par):
-            par, pe = None, None
-        res.append(loglike(flux[i], err[i], mask[i], models, parallax=par,
-                           parallax_err=pe, **kw))
-    return res
+def _one(args):
+    flux, err, mask, models, par, pe, kw, serial = args
+    if serial:
+        _load().brutus_ref_set_threads(1)
+    if par is not None and not np.isfinite(par):
+        par, pe = None, None
+    return loglike(flux, err, mask, models, parallax=par, parallax_err=pe, **kw)
+
+
+def loglike_many(flux, err, mask, models, parallax, parallax_err, threads=1, **kw):
+    """Many stars.  `threads == 1`: one star after the other, OpenMP over models
+    inside each; `threads > 1`: a pool of host threads, one serial star each
+    (ctypes releases the GIL during the C call)."""
+    models = np.ascontiguousarray(models, dtype=np.float32)
+    jobs = [(flux[i], err[i], mask[i], models,
+             None if parallax is None else parallax[i],
+             None if parallax_err is None else parallax_err[i], kw, threads > 1)
+            for i in range(len(flux))]
+    if threads <= 1:
+        return [_one(j) for j in jobs]
+    from concurrent.futures import ThreadPoolExecutor
+    with ThreadPoolExecutor(max_workers=threads) as pool:
+        return list(pool.map(_one, jobs))

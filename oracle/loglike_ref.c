@@ -19,7 +19,9 @@
  * The numpy row sums at fitting.py:745,792,807 use numpy's pairwise-8 order
  * for 8 <= n <= 128; rowsum() reproduces it.
  *
- * OpenMP parallelises over models inside one star (the reference is serial).
+ * OpenMP parallelises over models inside one star (the reference is serial);
+ * bench.py's CPU baseline instead runs one serial star per host thread
+ * (brutus_ref_set_threads(1) + a thread pool), which scales better.
  */
 #include <math.h>
 #include <stdint.h>
@@ -40,6 +42,16 @@ int brutus_ref_num_threads(void) {
     return omp_get_max_threads();
 #else
     return 1;
+#endif
+}
+
+/* Per-thread OpenMP team size for subsequent calls from the calling thread
+ * (1 = serial inside a star, so that the caller can parallelise over stars). */
+void brutus_ref_set_threads(int n) {
+#ifdef _OPENMP
+    omp_set_num_threads(n > 0 ? n : 1);
+#else
+    (void)n;
 #endif
 }
 

@@ -331,3 +331,60 @@ def test_device_exp10_accuracy():
     ref = 10. ** x
     assert np.max(np.abs(y - ref) / ref) < 4.5e-16     # <= 2 ulp
     assert y[x == 0.][0] == 1.0
+
+
+@pytest.mark.parametrize("nmodel,nfilt,nstar", [(1, 4, 1), (257, 5, 3), (1000, 20, 2),
+                                                (513, 32, 2), (4096, 12, 70)])
+def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
+    """Ragged / extreme shapes: a single model, model counts that are not a
+    multiple of the 256-model tile, band counts that need padding (5 -> 8,
+    20 -> 24), the maximum 32 bands, more stars than one scan group.  Both entry
+    points against the C oracle."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.pdf import scale_parallax_lnprior
+    from oracle import c_oracle
+    models, _, _ = synth.make_grid(nmodel, nfilt, seed=nmodel + nfilt)
+    st = synth.make_stars(models, nstar, seed=3)
+    if nfilt > 6:
+        st["mask"][0, 1] = False
+    grid = fitting.DeviceGrid(models)
+    full = fitting.loglike_batch(st["flux"], st["err"], st["mask"], grid,
+                                 parallax=st["parallax"],
+                                 parallax_err=st["parallax_err"])
+    eng = fitting._Engine(grid, max_batch=nstar)
+    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18),
+                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
+                         st["parallax_err"], params)
+    for i in range(min(nstar, 6)):
+        par, pe = st["parallax"][i], st["parallax_err"][i]
+        ref = c_oracle.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
+                               parallax=par, parallax_err=pe)
+        got = (full["lnl"][i], int(full["ndim"][i]), full["chi2"][i],
+               full["scale"][i], full["av"][i], full["rv"][i],
+               fitting._icov_from6(full["icov6"][:, i, :]))
+        _cmp_loglike(got, ref, "generic %d" % i)
+        lnl, nd, chi2, sc, av, rv, icov = ref
+        with np.errstate(all="ignore"):
+            lnprob = lnl + scale_parallax_lnprior(
+                sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), par, pe)
+        lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+        sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
+        assert np.array_equal(sel, recs[i]["sel"]), i
+        assert relerr(lnl[sel], recs[i]["lnlike"]) < RTOL
+        assert relerr(sc[sel], recs[i]["scale"]) < RTOL
+
+
+def test_argument_errors():
+    from brutus_amd import fitting, synth
+    models, _, _ = synth.make_grid(300, 6, seed=1)
+    st = synth.make_stars(models, 1, seed=1)
+    f, e, m = st["flux"][0], st["err"][0], st["mask"][0]
+    with pytest.raises(ValueError, match="initial threshold"):
+        fitting.loglike(f, e, m, models, init_thresh=0.5, ltol_subthresh=1e-2)
+    with pytest.raises(TypeError):
+        fitting.loglike(f, e, m, models, init_thresh=None)
+    with pytest.raises(ValueError, match="filters"):
+        fitting.DeviceGrid(np.zeros((10, 33, 3), np.float32))
+    with pytest.raises(ValueError, match="bands"):
+        fitting.loglike(f[:5], e[:5], m[:5], models)
