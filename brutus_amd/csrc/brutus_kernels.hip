@@ -1141,7 +1141,8 @@ __global__ void k_fdecide(int nblkx, int nstar, int nrun, const int32_t *__restr
 __global__ void __launch_bounds__(TILE)
 k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
             const double *__restrict__ thr, const double *__restrict__ other,
-            int64_t *__restrict__ counts, double *__restrict__ other_max) {
+            int64_t *__restrict__ counts, double *__restrict__ other_max,
+            unsigned long long *__restrict__ mask) {
     __shared__ int wsum[4];
     __shared__ double slot[4];
     const int s = blockIdx.y, c = blockIdx.x;
@@ -1151,15 +1152,22 @@ k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
     double om = -INFINITY;
     for (int t = t0; t < t1; ++t) {
         const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        bool hit = false;
         if (i < nmodel) {
             const int64_t o = (int64_t)s * nmodel + i;
             if (plane[o] > th) {
+                hit = true;
                 ++n;
             } else if (other) {
                 const double x = other[o];
                 if (x > om) om = x;
             }
         }
+        // one 64-bit membership word per wave: the scatter pass reads these
+        // instead of the 8-byte-per-model plane
+        const unsigned long long b = __ballot(hit);
+        if ((threadIdx.x & 63) == 0)
+            mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
@@ -1207,19 +1215,18 @@ __global__ void k_offsets(int nstar, const int64_t *__restrict__ counts,
 }
 
 __global__ void __launch_bounds__(TILE)
-k_cmp_scatter(int64_t nmodel, int ntile, const double *__restrict__ plane,
-              const double *__restrict__ thr, const int64_t *__restrict__ offsets,
-              int64_t capacity, int32_t *__restrict__ out_idx) {
+k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ mask,
+              const int64_t *__restrict__ offsets, int64_t capacity,
+              int32_t *__restrict__ out_idx) {
     __shared__ int wsum[4];
     const int s = blockIdx.y, c = blockIdx.x;
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
-    const double th = thr[s];
     int64_t base = offsets[(int64_t)s * NCHUNK + c];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
     for (int t = t0; t < t1; ++t) {
         const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        const bool sel = i < nmodel && plane[(int64_t)s * nmodel + i] > th;
-        const unsigned long long b = __ballot(sel);
+        const unsigned long long b = mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + w];
+        const bool sel = (b >> lane) & 1ull;
         const int rank = __popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[w] = __popcll(b);
         __syncthreads();
@@ -1576,6 +1583,7 @@ struct Workspace {
     int32_t *surv_idx;  // (S * nmodel,) worst case
     int64_t *surv_off;  // (S + 1,)
     int32_t *wbase_surv, *wbase_sel;   // (S + 1,)
+    unsigned long long *mask;          // (S, nmodel_pad / 64) membership words
     size_t bytes;
 };
 
@@ -1627,6 +1635,8 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         w.surv_off = (int64_t *)take(sizeof(int64_t) * (nstar + 1));
         w.wbase_surv = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
         w.wbase_sel = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
+        w.mask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
+                                            (size_t)(pad_models(nmodel) / 64));
     }
     w.bytes = off;
     return w;
@@ -1817,11 +1827,11 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     tm.begin("k_select");
     hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
                        w.pl.lnprob, w.thr_sel, (const double *)nullptr, w.counts,
-                       (double *)nullptr);
+                       (double *)nullptr, w.mask);
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts,
                        w.offsets, d_sel_off, w.wbase_sel);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                       w.pl.lnprob, w.thr_sel, w.offsets, capacity, d_sel_idx);
+                       w.mask, w.offsets, capacity, d_sel_idx);
     tm.end();
     tm.begin("k_emit");
     hipLaunchKernelGGL(k_emit<NB>, dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
@@ -1875,11 +1885,11 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     // ---- cull: ordered survivor lists -----------------------------------------
     tm.begin("k_surv_compact");
     hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile, w.pl.lnlp,
-                       w.thr_cull, w.pl.lnprob, w.counts, w.maxns_part);
+                       w.thr_cull, w.pl.lnprob, w.counts, w.maxns_part, w.mask);
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
                        w.surv_off, w.wbase_surv);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                       w.pl.lnlp, w.thr_cull, w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
+                       w.mask, w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
     tm.end();
 
     // ---- flux phase on survivors ------------------------------------------------
