@@ -44,6 +44,9 @@ def parse():
                     help="host threads / HIP streams per GPU, each with its own "
                          "workspace, taking the steps round-robin (kernels of "
                          "consecutive batches overlap on the device)")
+    ap.add_argument("--e2e-stars", type=int, default=8,
+                    help="stars for the end-to-end BruteForce.fit() rate reported "
+                         "beside the metric (0 = skip); rank 0, N=1 only")
     ap.add_argument("--no-kernel-timing", action="store_true")
     return ap.parse_args()
 
@@ -63,6 +66,35 @@ def cpu_baseline(config, nmodel, nfilt, budget_s):
     except Exception as e:          # the GPU numbers stay valid without it
         return {"value": None, "unit": "stars/s", "cores": 0, "kind": "port",
                 "sample": "cpu baseline failed: %r" % (e,)}
+
+
+def end_to_end(models, grid, stars, n, kw, with_par):
+    """Second number asked for by SURVEY 8d: the whole `BruteForce.fit()` --
+    device scan + host `lnpost` stage (user prior hook, numpy RandomState draws,
+    resampling) + HDF5 output -- on `n` stars of the same workload.  The host
+    stage dominates: it integrates the prior over every selected model with
+    Nmc_prior=50 draws each, exactly like the reference."""
+    import tempfile
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    _, labels, lmask = synth.make_mist_like_grid(models.shape[0], models.shape[1])
+    bf = fitting.BruteForce(models, labels, lmask)
+    bf.use_device_grid(grid)
+    bf.batch_size = n
+    with tempfile.TemporaryDirectory() as tmp:
+        t0 = time.perf_counter()
+        bf.fit(stars["flux"][:n], stars["err"][:n], stars["mask"][:n],
+               np.arange(n), os.path.join(tmp, "e2e"),
+               parallax=stars["parallax"][:n] if with_par else None,
+               parallax_err=stars["parallax_err"][:n] if with_par else None,
+               data_coords=stars["coords"][:n], lngalprior=gal_lnprior,
+               # Av-only end to end = Rv pinned by its prior: rvlim=(3.32, 3.32)
+               # would reject every Monte Carlo draw in lnpost (SURVEY F5)
+               rv_gauss=(3.32, 1e-6) if "rvlim" in kw else (3.32, 0.18),
+               rstate=np.random.RandomState(862), verbose=False)
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "stars/s", "stars": n,
+            "note": "BruteForce.fit incl. host lnpost (Nmc_prior=50, Ndraws=250) and HDF5"}
 
 
 def measured_traffic(kernel, batch, config):
@@ -258,6 +290,9 @@ def main():
     }
     if roofline is not None:
         line["roofline"] = roofline
+    if world == 1 and args.e2e_stars > 0:
+        line["fit_end_to_end"] = end_to_end(models, grid, stars, args.e2e_stars,
+                                            kw, with_par)
     if world == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(args.config, nmodel, nfilt, args.cpu_seconds)
     print(json.dumps(line))

@@ -429,10 +429,12 @@ def _lnpost_selected(sel, lnlike, scales, avs, rvs, icovs, lnprior, parallax,
         if Nmc_prior > 0:
             s_mc, a_mc, r_mc = mvn(np.transpose([scale, av, rv]), cov,
                                    size=Nmc_prior, rstate=rstate)
-            if dlabels is not None:
-                dl_mc = np.tile(dlabels[sel], Nmc_prior).reshape(-1, Nsel)
-            else:
+            if dlabels is None:
                 dl_mc = None
+            elif getattr(lngalprior, "broadcasts_labels", False):
+                dl_mc = dlabels[sel]      # (Nsel,) broadcasts against (Nmc, Nsel)
+            else:                         # the reference's tiled copy (fitting.py:1074)
+                dl_mc = np.tile(dlabels[sel], Nmc_prior).reshape(-1, Nsel)
             par_mc = np.sqrt(s_mc)
             dist_mc = 1. / par_mc
             lnp_mc = np.array(lngalprior(dist_mc, coord, labels=dl_mc),
@@ -445,7 +447,9 @@ def _lnpost_selected(sel, lnlike, scales, avs, rvs, icovs, lnprior, parallax,
             inb = ((s_mc >= 1e-20) & (a_mc >= avlim[0]) & (a_mc <= avlim[1])
                    & (r_mc >= rvlim[0]) & (r_mc <= rvlim[1]))
             lnp_mc[~inb] = -1e300
-            lnp = lnp + (logsumexp(lnp_mc, axis=0) - np.log(np.sum(inb, axis=0)))
+            top = np.max(lnp_mc, axis=0)
+            lnp = lnp + (np.log(np.sum(np.exp(lnp_mc - top), axis=0)) + top
+                         - np.log(np.sum(inb, axis=0)))
         else:
             # the reference's Nmc_prior=0 branch is unreachable (ZeroDivision at
             # fitting.py:970, then undefined dist_mc at :1107); implement the

@@ -20,10 +20,20 @@ from math import erf, log, sqrt
 
 import numpy as np
 
-try:
-    from scipy.special import logsumexp
-except ImportError:  # pragma: no cover
-    from scipy.misc import logsumexp
+
+
+def _lse(parts):
+    """log(sum_k exp(parts[k])) over a short list of equally shaped arrays,
+    the usual max-shifted form; lean replacement for scipy's `logsumexp` (whose
+    array-API plumbing dominates the runtime of this prior)."""
+    m = parts[0]
+    for q in parts[1:]:
+        m = np.maximum(m, q)
+    safe = np.where(np.isfinite(m), m, 0.)
+    acc = np.exp(parts[0] - safe)
+    for q in parts[1:]:
+        acc = acc + np.exp(q - safe)
+    return np.log(acc) + safe
 
 __all__ = ["galactic_to_RZ", "logn_disk", "logn_halo", "logp_feh",
            "logp_age_from_feh", "gal_lnprior"]
@@ -108,7 +118,7 @@ def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
             logn_halo(R, Z, R_solar, Z_solar, Rs_halo, eta_halo, q_halo_ctr,
                       q_halo_inf, r_q_halo) + volume + np.log(f_halo),
         ]
-        lnprior = logsumexp(comp, axis=0)
+        lnprior = _lse(comp)
         components = {"number_density": comp}
         if labels is not None:
             member = [c - lnprior for c in comp]   # ln P(component | position)
@@ -119,7 +129,7 @@ def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
                          zip(((feh_thin, feh_thin_sigma),
                               (feh_thick, feh_thick_sigma),
                               (feh_halo, feh_halo_sigma)), member)]
-                lnprior = lnprior + logsumexp(parts, axis=0)
+                lnprior = lnprior + _lse(parts)
                 components["feh"] = parts
             if "loga" in names:
                 age = 10. ** labels["loga"] / 1e9
@@ -127,8 +137,13 @@ def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
                                            feh_age_scale, nsigma_from_max_age,
                                            max_sigma, min_sigma) + w
                          for m, w in zip((feh_thin, feh_thick, feh_halo), member)]
-                lnprior = lnprior + logsumexp(parts, axis=0)
+                lnprior = lnprior + _lse(parts)
                 components["age"] = parts
     if return_components:
         return lnprior, components
     return lnprior
+
+
+#: `lnpost` may pass the (Nsel,) label table for (Nmc, Nsel) distances instead
+#: of a tiled copy: every label use above broadcasts.
+gal_lnprior.broadcasts_labels = True
