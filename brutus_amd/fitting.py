@@ -529,6 +529,45 @@ def lnpost(results, parallax=None, parallax_err=None, coord=None,
 
 
 # ---------------------------------------------------------------------------
+# host-stage worker pool (objects with their own RNG seed are independent)
+# ---------------------------------------------------------------------------
+_POOL_CTX = {}
+
+
+def _pool_init(ctx):
+    _POOL_CTX.update(ctx)
+
+
+def _pool_task(args):
+    rec, parallax, parallax_err, coord, seed = args
+    c = _POOL_CTX
+    return BruteForce._finish_star(
+        rec, parallax, parallax_err, coord, c["Nmc_prior"], c["lnprior"],
+        c["wt_thresh"], c["cdf_thresh"], c["lngalprior"], c["lndustprior"],
+        c["dustfile"], c["dlabels"], c["avlim"], c["rvlim"], c["mem_lim"],
+        np.random.RandomState(seed), c["apply_av_prior"], c["Ndraws"],
+        c["return_distreds"])
+
+
+class _HostPool(object):
+    """`spawn`ed worker processes (they never touch the GPU) running
+    `_finish_star`; prior hooks must be picklable (module-level functions)."""
+
+    def __init__(self, nproc, ctx):
+        import multiprocessing as mp
+        self.pool = mp.get_context("spawn").Pool(nproc, initializer=_pool_init,
+                                                 initargs=(ctx,))
+
+    def submit(self, rec, parallax, parallax_err, coord, seed):
+        return self.pool.apply_async(_pool_task, ((rec, parallax, parallax_err,
+                                                   coord, seed),))
+
+    def close(self):
+        self.pool.terminate()
+        self.pool.join()
+
+
+# ---------------------------------------------------------------------------
 # BruteForce
 # ---------------------------------------------------------------------------
 class BruteForce(object):
@@ -550,6 +589,9 @@ class BruteForce(object):
         self._engine_obj = None
         #: stars per device batch (None = sized from the memory budget)
         self.batch_size = None
+        #: host processes for the `lnpost` stage when objects have their own
+        #: RNG seed (`_fit(seed0=...)`, `parallel.fit_sharded`); 0/1 = in-process
+        self.host_workers = 0
 
     # -- device state -------------------------------------------------------
     def _engine(self):
@@ -733,7 +775,7 @@ class BruteForce(object):
              apply_dlabels=True, data_coords=None,
              return_distreds=True, logl_dim_prior=True, ltol=3e-2,
              ltol_subthresh=1e-2, logl_initthresh=5e-3, mem_lim=8000.,
-             rstate=None, rstate_per_object=None):
+             rstate=None, rstate_per_object=None, seed0=None):
         """Generator yielding, per object and in input order, the tuple
         `(model_idx, scales, avs, rvs, cov_sar, Ndim, lnprob, levid, chi2min
         [, dists, reds, dreds, logwts])` of reference fitting.py:2059-2065.
@@ -745,6 +787,10 @@ class BruteForce(object):
         `rstate_per_object` (extension, default None): a callable `i ->
         RandomState` giving every object its own stream; results then do not
         depend on object order or on how a catalogue is sharded over GPUs.
+        `seed0` (extension): shorthand for `RandomState(seed0 + i)` per object;
+        because the objects' host stages are then independent they are farmed
+        out to `self.host_workers` processes (the reference's single stream
+        forces that stage to run one object after the other).
         """
         if Nmc_prior <= 0:
             raise ValueError("Nmc_prior must be positive (the reference "
@@ -789,6 +835,38 @@ class BruteForce(object):
                               ltol_subthresh, logl_initthresh, logl_dim_prior,
                               wt_thresh=wt_thresh)
         step = eng.batch if lnprior_ext is None else max(1, min(eng.batch, 8))
+        if seed0 is not None and rstate_per_object is None:
+            rstate_per_object = lambda i: np.random.RandomState(seed0 + i)
+        pool = None
+        if seed0 is not None and self.host_workers and self.host_workers > 1:
+            pool = _HostPool(self.host_workers, dict(
+                Nmc_prior=Nmc_prior, lnprior=lnprior, wt_thresh=wt_thresh,
+                cdf_thresh=cdf_thresh, lngalprior=lngalprior,
+                lndustprior=lndustprior, dustfile=dustfile, dlabels=dlabels,
+                avlim=avlim, rvlim=rvlim, mem_lim=mem_lim,
+                apply_av_prior=apply_av_prior, Ndraws=Ndraws,
+                return_distreds=return_distreds))
+        try:
+            for out in self._fit_loop(eng, params, step, Ndata, data, data_err,
+                                      data_mask, parallax, parallax_err,
+                                      data_coords, lnprior_ext, wt_thresh, pool,
+                                      seed0, rstate, rstate_per_object,
+                                      (Nmc_prior, lnprior, wt_thresh, cdf_thresh,
+                                       lngalprior, lndustprior, dustfile, dlabels,
+                                       avlim, rvlim, mem_lim),
+                                      (apply_av_prior, Ndraws, return_distreds)):
+                yield out
+        finally:
+            if pool is not None:
+                pool.close()
+
+    def _fit_loop(self, eng, params, step, Ndata, data, data_err, data_mask,
+                  parallax, parallax_err, data_coords, lnprior_ext, wt_thresh,
+                  pool, seed0, rstate, rstate_per_object, post_args, tail_args):
+        (Nmc_prior, lnprior, wt_thresh, cdf_thresh, lngalprior, lndustprior,
+         dustfile, dlabels, avlim, rvlim, mem_lim) = post_args
+        apply_av_prior, Ndraws, return_distreds = tail_args
+        pending = []      # in-flight host-pool results, in object order
         for a in range(0, Ndata, step):
             b = min(Ndata, a + step)
             if lnprior_ext is None:
@@ -799,6 +877,15 @@ class BruteForce(object):
                                                 data_mask[a:b], parallax[a:b],
                                                 parallax_err[a:b], params,
                                                 lnprior_ext, a, wt_thresh)
+            if pool is not None:
+                # keep the device busy: hand this batch to the pool, yield what
+                # is finished from earlier batches (always in object order)
+                for i, rec in zip(range(a, b), recs):
+                    pending.append(pool.submit(rec, parallax[i], parallax_err[i],
+                                               data_coords[i], seed0 + i))
+                while len(pending) > 2 * step:
+                    yield pending.pop(0).get()
+                continue
             for i, rec in zip(range(a, b), recs):
                 rs = rstate if rstate_per_object is None else rstate_per_object(i)
                 yield self._finish_star(rec, parallax[i], parallax_err[i],
@@ -807,6 +894,8 @@ class BruteForce(object):
                                         lndustprior, dustfile, dlabels, avlim,
                                         rvlim, mem_lim, rs, apply_av_prior,
                                         Ndraws, return_distreds)
+        while pending:
+            yield pending.pop(0).get()
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
                             lnprior_ext, offset, wt_thresh):

@@ -123,8 +123,7 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         lnprior=lnprior, lngalprior=lngalprior, lndustprior=lndustprior,
         av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[lo:hi],
         Ndraws=Ndraws, return_distreds=save_dar_draws,
-        rstate_per_object=lambda i: np.random.RandomState(seed0 + lo + i),
-        **fkw))
+        seed0=seed0 + lo, **fkw))
     allrows = gather_rows(rows, dst=0)
     if rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,

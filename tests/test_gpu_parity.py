@@ -388,3 +388,24 @@ def test_argument_errors():
         fitting.DeviceGrid(np.zeros((10, 33, 3), np.float32))
     with pytest.raises(ValueError, match="bands"):
         fitting.loglike(f[:5], e[:5], m[:5], models)
+
+
+def test_host_pool_matches_in_process():
+    """`_fit(seed0=...)` with a pool of host worker processes returns exactly
+    what the in-process host stage returns, in object order."""
+    from brutus_amd import fitting, synth
+    models, labels, lmask = synth.make_grid(5000, 8, seed=25)
+    st = synth.make_stars(models, 10, seed=26)
+    BF = fitting.BruteForce(models, labels, lmask)
+    BF.batch_size = 4
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"],
+              Nmc_prior=20, lngalprior=galprior, data_coords=st["coords"],
+              Ndraws=40, seed0=77)
+    a = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    BF.host_workers = 3
+    b = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    assert len(a) == len(b) == 10
+    for x, y in zip(a, b):
+        assert np.array_equal(x[0], y[0])
+        for u, v in zip(x[1:], y[1:]):
+            assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True)

@@ -44,9 +44,9 @@ def _worker(rank, world, port, tmp):
 
     class Stub(fitting.BruteForce):
         def _fit(self, data, data_err, data_mask, parallax=None, Ndraws=250,
-                 rstate_per_object=None, return_distreds=True, **kw):
+                 seed0=None, return_distreds=True, **kw):
             for i in range(data.shape[0]):
-                rs = rstate_per_object(i)
+                rs = np.random.RandomState(seed0 + i)
                 idx = rs.randint(0, 64, size=Ndraws)
                 val = np.full(Ndraws, float(np.sum(data[i])))
                 yield (idx, val, val, val, np.zeros((Ndraws, 3, 3)), 6, val,
