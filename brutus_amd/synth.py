@@ -134,7 +134,8 @@ def make_mist_like_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
                       ('loga', 'f8'), ('agewt', 'f8')])
     labels = np.zeros(nmodel, dtype=ltype)
     labels['mini'], labels['eep'], labels['feh'] = mm, ee, ff
-    labels['loga'] = 10.1 - 2.5 * np.log10(mm) + 0.4 * x
+    # ages stay below 13.5 Gyr so that age priors never exclude the whole grid
+    labels['loga'] = np.clip(9.9 - 2.2 * np.log10(mm) + 0.2 * x, 8.0, 10.13)
     labels['agewt'] = 0.05 + np.abs(np.gradient(labels['loga']))
     mtype = np.dtype([(n, '?') for n in ltype.names])
     labels_mask = np.zeros(1, dtype=mtype)
