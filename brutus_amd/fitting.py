@@ -701,10 +701,14 @@ class BruteForce(object):
             apply_dlabels=True, data_coords=None, logl_dim_prior=True,
             ltol=3e-2, ltol_subthresh=1e-2, logl_initthresh=5e-3,
             mag_max=50., merr_max=0.25, rstate=None, save_dar_draws=True,
-            running_io=True, mem_lim=8000., verbose=True):
+            running_io=True, mem_lim=8000., verbose=True, resume=False):
         """Fit every object and write `{save_file}.h5` in the reference's
         layout (fitting.py:1632-1662, 1734-1748).  Keyword arguments, units and
-        defaults are the reference's.  Returns None."""
+        defaults are the reference's.  Returns None.
+
+        `resume=True` (extension): if `{save_file}.h5` exists, only the objects
+        whose `model_idx` row still holds the reference's -99 sentinel are
+        fitted and filled in; without it an existing file raises (`"w-"`)."""
         from . import h5io
         (data, data_err, data_mask, data_labels, data_coords,
          lnprior, lngalprior, lndustprior, av_gauss, wt_thresh,
@@ -722,9 +726,26 @@ class BruteForce(object):
                                rstate=rstate)
         Ndata, Nfilt = data.shape
 
-        out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
-                               data_labels, save_dar_draws,
-                               running_io=running_io)
+        import os
+        todo = None
+        if resume and os.path.exists("{0}.h5".format(save_file)):
+            out = h5io.ResultsFile.resume("{0}.h5".format(save_file), Ndata,
+                                          Ndraws, save_dar_draws)
+            todo = out.todo
+            if len(todo) == 0:
+                out.close()
+                return
+            data, data_err, data_mask = data[todo], data_err[todo], data_mask[todo]
+            data_coords = data_coords[todo]
+            if parallax is not None:
+                parallax = np.asarray(parallax)[todo]
+                parallax_err = np.asarray(parallax_err)[todo]
+            if lnprior_ext is not None:
+                lnprior_ext = {k: np.asarray(v)[todo] for k, v in lnprior_ext.items()}
+        else:
+            out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
+                                   data_labels, save_dar_draws,
+                                   running_io=running_io)
         try:
             t0 = time.time()
             if verbose:
@@ -745,8 +766,9 @@ class BruteForce(object):
                             logl_dim_prior=logl_dim_prior,
                             logl_initthresh=logl_initthresh, ltol=ltol,
                             mem_lim=mem_lim)
+            Ndata = data.shape[0]
             for i, results in enumerate(gen):
-                out.write_row(i, results)
+                out.write_row(i if todo is None else int(todo[i]), results)
                 if verbose:
                     t_avg = (time.time() - t0) / (i + 1)
                     t_est = t_avg * (Ndata - i - 1)

@@ -247,6 +247,28 @@ class _File(object):
         L.H5Sclose(sid)
         self._dsets[name] = (did, tid, close, tuple(shape), data.dtype)
 
+    def open_dataset(self, name):
+        """Bind an existing dataset for `write_rows`; returns its contents."""
+        L = self.L
+        did = _check(L.H5Dopen2(self.fid, name.encode(), H5P_DEFAULT),
+                     "H5Dopen2 " + name)
+        ftid = L.H5Dget_type(did)
+        dt = _nptype(ftid)
+        L.H5Tclose(ftid)
+        sid = L.H5Dget_space(did)
+        nd = L.H5Sget_simple_extent_ndims(sid)
+        dims = (hsize_t * max(nd, 1))()
+        L.H5Sget_simple_extent_dims(sid, dims, None)
+        L.H5Sclose(sid)
+        shape = tuple(int(d) for d in dims[:nd])
+        tid, close = _h5type(dt)
+        out = np.empty(shape, dtype=dt)
+        if out.size:
+            _check(L.H5Dread(did, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT,
+                             out.ctypes.data_as(C.c_void_p)), "H5Dread " + name)
+        self._dsets[name] = (did, tid, close, shape, dt)
+        return out
+
     def write_rows(self, name, start, rows):
         """Overwrite rows [start, start+len(rows)) along axis 0."""
         L = self.L
@@ -382,6 +404,35 @@ class ResultsFile(object):
         self._lo = 0   # first row not yet on disk
         self._hi = 0   # one past the last row staged
 
+    @classmethod
+    def resume(cls, path, Ndata, Ndraws, save_dar_draws, flush_every=256):
+        """Re-open an interrupted `running_io=True` results file.  Rows whose
+        `model_idx` still holds the sentinel -99 (reference fitting.py:1635)
+        were never fitted; `todo` lists them."""
+        self = cls.__new__(cls)
+        self.file = _File(path, "r+")
+        self.Ndata, self.Ndraws = Ndata, Ndraws
+        self.running_io, self.flush_every = True, max(1, int(flush_every))
+        self.save_dar_draws = save_dar_draws
+        names = ["model_idx", "ml_scale", "ml_av", "ml_rv", "ml_cov_sar",
+                 "obj_log_post", "obj_log_evid", "obj_chi2min", "obj_Nbands"]
+        if save_dar_draws:
+            names += ["samps_dist", "samps_red", "samps_dred", "samps_logp"]
+        self.arrays = {}
+        try:
+            for k in names:
+                self.arrays[k] = self.file.open_dataset(k)
+            if self.arrays["model_idx"].shape != (Ndata, Ndraws):
+                raise ValueError("existing results file has shape %r, expected %r"
+                                 % (self.arrays["model_idx"].shape, (Ndata, Ndraws)))
+        except Exception:
+            self.file.close()
+            raise
+        self.todo = np.where(self.arrays["model_idx"][:, 0] == -99)[0]
+        self._lo = self._hi = 0
+        self._dirty = set()
+        return self
+
     def write_row(self, i, results):
         a = self.arrays
         a["model_idx"][i] = results[0]
@@ -398,11 +449,24 @@ class ResultsFile(object):
             a["samps_red"][i] = results[10]
             a["samps_dred"][i] = results[11]
             a["samps_logp"][i] = results[12]
+        if getattr(self, "_dirty", None) is not None:
+            # resumed file: rows arrive in arbitrary positions
+            self._dirty.add(i)
+            if len(self._dirty) >= self.flush_every:
+                self._flush_rows()
+            return
         self._hi = max(self._hi, i + 1)
         if self.running_io and self._hi - self._lo >= self.flush_every:
             self._flush_rows()
 
     def _flush_rows(self):
+        if getattr(self, "_dirty", None) is not None:
+            for i in sorted(self._dirty):
+                for k, v in self.arrays.items():
+                    self.file.write_rows(k, i, v[i:i + 1])
+            self._dirty.clear()
+            self.file.flush()
+            return
         if self._hi > self._lo:
             for k, v in self.arrays.items():
                 self.file.write_rows(k, self._lo, v[self._lo:self._hi])

@@ -238,3 +238,74 @@ def phot_loglike(data, data_err, data_mask, models, dim_prior=True):
         a = 0.5 * (ndim - 3)
         return xlogy(a - 1., chi2) - chi2 / 2. - gammaln(a) - np.log(2.) * a
     return -0.5 * chi2 - 0.5 * (ndim * np.log(2. * np.pi) + np.sum(np.log(var)))
+
+
+def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
+                        sel=None, weights=None, mask_fit=None, Nmc=150,
+                        old_offsets=None, dim_prior=True, prior_mean=None,
+                        prior_std=None, verbose=True, rstate=None):
+    """Multiplicative photometric offsets (model / data) per band from the
+    resampled fits of many objects, with bootstrap errors; same arguments,
+    RNG call order and returns `(ratios, ratios_err, nratio)` as reference
+    `utils.photometric_offsets` (utils.py:1218-1400).
+
+    For a band that took part in the fit the model draws of every object are
+    re-weighted by the likelihood of the *other* bands (leave-one-band-out),
+    so that the band does not calibrate itself."""
+    import sys
+    from scipy.special import logsumexp
+    phot, err = np.asarray(phot, float), np.asarray(err, float)
+    mask = np.asarray(mask, dtype=bool)
+    Nobj, Nfilt = phot.shape
+    Nsamps = idxs.shape[1]
+    sel = np.ones(Nobj, dtype=bool) if sel is None else np.asarray(sel, bool)
+    weights = np.ones((Nobj, Nsamps)) if weights is None else np.asarray(weights, float)
+    mask_fit = np.ones(Nfilt, dtype=bool) if mask_fit is None else np.asarray(mask_fit, bool)
+    old_offsets = np.ones(Nfilt) if old_offsets is None else np.asarray(old_offsets, float)
+    if rstate is None:
+        rstate = getattr(np, "random_intel", np.random)
+
+    seds = get_seds(models[idxs.ravel()], av=reds.ravel(), rv=dreds.ravel(),
+                    return_flux=True)
+    seds = (seds / dists.ravel()[:, None] ** 2).reshape(Nobj, Nsamps, Nfilt)
+
+    ratios, ratios_err = np.ones(Nfilt), np.zeros(Nfilt)
+    nratio = np.zeros(Nfilt, dtype=int)
+    nbands = mask.sum(axis=1)
+    usable = sel & (weights.sum(axis=1) > 0)
+    for b in range(Nfilt):
+        need = 3 + (1 if mask_fit[b] else 0)      # bands besides this one
+        s = np.where(mask[:, b] & usable & (nbands > need))[0]
+        n = nratio[b] = len(s)
+        if n == 0:
+            continue
+        ratio = seds[s, :, b] / phot[s, None, b]
+        if mask_fit[b]:
+            others = mask[s].copy()
+            others[:, b] = False
+            lnl = np.array([phot_loglike(p * old_offsets, e * old_offsets, m, sd,
+                                         dim_prior=dim_prior)
+                            for p, e, m, sd in zip(phot[s], err[s], others, seds[s])])
+            wt = np.exp(lnl - logsumexp(lnl, axis=1)[:, None])
+        else:
+            wt = np.ones((n, Nsamps))
+        wt = wt * weights[s]
+        wt /= wt.sum(axis=1)[:, None]
+        wt_obj = np.array(weights[s].sum(axis=1) > 0, dtype=float)
+        wt_obj /= wt_obj.sum()
+        meds = np.empty(Nmc)
+        for j in range(Nmc):
+            if verbose:
+                sys.stderr.write('\rBand {0} ({1}/{2})     '.format(b + 1, j + 1, Nmc))
+                sys.stderr.flush()
+            ridx = rstate.choice(n, size=n, p=wt_obj)
+            midx = [rstate.choice(Nsamps, p=w) for w in wt[ridx]]
+            meds[j] = np.median(ratio[ridx, midx])
+        ratios[b], ratios_err[b] = np.median(meds), np.std(meds)
+    if verbose:
+        sys.stderr.write('\n')
+    if prior_mean is not None and prior_std is not None:
+        var = ratios_err ** 2 + prior_std ** 2
+        ratios = (ratios * prior_std ** 2 + prior_mean * ratios_err ** 2) / var
+        ratios_err = ratios_err * prior_std / np.sqrt(var)
+    return ratios, ratios_err, nratio

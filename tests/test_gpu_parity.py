@@ -409,3 +409,32 @@ def test_host_pool_matches_in_process():
         assert np.array_equal(x[0], y[0])
         for u, v in zip(x[1:], y[1:]):
             assert np.array_equal(np.asarray(u), np.asarray(v), equal_nan=True)
+
+
+def test_fit_resume(tmp_path):
+    """fit(resume=True) fills only the rows that still hold the -99 sentinel."""
+    from brutus_amd import fitting, h5io, synth
+    models, labels, lmask = synth.make_grid(3000, 6, seed=5)
+    st = synth.make_stars(models, 6, seed=6)
+    BF = fitting.BruteForce(models, labels, lmask)
+    path = os.path.join(str(tmp_path), "res")
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"],
+              data_coords=st["coords"], lngalprior=galprior, Nmc_prior=10,
+              Ndraws=20, verbose=False)
+    BF.fit(st["flux"], st["err"], st["mask"], np.arange(6), path,
+           rstate=np.random.RandomState(1), **kw)
+    full = h5io.read_dataset(path + ".h5", "model_idx")
+    # knock two rows back to "never fitted"
+    f = h5io._File(path + ".h5", "r+")
+    arr = f.open_dataset("model_idx")
+    arr[[2, 4]] = -99
+    f.write_rows("model_idx", 2, arr[2:3])
+    f.write_rows("model_idx", 4, arr[4:5])
+    f.close()
+    BF.fit(st["flux"], st["err"], st["mask"], np.arange(6), path,
+           rstate=np.random.RandomState(2), resume=True, **kw)
+    again = h5io.read_dataset(path + ".h5", "model_idx")
+    assert np.array_equal(again[[0, 1, 3, 5]], full[[0, 1, 3, 5]])
+    assert again[[2, 4]].min() >= 0
+    # the resampled models of the refilled rows come from the same posterior
+    assert set(again[2]) & set(full[2])

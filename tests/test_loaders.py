@@ -117,3 +117,40 @@ def test_output_consumers_match_reference():
         got = utils.phot_loglike(z["pl_d"], z["pl_e"], z["pl_m"], z["pl_models"],
                                  dim_prior=dp)
         assert np.max(np.abs(got - z[key])) < 1e-12
+
+
+def test_photometric_offsets_match_reference():
+    """`photometric_offsets` (reference utils.py:1218-1400) incl. its RNG call
+    order, against a vector generated from the upstream code."""
+    import os as _os
+    z = np.load(_os.path.join(_os.path.dirname(__file__), "golden", "consumers.npz"))
+    r, re_, n = utils.photometric_offsets(
+        z["po_phot"], z["po_err"], z["po_mask"], z["po_models"], z["po_idxs"],
+        z["po_reds"], z["po_dreds"], z["po_dists"], sel=z["po_sel"],
+        weights=z["po_weights"], mask_fit=z["po_mask_fit"], Nmc=20,
+        old_offsets=z["po_old"], prior_mean=np.ones(6), prior_std=np.full(6, 0.05),
+        verbose=False, rstate=np.random.RandomState(5))
+    assert np.array_equal(n, z["po_nratio"])
+    assert np.max(np.abs(r - z["po_ratios"])) < 1e-12
+    assert np.max(np.abs(re_ - z["po_ratios_err"])) < 1e-12
+
+
+def test_results_file_resume(tmp_path):
+    path = os.path.join(str(tmp_path), "r.h5")
+    row = lambda k: (np.full(3, k), np.ones(3), np.ones(3), np.ones(3),
+                     np.ones((3, 3, 3)), 7, np.ones(3), -2.5, 3.5, np.ones(3),
+                     np.ones(3), np.ones(3), np.full(3, float(k)))
+    rf = h5io.ResultsFile(path, 5, 3, np.arange(5), True, flush_every=1)
+    rf.write_row(0, row(10))
+    rf.write_row(1, row(11))
+    rf.close()                      # "interrupted" after two objects
+    rf = h5io.ResultsFile.resume(path, 5, 3, True)
+    assert list(rf.todo) == [2, 3, 4]
+    for k in rf.todo:
+        rf.write_row(int(k), row(20 + k))
+    rf.close()
+    idx = h5io.read_dataset(path, "model_idx")
+    assert [int(r[0]) for r in idx] == [10, 11, 22, 23, 24]
+    assert list(h5io.read_dataset(path, "samps_logp")[:, 0]) == [10., 11., 22., 23., 24.]
+    with pytest.raises(ValueError):
+        h5io.ResultsFile.resume(path, 6, 3, True)
