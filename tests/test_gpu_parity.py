@@ -438,3 +438,26 @@ def test_fit_resume(tmp_path):
     assert again[[2, 4]].min() >= 0
     # the resampled models of the refilled rows come from the same posterior
     assert set(again[2]) & set(full[2])
+
+
+def test_fit_orion_catalogue_vs_reference_golden():
+    """Real-data inputs (20 rows of the reference's Orion demo catalogue: 4-8
+    valid bands, missing parallaxes, poor fits with chi2 up to ~1e4) through
+    `BruteForce._fit`: indices bit-exact, floats <=1e-5 vs the reference."""
+    from brutus_amd import fitting, synth
+    z = np.load(os.path.join(GOLDEN, "fit_orion20.npz"))
+    models, labels, lmask = synth.make_mist_like_grid(int(z["grid_nmodel"]),
+                                                      int(z["grid_nfilt"]),
+                                                      seed=int(z["grid_seed"]))
+    BF = fitting.BruteForce(models, labels, lmask)
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    outs = list(BF._fit(z["flux"], z["err"], z["mask"], parallax=z["parallax"],
+                        parallax_err=z["parallax_err"], Nmc_prior=30,
+                        lnprior=z["lnprior"], lngalprior=galprior,
+                        data_coords=z["coords"], Ndraws=100,
+                        seed0=int(z["seed0"])))
+    for i, out in enumerate(outs):
+        assert np.array_equal(out[0], z["sidxs"][i]), "object %d indices" % i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))

@@ -87,3 +87,23 @@ def test_c_oracle_matches_reference(path):
     for name, got in (("lnl", out[0]), ("chi2", out[2]), ("scale", out[3]),
                       ("av", out[4]), ("rv", out[5]), ("icov", out[6])):
         assert relerr(z[name], got) < 1e-11, name
+
+
+def test_fit_orion_catalogue_matches_reference():
+    """20 objects of the reference's real-data demo catalogue (missing bands,
+    NaN parallaxes, poor fits) through the oracle's `_fit` restatement."""
+    z = np.load(os.path.join(GOLDEN, "fit_orion20.npz"))
+    models, labels, lmask = synth.make_mist_like_grid(int(z["grid_nmodel"]),
+                                                      int(z["grid_nfilt"]),
+                                                      seed=int(z["grid_seed"]))
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(z["flux"])):
+        out = O.fit_star(z["flux"][i], z["err"][i], z["mask"][i], models,
+                         z["lnprior"], labels, z["coords"][i], z["parallax"][i],
+                         z["parallax_err"][i],
+                         np.random.RandomState(int(z["seed0"]) + i), galprior,
+                         Nmc_prior=30, Ndraws=100)
+        assert np.array_equal(out[0], z["sidxs"][i]), i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-8, (i, n)

@@ -292,12 +292,66 @@ def gen_cluster():
     np.savez_compressed(os.path.join(OUT, "cluster.npz"), **res)
 
 
+def gen_orion():
+    """`_fit` yields for 20 objects of the reference's real-data demo
+    catalogue (demos/Orion_l204.7_b-19.2.h5: PS grizy + 2MASS JHKs magnitudes,
+    missing bands flagged mag = -999 / err = inf, Gaia parallaxes in arcsec),
+    converted like the notebook does (Overview 3, cell "convert to flux"),
+    against a 10k-model synthetic grid.  The 20 catalogue rows are stored in
+    the fixture (input data), the reference outputs beside them."""
+    from brutus_amd import h5io
+    cat = h5io.read_dataset(os.path.join(ref_shim.REFERENCE_ROOT, "demos",
+                                         "Orion_l204.7_b-19.2.h5"),
+                            "/photometry/pixel 0-0")
+    nb = np.sum(np.isfinite(cat["err"]) & (cat["mag"] > -900), axis=1)
+    pick = np.concatenate([np.where(nb == 8)[0][:8], np.where(nb == 7)[0][:4],
+                           np.where((nb >= 4) & (nb <= 6))[0][:8]])[:20]
+    cat = cat[pick]
+    mag, magerr = cat["mag"].astype(np.float64), cat["err"].astype(np.float64)
+    mask = np.isfinite(magerr) & (mag > -900)
+    with np.errstate(all="ignore"):
+        flux = np.where(mask, 10. ** (-0.4 * mag), np.nan)
+        err = np.where(mask, flux * magerr * 0.4 * np.log(10.), np.nan)
+    par = cat["parallax"].astype(np.float64) * 1e3
+    perr = cat["parallax_error"].astype(np.float64) * 1e3
+    bad = ~(np.isfinite(par) & np.isfinite(perr) & (perr > 0) & (perr < 1e3)) | (par == 0)
+    par[bad], perr[bad] = np.nan, np.nan
+    coords = np.c_[cat["l"], cat["b"]]
+    models, labels, lmask = synth.make_mist_like_grid(10000, 8, seed=77)
+    # put the grid at the catalogue's brightness: shift to apparent mags ~ 14-20 at 0.4 kpc
+    BF = F.BruteForce(models.astype(np.float64), labels, lmask)
+    sp = BF._setup(flux.copy(), err.copy(), mask.copy(), None, data_coords=coords,
+                   lngalprior=galprior, parallax=par, parallax_err=perr,
+                   merr_max=1.0)
+    lnprior, mask2 = sp[5], np.array(sp[2])
+    res = {}
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(flux)):
+        sl = slice(i, i + 1)
+        r = next(BF._fit(flux[sl].copy(), err[sl].copy(), mask2[sl].copy(),
+                         parallax=par[sl], parallax_err=perr[sl], Nmc_prior=30,
+                         lnprior=lnprior.copy(), lngalprior=galprior,
+                         data_coords=coords[sl],
+                         rstate=np.random.RandomState(2000 + i), Ndraws=100))
+        for n, v in zip(names, r):
+            res.setdefault(n, []).append(np.asarray(v))
+        print("orion star", i, "bands", int(mask2[i].sum()), "par", par[i], "levid", r[7])
+    np.savez_compressed(os.path.join(OUT, "fit_orion20.npz"), grid_nmodel=10000,
+                        grid_nfilt=8, grid_seed=77, flux=flux, err=err, mask=mask2,
+                        parallax=par, parallax_err=perr, coords=coords,
+                        lnprior=lnprior, seed0=2000,
+                        **{k: np.array(v) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
                              "cluster"]
     if "cluster" in which:
         gen_cluster()
+    if "orion" in which:
+        gen_orion()
     if "galprior" in which:
         gen_galprior_pieces()
     if "helpers" in which:
