@@ -8,9 +8,10 @@
 //   fitting.py:502-576   _get_sed_mle                      (mle_eval)
 //   fitting.py:385-420   _optimize_fit_flux step           (k_flux)
 //   utils.py:330-345     _get_seds                         (inlined in both)
-//   utils.py:161-176     _chisquare_logpdf                 (k_finalize)
-//   fitting.py:976-991   lnpost parallax clip + first cut  (k_finalize, k_count,
-//                                                           k_scatter)
+//   utils.py:161-176     _chisquare_logpdf                 (k_finalize, final_lnl)
+//   fitting.py:976-991   lnpost parallax clip + first cut  (first_cut_lnprob,
+//                                                           k_cmp_*, k_emit)
+//   cluster.py:336-414   isochrone_loglike hot block       (k_cluster)
 //
 // Execution model.  One lane owns one model; a 256-lane workgroup owns a tile
 // of 256 consecutive models and keeps that tile's 3*NB float32 coefficients in
@@ -102,24 +103,13 @@ struct DevParams {
 };
 
 struct Planes {            // each (nstar, nmodel) float64, row stride = nmodel
-    double *lnlp;          // cull statistic (generic path: later lnprob of the first cut)
+    double *lnlp;          // cull statistic lnl_p
     double *lnprob;        // fast path: first-cut statistic
     double *lnl, *chi2, *scale, *av, *rv;
     double *icov[6];
     double *step;
     int64_t nmodel;
 };
-
-__device__ __forceinline__ unsigned long long dkey(double x) {
-    long long b = __double_as_longlong(x);
-    return b < 0 ? ~(unsigned long long)b
-                 : ((unsigned long long)b | 0x8000000000000000ull);
-}
-__device__ __forceinline__ double dunkey(unsigned long long k) {
-    long long b = (k & 0x8000000000000000ull) ? (long long)(k & 0x7fffffffffffffffull)
-                                              : (long long)~k;
-    return __longlong_as_double(b);
-}
 
 __device__ __forceinline__ double wave_max(double v) {
 #pragma unroll
@@ -706,116 +696,22 @@ k_flux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
     }
 }
 
-// Phase 4: constants, dimensionality prior, parallax clip (elementwise).
-// fitting.py:806-815 and :976-985.  Overwrites lnlp with lnprob when
-// `want_lnprob`; emits per (tile, star) max lnprob.
+// Phase 4: constants and dimensionality prior (elementwise), fitting.py:806-815.
 __global__ void __launch_bounds__(TILE)
 k_finalize(int64_t nmodel, int nstar, const StarPrep *__restrict__ stars, DevParams p,
-           const double *__restrict__ lnlp_max, int want_lnprob, Planes pl,
-           double *__restrict__ part) {
-    __shared__ double slot[4];
+           const double *__restrict__ lnlp_max, Planes pl) {
     const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
-    const bool live = i < nmodel;
+    if (i >= nmodel) return;
     const int s = blockIdx.y;
     const StarPrep &sp = stars[s];
     const int64_t o = (int64_t)s * pl.nmodel + i;
-    double lnprob = -INFINITY;
-    if (live) {
-        const bool surv = pl.lnlp[o] > lnlp_max[s] + p.ln_init;
-        const double chi2 = pl.chi2[o];
-        double lnl = pl.lnl[o];
-        if (surv) lnl += sp.lnl_const;                              // fitting.py:806-807
-        if (p.dim_prior)                                            // utils.py:161-176
-            lnl = chi2 > 0. ? sp.c0 + sp.c1 * log(chi2) - chi2 / 2. : -INFINITY;
-        pl.lnl[o] = lnl;
-        if (want_lnprob) {
-            lnprob = lnl;
-            if (sp.sp_on) {                                         // pdf.py:209-218
-                const double serr2 = 1. / fabs(pl.icov[0][o]);
-                const double vt = sp.sp_var + serr2;
-                const double ds = pl.scale[o] - sp.sp_mean;
-                lnprob = lnl + -0.5 * (ds * ds / vt + log(2. * M_PI * vt));
-            }
-            if (!isfinite(lnprob)) lnprob = -BIG;                   // fitting.py:983-985
-            pl.lnlp[o] = lnprob;
-        }
-    }
-    if (want_lnprob)
-        block_max_store(lnprob, slot, part + ((int64_t)blockIdx.x * nstar + s));
-}
-
-// Ordered compaction of {lnprob > max + ln(wt_thresh)} (fitting.py:988-991).
-// grid = (NCHUNK, nstar); workgroup (c, s) owns a contiguous range of tiles.
-__global__ void __launch_bounds__(TILE)
-k_count(int64_t nmodel, int ntile, const double *__restrict__ lnprob,
-        const double *__restrict__ pmax, double ln_wt, int64_t *__restrict__ counts) {
-    __shared__ int wsum[4];
-    const int s = blockIdx.y, c = blockIdx.x;
-    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
-    const double thr = pmax[s] + ln_wt;
-    int n = 0;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        if (i < nmodel && lnprob[(int64_t)s * nmodel + i] > thr) ++n;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-}
-
-__global__ void k_scan(int nstar, const int64_t *__restrict__ counts,
-                       int64_t *__restrict__ offsets, int64_t *__restrict__ star_off) {
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    int64_t run = 0;
-    for (int s = 0; s < nstar; ++s) {
-        star_off[s] = run;
-        for (int c = 0; c < NCHUNK; ++c) {
-            offsets[(int64_t)s * NCHUNK + c] = run;
-            run += counts[(int64_t)s * NCHUNK + c];
-        }
-    }
-    star_off[nstar] = run;
-}
-
-__global__ void __launch_bounds__(TILE)
-k_scatter(int64_t nmodel, int ntile, Planes pl, const double *__restrict__ pmax, double ln_wt,
-          const int64_t *__restrict__ offsets, int64_t capacity, int32_t *__restrict__ sel_idx,
-          double *__restrict__ sel_vals) {
-    __shared__ int wsum[4];
-    const int s = blockIdx.y, c = blockIdx.x;
-    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
-    const double thr = pmax[s] + ln_wt;
-    int64_t base = offsets[(int64_t)s * NCHUNK + c];
-    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        const int64_t o = (int64_t)s * nmodel + i;
-        const bool sel = i < nmodel && pl.lnlp[o] > thr;
-        const unsigned long long b = __ballot(sel);
-        const int rank = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[w] = __popcll(b);
-        __syncthreads();
-        int woff = 0;
-        for (int q = 0; q < w; ++q) woff += wsum[q];
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (sel) {
-            const int64_t r = base + woff + rank;
-            if (r < capacity) {
-                sel_idx[r] = (int32_t)i;
-                sel_vals[0 * capacity + r] = pl.lnl[o];
-                sel_vals[1 * capacity + r] = pl.chi2[o];
-                sel_vals[2 * capacity + r] = pl.scale[o];
-                sel_vals[3 * capacity + r] = pl.av[o];
-                sel_vals[4 * capacity + r] = pl.rv[o];
-#pragma unroll
-                for (int q = 0; q < 6; ++q) sel_vals[(5 + q) * capacity + r] = pl.icov[q][o];
-            }
-        }
-        base += tot;
-        __syncthreads();
-    }
+    const bool surv = pl.lnlp[o] > lnlp_max[s] + p.ln_init;
+    const double chi2 = pl.chi2[o];
+    double lnl = pl.lnl[o];
+    if (surv) lnl += sp.lnl_const;                                  // fitting.py:806-807
+    if (p.dim_prior)                                                // utils.py:161-176
+        lnl = chi2 > 0. ? sp.c0 + sp.c1 * log(chi2) - chi2 / 2. : -INFINITY;
+    pl.lnl[o] = lnl;
 }
 
 // PMC calibration stream with the fused scan's access widths: 4-byte loads and
@@ -1570,7 +1466,6 @@ struct Workspace {
     StarPrep *stars;
     double *part;       // per-(tile, star) partial maxima
     double *vmax_lnlp;  // (S,)
-    double *vmax_prob;  // (S,)
     int32_t *k1;        // (S,)
     int32_t *k2;        // (S,)  >=0 active iteration count, <0 done: -(K2)-1
     int32_t *n_unconv;  // (1,)
@@ -1616,7 +1511,6 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
     w.stars = (StarPrep *)take(sizeof(StarPrep) * nstar);
     w.part = (double *)take(sizeof(double) * (size_t)ntile * nstar * 2 * KCAP);
     w.vmax_lnlp = (double *)take(sizeof(double) * nstar);
-    w.vmax_prob = (double *)take(sizeof(double) * nstar);
     w.k1 = (int32_t *)take(sizeof(int32_t) * nstar);
     w.k2 = (int32_t *)take(sizeof(int32_t) * nstar);
     w.n_unconv = (int32_t *)take(sizeof(int32_t) * 4);
@@ -1709,7 +1603,7 @@ struct Timer {
 
 template <int NB>
 int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &p,
-                 int max_iter, Workspace &w, bool want_lnprob, int32_t *h_k1, int32_t *h_k2,
+                 int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
                  hipStream_t st, Timer &tm) {
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
@@ -1767,11 +1661,8 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
     // ---- phase 4: constants, dimensionality prior, parallax clip ------------
     tm.begin("k_finalize");
     hipLaunchKernelGGL(k_finalize, dim3(ntile, nstar), blk, 0, st, nmodel, nstar, w.stars, p,
-                       w.vmax_lnlp, want_lnprob ? 1 : 0, w.pl, w.part);
+                       w.vmax_lnlp, w.pl);
     tm.end();
-    if (want_lnprob)
-        hipLaunchKernelGGL(k_reduce_decide, dim3(nstar), dim3(256), 0, st, 1, ntile, nstar, 1,
-                           w.part, 0.0, w.vmax_prob, (int32_t *)nullptr, (int32_t *)nullptr);
     if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
@@ -1779,14 +1670,14 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
 }
 
 int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
-                      int max_iter, Workspace &w, bool want_lnprob, int32_t *h_k1, int32_t *h_k2,
+                      int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
                       hipStream_t st, Timer &tm) {
     switch (nb) {
-        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, want_lnprob, h_k1, h_k2, st, tm);
-        case 12: return run_pipeline<12>(grid, nmodel, nstar, p, max_iter, w, want_lnprob, h_k1, h_k2, st, tm);
-        case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, want_lnprob, h_k1, h_k2, st, tm);
-        case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, want_lnprob, h_k1, h_k2, st, tm);
-        case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, want_lnprob, h_k1, h_k2, st, tm);
+        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 12: return run_pipeline<12>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
     }
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
@@ -2047,8 +1938,8 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int
                              has_parallax, w, d_ndim, st))
         return rc;
     const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
-    int rc = dispatch_pipeline(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, max_iter, w, false,
-                               h_k1, h_k2, st, tm);
+    int rc = dispatch_pipeline(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, max_iter, w, h_k1,
+                               h_k2, st, tm);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);

@@ -475,3 +475,41 @@ def test_fit_orion_catalogue_vs_reference_golden():
                 continue
             assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
     assert n_illcond <= 4        # of 20
+
+
+def test_cabi_error_codes():
+    """The C ABI reports bad arguments / small buffers instead of crashing."""
+    import ctypes as C
+    import torch
+    from brutus_amd import _lib, fitting, synth
+    L = _lib.lib()
+    models, _, _ = synth.make_grid(600, 6, seed=1)
+    st = synth.make_stars(models, 2, seed=1)
+    grid = fitting.DeviceGrid(models)
+    eng = fitting._Engine(grid, max_batch=2)
+    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18),
+                                  3e-2, 1e-2, 5e-3, True)
+    f, e, m, p, pe, hp = eng._upload(st["flux"], st["err"], st["mask"],
+                                     st["parallax"], st["parallax_err"])
+    ws = eng._workspace(2)
+    idx = torch.empty(16, dtype=torch.int32, device="cuda")
+    vals = torch.empty((11, 16), dtype=torch.float64, device="cuda")
+    off = torch.empty(3, dtype=torch.int64, device="cuda")
+    ndim = torch.empty(2, dtype=torch.int32, device="cuda")
+    args = lambda wsn, ns: (grid.soa.data_ptr(), grid.nmodel, grid.nfilt, ns,
+                            f.data_ptr(), e.data_ptr(), m.data_ptr(), p.data_ptr(),
+                            pe.data_ptr(), hp, params, ws.data_ptr(), wsn, 16,
+                            idx.data_ptr(), vals.data_ptr(), off.data_ptr(),
+                            ndim.data_ptr(), None, None, None)
+    assert L.brutus_fit_batch(*args(1024, 2)) == -2          # BRUTUS_ENOMEM
+    assert b"workspace" in L.brutus_last_error()
+    assert L.brutus_fit_batch(*args(ws.numel(), 0)) == -1    # BRUTUS_EINVAL
+    assert L.brutus_fit_batch(*args(ws.numel(), 1000)) == -1
+    # capacity smaller than the selection: records are dropped, totals stay true
+    assert L.brutus_fit_batch(*args(ws.numel(), 2)) == 0
+    total = int(off.cpu()[-1])
+    assert total > 16
+    recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
+                         st["parallax_err"], params)
+    assert sum(len(r["sel"]) for r in recs) == total
+    assert np.array_equal(idx.cpu().numpy(), recs[0]["sel"][:16].astype(np.int32))
