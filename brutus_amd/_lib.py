@@ -7,7 +7,7 @@ no GPU is visible, every compute entry point raises.
 import ctypes as C
 import os
 
-__all__ = ["lib", "Params", "check", "LIB_PATH", "BrutusError", "NVALS",
+__all__ = ["lib", "Params", "PostParams", "check", "LIB_PATH", "BrutusError", "NVALS",
            "MAX_BATCH", "MAX_FILT"]
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
@@ -33,6 +33,30 @@ class Params(C.Structure):
 
 
 _vp, _i64, _i32, _sz, _dbl = C.c_void_p, C.c_int64, C.c_int, C.c_size_t, C.c_double
+_u64 = C.c_uint64
+
+
+class PostParams(C.Structure):
+    """struct brutus_post_params (include/brutus_amd.h)."""
+    _fields_ = [("nmc", C.c_int32), ("ndraws", C.c_int32),
+                ("return_distreds", C.c_int32), ("has_feh", C.c_int32),
+                ("has_loga", C.c_int32), ("per_object", C.c_int32),
+                ("wt_thresh", C.c_double), ("avlim", C.c_double * 2),
+                ("rvlim", C.c_double * 2), ("nsel_max", C.c_int64),
+                ("object0", C.c_int64), ("seed", C.c_uint64),
+                ("normal_base", C.c_uint64), ("uniform_base", C.c_uint64),
+                ("R_solar", C.c_double), ("Z_solar", C.c_double),
+                ("R_thin", C.c_double), ("Z_thin", C.c_double),
+                ("Rs_thin", C.c_double), ("R_thick", C.c_double),
+                ("Z_thick", C.c_double), ("f_thick", C.c_double),
+                ("Rs_thick", C.c_double), ("Rs_halo", C.c_double),
+                ("q_halo_ctr", C.c_double), ("q_halo_inf", C.c_double),
+                ("r_q_halo", C.c_double), ("eta_halo", C.c_double),
+                ("f_halo", C.c_double), ("feh_mean", C.c_double * 3),
+                ("feh_sigma", C.c_double * 3), ("age_mean", C.c_double * 3),
+                ("age_sigma", C.c_double * 3), ("age_lnnorm", C.c_double * 3),
+                ("min_age", C.c_double), ("max_age", C.c_double)]
+
 
 # name -> (restype, argtypes); mirrors include/brutus_amd.h one to one
 SIGNATURES = {
@@ -56,6 +80,13 @@ SIGNATURES = {
     "brutus_enable_timing": (None, [C.c_int]),
     "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "brutus_post_workspace_bytes": (_sz, [_i32, _i64]),
+    "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                    _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
+                                    _vp, _vp, _vp]),
+    "brutus_debug_rng": (C.c_int, [_u64, _u64, _i64, _vp, _vp, _vp]),
+    "brutus_debug_galprior": (C.c_int, [C.POINTER(PostParams), _i32, _vp, _vp, _vp, _vp,
+                                        _vp, _vp]),
     "brutus_cluster_workspace_bytes": (_sz, [_i32]),
     "brutus_cluster_lnl": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _i32, _vp, _sz, _vp, _vp]),

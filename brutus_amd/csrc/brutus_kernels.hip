@@ -1448,6 +1448,640 @@ __global__ void k_cluster_merge(int nobj, int nchunk, const double *__restrict__
     out[o] = m > -INFINITY ? m + log(ssum) : -INFINITY;
 }
 
+// ===========================================================================
+// lnpost on the device (fitting.py:1000-1107 and the tail of _fit, :2021-2061)
+// for the built-in priors, with the counter-based random stream specified in
+// brutus_amd/rng.py (Philox4x32-7 + polar normals): any deviate is a pure
+// function of (seed, index), so every selected model of every object is
+// integrated in parallel and the result still equals, deviate for deviate, a
+// sequential run of the reference with that `rstate` object.
+// ===========================================================================
+struct Philox4 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        if (r > 0) {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+    }
+    Philox4 o;
+    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// q-th uniform of the uniform stream (rng.py: philox_uniform)
+__device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t q) {
+    const Philox4 o = philox4x32_7((uint32_t)q, (uint32_t)(q >> 32), 0u, 1u, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+    return u53(o.w[0], o.w[1]);
+}
+
+// pair p of the normal stream (rng.py: philox_normal): z0 = normal 2p, z1 = normal 2p+1
+__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, double &z0, double &z1) {
+    for (uint32_t retry = 0;; ++retry) {
+        const Philox4 o = philox4x32_7((uint32_t)p, (uint32_t)(p >> 32), retry, 0u, (uint32_t)seed,
+                                       (uint32_t)(seed >> 32));
+        const double x1 = 2.0 * u53(o.w[0], o.w[1]) - 1.0;
+        const double x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
+        const double r2 = __dadd_rn(__dmul_rn(x1, x1), __dmul_rn(x2, x2));   // no FMA: matches numpy
+        if (r2 < 1.0 && r2 > 0.0) {
+            const double f = sqrt(-2.0 * log(r2) / r2);
+            z0 = f * x1;
+            z1 = f * x2;
+            return;
+        }
+    }
+}
+__device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t j) {
+    double z0, z1;
+    rng_normal_pair(seed, j >> 1, z0, z1);
+    return (j & 1) ? z1 : z0;
+}
+
+struct PostParams {     // mirrors brutus_post_params
+    int32_t nmc, ndraws, return_distreds, has_feh, has_loga, per_object;
+    double wt_thresh, avlim[2], rvlim[2];
+    int64_t nsel_max, object0;
+    uint64_t seed, normal_base, uniform_base;
+    double R_solar, Z_solar, R_thin, Z_thin, Rs_thin, R_thick, Z_thick, f_thick, Rs_thick;
+    double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
+    double feh_mean[3], feh_sigma[3];
+    double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+};
+
+// stream key and uniform base of object s: one shared sequential stream, or
+// (per_object) an own stream keyed seed + object index
+__device__ __forceinline__ uint64_t star_seed(const PostParams &pp, int s) {
+    return pp.per_object ? pp.seed + (uint64_t)(pp.object0 + s) : pp.seed;
+}
+__device__ __forceinline__ uint64_t star_ubase(const PostParams &pp, int s) {
+    return pp.per_object ? 0ull
+                         : pp.uniform_base + (uint64_t)s * (uint64_t)(pp.ndraws * (pp.return_distreds ? 2 : 1));
+}
+
+struct StarGeom {      // per object: sightline unit vector and parallax
+    double cb_cl, cb_sl, sb;     // cos b cos l, cos b sin l, sin b
+    double par, par_ivar, par_lnorm;
+    int has_par;
+};
+
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    double m = a > b ? a : b;
+    m = c > m ? c : m;
+    if (!(m > -INFINITY)) return m;          // all -inf (or NaN)
+    return log(exp(a - m) + exp(b - m) + exp(c - m)) + m;
+}
+
+// per-model metallicity / age terms of the three components (pdf.py:380-473)
+__device__ __forceinline__ void label_terms(const PostParams &pp, double feh, double loga,
+                                            double (&Fc)[3], double (&Ac)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Fc[c] = 0.;
+        Ac[c] = 0.;
+        if (pp.has_feh) {
+            const double d = pp.feh_mean[c] - feh;
+            Fc[c] = -0.5 * (d * d / (pp.feh_sigma[c] * pp.feh_sigma[c]) +
+                            log(2. * M_PI * pp.feh_sigma[c] * pp.feh_sigma[c]));
+        }
+        if (pp.has_loga) {
+            const double age = exp10(loga) / 1e9;
+            const double xi = (age - pp.age_mean[c]) / pp.age_sigma[c];
+            Ac[c] = (age < pp.min_age || age > pp.max_age)
+                        ? -INFINITY
+                        : -0.91893853320467274178 - 0.5 * xi * xi - pp.age_lnnorm[c];
+        }
+    }
+}
+
+// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc]
+__device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const StarGeom &g, double d,
+                                                  const double (&Fc)[3], const double (&Ac)[3]) {
+    const double vol = 2. * log(d + 1e-300);
+    const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
+    const double R2 = x * x + y * y;
+    const double aZ = fabs(Z), aZs = fabs(pp.Z_solar);
+    double comp[3];
+    comp[0] = -((sqrt(R2 + pp.Rs_thin * pp.Rs_thin) - pp.R_solar) / pp.R_thin +
+                (aZ - aZs) / pp.Z_thin) + vol;
+    comp[1] = -((sqrt(R2 + pp.Rs_thick * pp.Rs_thick) - pp.R_solar) / pp.R_thick +
+                (aZ - aZs) / pp.Z_thick) + vol + log(pp.f_thick);
+    {
+        const double rq2 = pp.r_q_halo * pp.r_q_halo;
+        const double q = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
+                                             exp(1. - sqrt(R2 + Z * Z + rq2) / pp.r_q_halo);
+        const double reff = sqrt(R2 + (Z / q) * (Z / q) + pp.Rs_halo * pp.Rs_halo);
+        const double Rs2 = pp.R_solar * pp.R_solar, Zs = pp.Z_solar;
+        const double qs = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
+                                              exp(1. - sqrt(Rs2 + Zs * Zs + rq2) / pp.r_q_halo);
+        const double reff_s = sqrt(Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
+        comp[2] = -pp.eta_halo * log(reff / reff_s) + vol + log(pp.f_halo);
+    }
+    const double base = lse3(comp[0], comp[1], comp[2]);
+    double out = base;
+    // lse_c(F_c + comp_c - base) etc.: membership-weighted label priors
+    if (pp.has_feh)
+        out += lse3(Fc[0] + (comp[0] - base), Fc[1] + (comp[1] - base), Fc[2] + (comp[2] - base));
+    if (pp.has_loga)
+        out += lse3(Ac[0] + (comp[0] - base), Ac[1] + (comp[1] - base), Ac[2] + (comp[2] - base));
+    return out;
+}
+
+constexpr int PCH = 64;      // chunks per object for the record passes
+
+// first membership word of object s (objects' 256-record tiles do not share words)
+__device__ __forceinline__ int64_t mask_base(const int64_t *__restrict__ off, int s) {
+    return ((off[s] + 63) >> 6) + 8 * (int64_t)s;
+}
+
+// record range of workgroup (chunk c, star s): 256-aligned slices of [off[s], off[s+1])
+__device__ __forceinline__ void rec_range(const int64_t *__restrict__ off, int s, int c, int64_t &a,
+                                          int64_t &b) {
+    const int64_t lo = off[s], n = off[s + 1] - lo;
+    const int64_t ntile = (n + TILE - 1) / TILE;
+    a = lo + (ntile * c / PCH) * TILE;
+    b = lo + (ntile * (c + 1) / PCH) * TILE;
+    if (b > lo + n) b = lo + n;
+    if (a > lo + n) a = lo + n;
+}
+
+// P1: lnp of the MLE point for the second cut (fitting.py:1000-1010)
+__global__ void __launch_bounds__(TILE)
+k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
+            const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+            const StarGeom *__restrict__ geom, const double *__restrict__ lnprior,
+            const double *__restrict__ feh, const double *__restrict__ loga,
+            double *__restrict__ lnp1, double *__restrict__ part) {
+    __shared__ double slot[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    const StarGeom g = geom[s];
+    double m = -INFINITY;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        if (r < b) {
+            const int64_t i = sel_idx[r];
+            double Fc[3], Ac[3];
+            label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+            const double scale = sel_vals[2 * cap + r];
+            const double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, 1. / sqrt(scale), Fc, Ac);
+            lnp1[r] = v;
+            if (v > m) m = v;
+        }
+    }
+    block_max_store(m, slot, part + (int64_t)s * PCH + c);
+}
+
+// P2a: second cut (fitting.py:1013-1016): count + membership words
+__global__ void __launch_bounds__(TILE)
+k_post_count2(double ln_wt, const int64_t *__restrict__ sel_off, const double *__restrict__ lnp1,
+              const double *__restrict__ part, int64_t *__restrict__ counts,
+              unsigned long long *__restrict__ mask) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    double mx = -INFINITY;
+    for (int q = 0; q < PCH; ++q) {
+        const double v = part[(int64_t)s * PCH + q];
+        mx = v > mx ? v : mx;
+    }
+    const double thr = mx + ln_wt;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    int n = 0;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        const bool hit = r < b && lnp1[r] > thr;
+        n += hit ? 1 : 0;
+        const unsigned long long bl = __ballot(hit);
+        if ((threadIdx.x & 63) == 0)
+            mask[mask_base(sel_off, s) + ((r0 - sel_off[s]) >> 6) + (threadIdx.x >> 6)] = bl;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)s * PCH + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// P2b: offsets of the second-cut lists; normal-stream base of every object
+// (3 * nmc normals per kept model, objects in order: exactly what a sequential
+// rstate would have consumed), host-fallback flags.
+__global__ void k_post_offsets(PostParams pp, int nstar, const int64_t *__restrict__ counts,
+                               int64_t *__restrict__ offsets, int64_t *__restrict__ off2,
+                               uint64_t *__restrict__ nbase, int32_t *__restrict__ flags) {
+    __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
+    const int s = threadIdx.x;
+    int64_t n = 0;
+    if (s < nstar)
+        for (int c = 0; c < PCH; ++c) n += counts[(int64_t)s * PCH + c];
+    if (s < nstar) tot[s] = n;
+    __syncthreads();
+    if (s == 0) {
+        int64_t run = 0;
+        uint64_t nb = pp.normal_base;
+        for (int q = 0; q < nstar; ++q) {
+            const int64_t m = tot[q];
+            tot[q] = run;
+            off2[q] = run;
+            nbase[q] = pp.per_object ? 0ull : nb;
+            const int64_t used = m > pp.nsel_max ? pp.nsel_max : m;   // fitting.py:1029-1036
+            flags[q] = m > pp.nsel_max ? 1 : 0;
+            nb += (uint64_t)(3 * (int64_t)pp.nmc * used);
+            run += m;
+        }
+        off2[nstar] = run;
+        nbase[nstar] = nb;
+    }
+    __syncthreads();
+    if (s < nstar) {
+        int64_t run = tot[s];
+        for (int c = 0; c < PCH; ++c) {
+            offsets[(int64_t)s * PCH + c] = run;
+            run += counts[(int64_t)s * PCH + c];
+        }
+    }
+}
+
+// P2c: ordered scatter of the kept records + per-record preparation
+// (fitting.py:1023, 1039-1065): lnp0 = lnlike + lnprior, covariance by the
+// adjugate, PSD repair, Cholesky factor of cov + 1e-30 I.
+struct RecPost {      // arrays over second-cut records (capacity = first-cut capacity)
+    int32_t *src;     // position in the first-cut record arrays
+    double *lnp;      // lnp0, later the final lnp
+    double *cov;      // [6][cap]
+    double *chol;     // [6][cap]  L00 L10 L11 L20 L21 L22
+};
+
+__device__ __forceinline__ bool inv3_sym(const double (&A)[6], double (&C)[6]) {
+    // A, C: 00 01 02 11 12 22.  Adjugate by row cross products, determinant as
+    // the mean of the three row.cofactor-row dots (utils.py:71-114).
+    const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double c11 = a22 * a00 - a02 * a02, c12 = a02 * a01 - a12 * a00;
+    const double c22 = a00 * a11 - a01 * a01;
+    const double d0 = c00 * a00 + c01 * a01 + c02 * a02;
+    const double d1 = c01 * a01 + c11 * a11 + c12 * a12;
+    const double d2 = c02 * a02 + c12 * a12 + c22 * a22;
+    const double det = (d0 + d1 + d2) / 3.;
+    C[0] = c00 / det; C[1] = c01 / det; C[2] = c02 / det;
+    C[3] = c11 / det; C[4] = c12 / det; C[5] = c22 / det;
+    return true;
+}
+
+__device__ __forceinline__ bool is_pd3(const double (&C)[6]) {
+    // all eigenvalues > 0 (fitting.py:1042) <=> leading principal minors > 0
+    const double m2 = C[0] * C[3] - C[1] * C[1];
+    const double m3 = C[0] * (C[3] * C[5] - C[4] * C[4]) - C[1] * (C[1] * C[5] - C[4] * C[2]) +
+                      C[2] * (C[1] * C[4] - C[3] * C[2]);
+    return C[0] > 0. && m2 > 0. && m3 > 0.;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const double *__restrict__ sel_vals,
+                const int64_t *__restrict__ sel_off, const double *__restrict__ lnprior,
+                const unsigned long long *__restrict__ mask, const int64_t *__restrict__ offsets,
+                RecPost rp) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    int64_t base = offsets[(int64_t)s * PCH + c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        const unsigned long long bl = mask[mask_base(sel_off, s) + ((r0 - sel_off[s]) >> 6) + w];
+        const bool sel = (bl >> lane) & 1ull;
+        const int rank = __popcll(bl & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(bl);
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < w; ++q) woff += wsum[q];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (sel) {
+            const int64_t o = base + woff + rank;
+            rp.src[o] = (int32_t)(r - sel_off[s]);
+            rp.lnp[o] = sel_vals[r] + lnprior[sel_idx[r]];
+            double A[6], C[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + r];
+            inv3_sym(A, C);
+            const double scale = sel_vals[2 * cap + r];
+            const double width = 0.02;
+            double count = 1.;
+            for (int it = 0; it < 200 && !is_pd3(C); ++it) {       // fitting.py:1045-1065
+                const double sf = scale * width;
+                const bool i1 = C[0] <= 0., i2 = C[3] <= 0., i3 = C[5] <= 0.;
+                if (i1 || (!i2 && !i3)) A[0] += count / (sf * sf);
+                if (i2 || (!i1 && !i3)) A[3] += count / (width * width);
+                if (i3 || (!i1 && !i2)) A[5] += count / (width * width);
+                inv3_sym(A, C);
+                count *= 2.;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rp.cov[(int64_t)k * cap + o] = C[k];
+            // Cholesky of cov + 1e-30 I (utils.py:892-894)
+            const double l00 = sqrt(C[0] + 1e-30);
+            const double l10 = C[1] / l00, l20 = C[2] / l00;
+            const double l11 = sqrt(C[3] + 1e-30 - l10 * l10);
+            const double l21 = (C[4] - l20 * l10) / l11;
+            const double l22 = sqrt(C[5] + 1e-30 - l20 * l20 - l21 * l21);
+            rp.chol[0 * cap + o] = l00;
+            rp.chol[1 * cap + o] = l10;
+            rp.chol[2 * cap + o] = l11;
+            rp.chol[3 * cap + o] = l20;
+            rp.chol[4 * cap + o] = l21;
+            rp.chol[5 * cap + o] = l22;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+// One Monte Carlo sample t of kept record `o` of object s (fitting.py:1071-1093):
+// returns lnp_mc and the sample (dist, av, rv).  n = rank of the record in the
+// object's list: its normals sit at nbase + (3 n + k) nmc + t (utils.py:897).
+__device__ __forceinline__ double mc_sample(const PostParams &pp, uint64_t seed, const StarGeom &g,
+                                            uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
+                                            const double (&L)[6], const double (&Fc)[3],
+                                            const double (&Ac)[3], double &dist, double &a_mc,
+                                            double &r_mc, bool &inb) {
+    const uint64_t j0 = nb + (uint64_t)((3 * n) * (int64_t)pp.nmc + t);
+    const double z0 = rng_normal(seed, j0);
+    const double z1 = rng_normal(seed, j0 + (uint64_t)pp.nmc);
+    const double z2 = rng_normal(seed, j0 + 2ull * (uint64_t)pp.nmc);
+    const double s_mc = s0 + L[0] * z0;
+    a_mc = a0 + (L[1] * z0 + L[2] * z1);
+    r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
+    const double par = sqrt(s_mc);
+    dist = 1. / par;
+    double v = gal_lnprior_dev(pp, g, dist, Fc, Ac);
+    if (g.has_par) {                                            // pdf.py:166-173
+        const double dp = par - g.par;
+        v += -0.5 * (dp * dp * g.par_ivar + g.par_lnorm);
+    }
+    inb = s_mc >= 1e-20 && a_mc >= pp.avlim[0] && a_mc <= pp.avlim[1] &&
+          r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
+    if (!inb) v = -BIG;
+    return v;
+}
+
+// P4: Monte Carlo prior integral of every kept record (fitting.py:1068-1105)
+// and chi2min (fitting.py:2025-2034).  One lane per record.
+__global__ void __launch_bounds__(TILE)
+k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
+          const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+          const int64_t *__restrict__ off2, const uint64_t *__restrict__ nbase,
+          const int32_t *__restrict__ flags, const StarGeom *__restrict__ geom,
+          const double *__restrict__ feh, const double *__restrict__ loga, RecPost rp,
+          double *__restrict__ part_max, double *__restrict__ part_chi2) {
+    __shared__ double slot[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    int64_t a, b;
+    rec_range(off2, s, c, a, b);
+    const StarGeom g = geom[s];
+    const uint64_t nb = nbase[s];
+    const uint64_t seed = star_seed(pp, s);
+    double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
+    if (!flags[s]) {
+        for (int64_t o0 = a; o0 < b; o0 += TILE) {
+            const int64_t o = o0 + threadIdx.x;
+            if (o < b) {
+                const int64_t r = sel_off[s] + rp.src[o];
+                const int64_t i = sel_idx[r];
+                double Fc[3], Ac[3], L[6];
+                label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+                for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+                const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
+                             r0 = sel_vals[4 * cap + r];
+                const int64_t n = o - off2[s];
+                double m = -INFINITY, acc = 0.;
+                int ninb = 0;
+                for (int t = 0; t < pp.nmc; ++t) {
+                    double d_, a_, r_;
+                    bool inb;
+                    const double v = mc_sample(pp, seed, g, nb, n, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb);
+                    if (inb) ++ninb;
+                    if (v == v) {                       // logsumexp ignores nothing; NaN poisons
+                        if (v > m) {
+                            acc = acc * exp(m - v) + 1.;
+                            m = v;
+                        } else if (v > -INFINITY) {
+                            acc += exp(v - m);
+                        }
+                    } else {
+                        acc = nan("");
+                    }
+                }
+                double lnp = rp.lnp[o] + ((log(acc) + m) - log((double)ninb));
+                if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
+                rp.lnp[o] = lnp;
+                if (lnp > mx) mx = lnp;
+                double chi2 = sel_vals[1 * cap + r];
+                if (g.has_par) {
+                    const double dp = sqrt(s0) - g.par;
+                    chi2 += dp * dp * g.par_ivar;
+                }
+                if (-chi2 > cmin) cmin = -chi2;
+            }
+        }
+    }
+    block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
+    block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
+}
+
+// P5: evidence and the cumulative weights of one object (fitting.py:2033-2038);
+// one workgroup per object, sequential 256-wide scan with carry.
+__global__ void __launch_bounds__(TILE)
+k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int32_t *__restrict__ flags,
+           const double *__restrict__ part_max, const double *__restrict__ part_chi2, RecPost rp,
+           double *__restrict__ cdf, double *__restrict__ star_out) {
+    __shared__ double sh[TILE];
+    __shared__ double carry;
+    const int s = blockIdx.x;
+    if (flags[s]) return;
+    const int64_t a = off2[s], b = off2[s + 1];
+    double mx = -INFINITY, cm = -INFINITY;
+    for (int q = 0; q < PCH; ++q) {
+        mx = fmax(mx, part_max[(int64_t)s * PCH + q]);
+        cm = fmax(cm, part_chi2[(int64_t)s * PCH + q]);
+    }
+    // levid = logsumexp(lnp)
+    double acc = 0.;
+    for (int64_t o = a + threadIdx.x; o < b; o += TILE) acc += exp(rp.lnp[o] - mx);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = TILE / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    const double levid = log(sh[0]) + mx;
+    __syncthreads();
+    // running sum of wt = exp(lnp - levid)
+    if (threadIdx.x == 0) carry = 0.;
+    __syncthreads();
+    for (int64_t o0 = a; o0 < b; o0 += TILE) {
+        const int64_t o = o0 + threadIdx.x;
+        const double w = o < b ? exp(rp.lnp[o] - levid) : 0.;
+        sh[threadIdx.x] = w;
+        __syncthreads();
+        for (int st = 1; st < TILE; st <<= 1) {          // Hillis-Steele inclusive scan
+            const double v = threadIdx.x >= st ? sh[threadIdx.x - st] : 0.;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (o < b) cdf[o] = carry + sh[threadIdx.x];
+        __syncthreads();
+        if (threadIdx.x == TILE - 1) carry += sh[TILE - 1];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        star_out[4 * s + 0] = levid;
+        star_out[4 * s + 1] = -cm;            // chi2min
+        star_out[4 * s + 2] = carry;          // total weight (cdf normaliser)
+        star_out[4 * s + 3] = (double)(b - a);
+    }
+}
+
+// P6: resampling (fitting.py:2037-2057).  One lane per (object, draw).
+constexpr int POST_NOUT = 17;   // scale av rv cov[9] lnprob dist red dred logwt
+__global__ void __launch_bounds__(64)
+k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ sel_idx,
+            const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+            const int64_t *__restrict__ off2, const uint64_t *__restrict__ nbase,
+            const int32_t *__restrict__ flags, const StarGeom *__restrict__ geom,
+            const double *__restrict__ feh, const double *__restrict__ loga, RecPost rp,
+            const double *__restrict__ cdf, const double *__restrict__ star_out,
+            int32_t *__restrict__ out_idx, double *__restrict__ out_vals) {
+    const int s = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= pp.ndraws || flags[s]) return;
+    const int64_t a = off2[s], nsel = off2[s + 1] - a;
+    if (nsel <= 0) return;
+    const StarGeom g = geom[s];
+    const uint64_t ub = star_ubase(pp, s);
+    const uint64_t seed = star_seed(pp, s);
+    // choice(Nsel, p=wt): searchsorted(cdf / cdf[-1], u, side='right')
+    const double total = star_out[4 * s + 2];
+    const double u = rng_uniform(seed, ub + (uint64_t)q);
+    int64_t lo = 0, hi = nsel;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[a + mid] / total <= u) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= nsel) lo = nsel - 1;
+    const int64_t o = a + lo;
+    const int64_t r = sel_off[s] + rp.src[o];
+    const int64_t i = sel_idx[r];
+    out_idx[(int64_t)s * pp.ndraws + q] = (int32_t)i;
+    double *ov = out_vals + ((int64_t)s * pp.ndraws + q) * POST_NOUT;
+    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r], r0 = sel_vals[4 * cap + r];
+    ov[0] = s0;
+    ov[1] = a0;
+    ov[2] = r0;
+    double C[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = rp.cov[(int64_t)k * cap + o];
+    ov[3] = C[0]; ov[4] = C[1]; ov[5] = C[2];
+    ov[6] = C[1]; ov[7] = C[3]; ov[8] = C[4];
+    ov[9] = C[2]; ov[10] = C[4]; ov[11] = C[5];
+    ov[12] = rp.lnp[o];
+    if (!pp.return_distreds) return;
+    // second stage (fitting.py:2049-2057): pick one of the record's nmc samples
+    double Fc[3], Ac[3], L[6];
+    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+    const uint64_t nb = nbase[s];
+    double m = -INFINITY;
+    bool inb_;
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        const double v = mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        if (v > m) m = v;
+    }
+    double z = 0.;
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        z += exp(mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_) - m);
+    }
+    // wt = softmax(logwts); imc = searchsorted(cumsum(wt) / sum, u2, side='right')
+    const double u2 = rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
+    double run = 0., dist = 0., red = 0., dred = 0., lw = 0.;
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        const double v = mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        run += exp(v - m);
+        dist = d_; red = a_; dred = r_; lw = v;
+        if (run / z > u2) break;          // first cumulative weight above u2
+    }
+    ov[13] = dist;
+    ov[14] = red;
+    ov[15] = dred;
+    ov[16] = lw;
+}
+
+// per-object geometry / parallax constants
+__global__ void k_post_geom(int nstar, const double *__restrict__ coords,
+                            const double *__restrict__ par, const double *__restrict__ perr,
+                            StarGeom *__restrict__ geom) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstar) return;
+    const double l = coords[2 * s] * (M_PI / 180.), b = coords[2 * s + 1] * (M_PI / 180.);
+    StarGeom g;
+    g.cb_cl = cos(b) * cos(l);
+    g.cb_sl = cos(b) * sin(l);
+    g.sb = sin(b);
+    const double p = par ? par[s] : nan(""), pe = perr ? perr[s] : nan("");
+    g.has_par = (isfinite(p) && isfinite(pe)) ? 1 : 0;
+    g.par = g.has_par ? p : 0.;
+    g.par_ivar = g.has_par ? 1. / (pe * pe) : 0.;
+    g.par_lnorm = g.has_par ? log(2. * M_PI * pe * pe) : 0.;
+    geom[s] = g;
+}
+
+__global__ void k_debug_normals(uint64_t seed, uint64_t start, int64_t n, double *__restrict__ z,
+                                double *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[i] = rng_normal(seed, start + (uint64_t)i);
+    u[i] = rng_uniform(seed, start + (uint64_t)i);
+}
+
+__global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict__ dist,
+                                 const double *__restrict__ coords, const double *__restrict__ feh,
+                                 const double *__restrict__ loga, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StarGeom g;
+    const double l = coords[0] * (M_PI / 180.), b = coords[1] * (M_PI / 180.);
+    g.cb_cl = cos(b) * cos(l);
+    g.cb_sl = cos(b) * sin(l);
+    g.sb = sin(b);
+    g.has_par = 0;
+    double Fc[3], Ac[3];
+    label_terms(pp, feh[i], loga[i], Fc, Ac);
+    out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac);
+}
+
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
@@ -2041,6 +2675,139 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
 #undef BRUTUS_CL
     hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + 255) / 256), dim3(256), 0, st, nobj, nchunk, pm,
                        ps, d_lnl);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- lnpost on the device ---------------------------------------------------
+struct PostWs {
+    double *lnp1, *part, *part_max, *part_chi2, *cdf, *star_out;
+    unsigned long long *mask;
+    int64_t *counts, *offsets, *off2;
+    uint64_t *nbase;
+    int32_t *flags;
+    StarGeom *geom;
+    RecPost rp;
+    size_t bytes;
+};
+
+PostWs carve_post(char *base, int nstar, int64_t cap) {
+    PostWs w{};
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        char *p = base ? base + off : nullptr;
+        off += align_up(n);
+        return p;
+    };
+    const size_t c = (size_t)cap;
+    w.lnp1 = (double *)take(8 * c);
+    w.mask = (unsigned long long *)take(8 * (c / 64 + 8 * (size_t)nstar + 16));
+    w.counts = (int64_t *)take(8 * (size_t)nstar * PCH);
+    w.offsets = (int64_t *)take(8 * (size_t)nstar * PCH);
+    w.part = (double *)take(8 * (size_t)nstar * PCH);
+    w.part_max = (double *)take(8 * (size_t)nstar * PCH);
+    w.part_chi2 = (double *)take(8 * (size_t)nstar * PCH);
+    w.off2 = (int64_t *)take(8 * ((size_t)nstar + 1));
+    w.nbase = (uint64_t *)take(8 * ((size_t)nstar + 1));
+    w.flags = (int32_t *)take(4 * (size_t)nstar);
+    w.geom = (StarGeom *)take(sizeof(StarGeom) * (size_t)nstar);
+    w.star_out = (double *)take(8 * 4 * (size_t)nstar);
+    w.rp.src = (int32_t *)take(4 * c);
+    w.rp.lnp = (double *)take(8 * c);
+    w.rp.cov = (double *)take(8 * 6 * c);
+    w.rp.chol = (double *)take(8 * 6 * c);
+    w.cdf = (double *)take(8 * c);
+    w.bytes = off;
+    return w;
+}
+
+size_t brutus_post_workspace_bytes(int nstar, int64_t capacity) {
+    if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1) return 0;
+    return carve_post(nullptr, nstar, capacity).bytes;
+}
+
+int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                      const double *d_sel_vals, const int64_t *d_sel_off, const double *d_lnprior,
+                      const double *d_feh, const double *d_loga, const double *d_coords,
+                      const double *d_parallax, const double *d_parallax_err,
+                      const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
+                      int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
+                      int32_t *h_flags, uint64_t *h_nbase, void *stream) {
+    static_assert(sizeof(PostParams) == sizeof(brutus_post_params), "post params layout");
+    if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1)
+        return fail(BRUTUS_EINVAL, "bad post dimensions");
+    if (!d_sel_idx || !d_sel_vals || !d_sel_off || !d_lnprior || !d_coords || !params ||
+        !d_workspace || !d_out_idx || !d_out_vals || !h_star_out || !h_flags)
+        return fail(BRUTUS_EINVAL, "NULL pointer");
+    if (params->nmc < 1 || params->ndraws < 1 || !(params->wt_thresh > 0.))
+        return fail(BRUTUS_EINVAL, "nmc, ndraws and wt_thresh must be positive");
+    if ((params->has_feh && !d_feh) || (params->has_loga && !d_loga))
+        return fail(BRUTUS_EINVAL, "label arrays missing");
+    PostWs w = carve_post((char *)d_workspace, nstar, capacity);
+    if (w.bytes > workspace_bytes)
+        return fail(BRUTUS_ENOMEM, "post workspace too small: need %zu bytes, got %zu", w.bytes,
+                    workspace_bytes);
+    PostParams pp;
+    memcpy(&pp, params, sizeof(pp));
+    hipStream_t st = (hipStream_t)stream;
+    Timer tm(st);
+    const dim3 g2(PCH, nstar), blk(TILE);
+    hipLaunchKernelGGL(k_post_geom, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, d_coords,
+                       d_parallax, d_parallax_err, w.geom);
+    tm.begin("k_post_lnp1");
+    hipLaunchKernelGGL(k_post_lnp1, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+                       w.geom, d_lnprior, d_feh, d_loga, w.lnp1, w.part);
+    tm.end();
+    tm.begin("k_post_cut2");
+    hipLaunchKernelGGL(k_post_count2, g2, blk, 0, st, log(pp.wt_thresh), d_sel_off, w.lnp1, w.part,
+                       w.counts, w.mask);
+    hipLaunchKernelGGL(k_post_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, pp, nstar, w.counts,
+                       w.offsets, w.off2, w.nbase, w.flags);
+    hipLaunchKernelGGL(k_post_scatter2, g2, blk, 0, st, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+                       d_lnprior, w.mask, w.offsets, w.rp);
+    tm.end();
+    tm.begin("k_post_mc");
+    hipLaunchKernelGGL(k_post_mc, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+                       w.off2, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.part_max,
+                       w.part_chi2);
+    tm.end();
+    tm.begin("k_post_cdf");
+    hipLaunchKernelGGL(k_post_cdf, dim3(nstar), blk, 0, st, nstar, w.off2, w.flags, w.part_max,
+                       w.part_chi2, w.rp, w.cdf, w.star_out);
+    tm.end();
+    tm.begin("k_post_draw");
+    hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, nstar), dim3(64), 0, st, pp, nstar,
+                       capacity, d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nbase, w.flags, w.geom,
+                       d_feh, d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
+    tm.end();
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_star_out, w.star_out, 8 * 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(h_flags, w.flags, 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
+    if (h_nbase)
+        HIP_TRY(hipMemcpyAsync(h_nbase, w.nbase, 8 * ((size_t)nstar + 1), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    tm.collect();
+    return 0;
+}
+
+int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
+                     double *d_uniforms, void *stream) {
+    if (!d_normals || !d_uniforms || n <= 0) return fail(BRUTUS_EINVAL, "bad arguments");
+    hipLaunchKernelGGL(k_debug_normals, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, seed, start, n, d_normals, d_uniforms);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_debug_galprior(const brutus_post_params *params, int n, const double *d_dist,
+                          const double *d_coord, const double *d_feh, const double *d_loga,
+                          double *d_out, void *stream) {
+    if (!params || !d_dist || !d_coord || !d_feh || !d_loga || !d_out || n <= 0)
+        return fail(BRUTUS_EINVAL, "bad arguments");
+    PostParams pp;
+    memcpy(&pp, params, sizeof(pp));
+    hipLaunchKernelGGL(k_debug_galprior, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+                       pp, n, d_dist, d_coord, d_feh, d_loga, d_out);
     HIP_TRY(hipGetLastError());
     return 0;
 }

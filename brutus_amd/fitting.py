@@ -230,6 +230,68 @@ class _Engine(object):
             k1.ctypes.data, k2.ctypes.data, _stream_ptr(torch)))
         return sel_idx, sel_vals, sel_off, ndim, k1, k2
 
+    def records_device(self, f, e, m, p, pe, has_par, params):
+        """`fit_batch_device` with automatic growth of the record buffers."""
+        torch, L, g = self.torch, self.L, self.grid
+        S = f.shape[0]
+        bufs = getattr(self, "_sel_bufs", None)
+        sel_idx, sel_vals, sel_off, ndim, k1, k2 = self.fit_batch_device(
+            f, e, m, p, pe, has_par, params, sel_buffers=bufs)
+        off = sel_off.cpu().numpy()
+        total, cap = int(off[-1]), sel_idx.numel()
+        if total > cap:
+            cap = int(total * 1.25) + 1024
+            sel_idx = torch.empty(cap, dtype=torch.int32, device=g.device)
+            sel_vals = torch.empty((_lib.NVALS, cap), dtype=torch.float64,
+                                   device=g.device)
+            ws = self._workspace(S)
+            _lib.check(L.brutus_fit_gather(
+                g.soa.data_ptr(), g.nmodel, g.nfilt, S, params, ws.data_ptr(),
+                ws.numel(), cap, sel_idx.data_ptr(), sel_vals.data_ptr(),
+                sel_off.data_ptr(), _stream_ptr(torch)))
+        self._sel_bufs = (sel_idx, sel_vals)
+        return sel_idx, sel_vals, sel_off, off, ndim.cpu().numpy(), k1, k2
+
+    def post_batch_device(self, sel_idx, sel_vals, sel_off, nstar, statics,
+                          coords, parallax, parallax_err, pp):
+        """`brutus_post_batch` on device-resident records.  `statics` =
+        (lnprior, feh, loga) device tensors (feh / loga may be None)."""
+        torch, L, g = self.torch, self.L, self.grid
+        cap = sel_idx.numel()
+        nbytes = L.brutus_post_workspace_bytes(nstar, cap)
+        if getattr(self, "_post_ws", None) is None or self._post_ws.numel() < nbytes:
+            self._post_ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)
+        t_coords, t_par, t_perr = dev(coords), dev(parallax), dev(parallax_err)
+        out_idx = torch.empty((nstar, pp.ndraws), dtype=torch.int32, device=g.device)
+        out_vals = torch.empty((nstar, pp.ndraws, 17), dtype=torch.float64,
+                               device=g.device)
+        star_out = np.zeros((nstar, 4))
+        flags = np.zeros(nstar, dtype=np.int32)
+        nbase = np.zeros(nstar + 1, dtype=np.uint64)
+        lnprior, feh, loga = statics
+        _lib.check(L.brutus_post_batch(
+            nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
+            lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
+            loga.data_ptr() if loga is not None else None, t_coords.data_ptr(),
+            t_par.data_ptr(), t_perr.data_ptr(), pp, self._post_ws.data_ptr(),
+            self._post_ws.numel(), out_idx.data_ptr(), out_vals.data_ptr(),
+            star_out.ctypes.data, flags.ctypes.data, nbase.ctypes.data,
+            _stream_ptr(torch)))
+        return (out_idx.cpu().numpy(), out_vals.cpu().numpy(), star_out, flags,
+                nbase)
+
+    @staticmethod
+    def record_of(sel_idx, sel_vals, off, s, ndim, k1=0, k2=0):
+        """One object's first-cut records as the host-stage dict."""
+        a, b = int(off[s]), int(off[s + 1])
+        idx = sel_idx[a:b].cpu().numpy()
+        vals = sel_vals[:, a:b].cpu().numpy()
+        return dict(sel=idx.astype(np.int64), lnlike=vals[0], chi2=vals[1],
+                    scale=vals[2], av=vals[3], rv=vals[4],
+                    icov=_icov_from6(vals[5:11]), Ndim=int(ndim), K1=int(k1),
+                    K2=int(k2))
+
     def fit_batch(self, flux, err, mask, parallax, parallax_err, params):
         """Host numpy in -> list of per-star compact record dicts."""
         torch, L, g = self.torch, self.L, self.grid
@@ -589,6 +651,9 @@ class BruteForce(object):
         self._engine_obj = None
         #: stars per device batch (None = sized from the memory budget)
         self.batch_size = None
+        #: run `lnpost` + resampling on the device when the priors are the
+        #: built-in ones and `rstate` is a `rng.PhiloxRandomState`
+        self.device_lnpost = True
         #: host processes for the `lnpost` stage when objects have their own
         #: RNG seed (`_fit(seed0=...)`, `parallel.fit_sharded`); 0/1 = in-process
         self.host_workers = 0
@@ -857,6 +922,24 @@ class BruteForce(object):
                               ltol_subthresh, logl_initthresh, logl_dim_prior,
                               wt_thresh=wt_thresh)
         step = eng.batch if lnprior_ext is None else max(1, min(eng.batch, 8))
+        from .rng import PhiloxRandomState
+        philox_per_object = (seed0 is not None and isinstance(rstate_per_object, str)
+                             and rstate_per_object == "philox")
+        if philox_per_object:
+            rstate_per_object = lambda i: PhiloxRandomState(seed0 + i)
+        if (self.device_lnpost and lnprior_ext is None and not apply_av_prior
+                and lndustprior is None and wt_thresh is not None and wt_thresh > 0
+                and getattr(lngalprior, "device_params", None) is not None
+                and (philox_per_object
+                     or (isinstance(rstate, PhiloxRandomState)
+                         and rstate_per_object is None))):
+            for out in self._fit_device_post(
+                    eng, params, step, data, data_err, data_mask, parallax,
+                    parallax_err, data_coords, lnprior, lngalprior, dlabels,
+                    Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim, rvlim,
+                    mem_lim, return_distreds, rstate, seed0 if philox_per_object else None):
+                yield out
+            return
         if seed0 is not None and rstate_per_object is None:
             rstate_per_object = lambda i: np.random.RandomState(seed0 + i)
         pool = None
@@ -918,6 +1001,91 @@ class BruteForce(object):
                                         Ndraws, return_distreds)
         while pending:
             yield pending.pop(0).get()
+
+    def _fit_device_post(self, eng, params, step, data, data_err, data_mask,
+                         parallax, parallax_err, data_coords, lnprior, lngalprior,
+                         dlabels, Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim,
+                         rvlim, mem_lim, return_distreds, rstate, seed0):
+        """`_fit` with `lnpost` and the resampling on the device
+        (`brutus_post_batch`): built-in priors, Philox random stream.  Yields
+        exactly what the host stage yields for the same `rstate` -- one shared
+        sequential `PhiloxRandomState`, or (`seed0`) one stream per object."""
+        from .rng import PhiloxRandomState
+        torch = eng.torch
+        dev = eng.grid.device
+        names = dlabels.dtype.names if dlabels is not None else ()
+        up = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(dev)
+        statics = (up(lnprior),
+                   up(dlabels['feh']) if 'feh' in names else None,
+                   up(dlabels['loga']) if 'loga' in names else None)
+        gp = lngalprior.device_params()
+        K = Ndraws * (2 if return_distreds else 1)
+        Ndata = data.shape[0]
+        for a in range(0, Ndata, step):
+            b = min(Ndata, a + step)
+            S = b - a
+            with torch.cuda.device(dev):
+                f, e, m, p, pe, hp = eng._upload(data[a:b], data_err[a:b],
+                                                 data_mask[a:b], parallax[a:b],
+                                                 parallax_err[a:b])
+                (sel_idx, sel_vals, sel_off, off, ndim, k1,
+                 k2) = eng.records_device(f, e, m, p, pe, hp, params)
+                pp = _lib.PostParams()
+                pp.nmc, pp.ndraws = int(Nmc_prior), int(Ndraws)
+                pp.return_distreds = 1 if return_distreds else 0
+                pp.has_feh = 1 if statics[1] is not None else 0
+                pp.has_loga = 1 if statics[2] is not None else 0
+                pp.wt_thresh = float(wt_thresh)
+                pp.avlim[:] = [float(avlim[0]), float(avlim[1])]
+                pp.rvlim[:] = [float(rvlim[0]), float(rvlim[1])]
+                pp.nsel_max = int(mem_lim / Nmc_prior / 4.0e-4)
+                if seed0 is not None:
+                    pp.per_object, pp.object0, pp.seed = 1, a, int(seed0) & (2 ** 64 - 1)
+                    pp.normal_base = pp.uniform_base = 0
+                else:
+                    pp.per_object, pp.object0, pp.seed = 0, 0, rstate.seed
+                    pp.normal_base, pp.uniform_base = rstate.n_normal, rstate.n_uniform
+                for k, val in gp.items():
+                    if isinstance(val, tuple):
+                        getattr(pp, k)[:] = list(val)
+                    else:
+                        setattr(pp, k, val)
+                out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
+                    sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
+                    parallax[a:b], parallax_err[a:b], pp)
+                ubase0 = pp.uniform_base
+                if seed0 is None:      # what the batch consumed from the shared stream
+                    rstate.n_normal = int(nbase[S])
+                    rstate.n_uniform = int(ubase0) + S * K
+                for s in range(S):
+                    i = a + s
+                    if flags[s]:
+                        # more than Nsel_max models survive the second cut: the
+                        # reference re-sorts them (fitting.py:1029-1036); rare,
+                        # done by the host stage on the same stream positions
+                        rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
+                              PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
+                                                n_uniform=int(ubase0) + s * K))
+                        rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
+                        yield self._finish_star(rec, parallax[i], parallax_err[i],
+                                                data_coords[i], Nmc_prior, lnprior,
+                                                wt_thresh, cdf_thresh, lngalprior, None,
+                                                None, dlabels, avlim, rvlim, mem_lim, rs,
+                                                False, Ndraws, return_distreds)
+                        continue
+                    if star_out[s, 3] < 1:
+                        raise ValueError("object %d: no model survives the prior "
+                                         "cuts (the reference fails in np.min on an "
+                                         "empty selection, fitting.py:2034)" % i)
+                    v = out_vals[s]
+                    nd = int(ndim[s]) + (1 if np.isfinite(parallax[i])
+                                         and np.isfinite(parallax_err[i]) else 0)
+                    res = (out_idx[s].astype(np.int64), v[:, 0], v[:, 1], v[:, 2],
+                           v[:, 3:12].reshape(-1, 3, 3), nd, v[:, 12],
+                           float(star_out[s, 0]), float(star_out[s, 1]))
+                    if return_distreds:
+                        res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
+                    yield res
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
                             lnprior_ext, offset, wt_thresh):

@@ -144,6 +144,42 @@ def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
     return lnprior
 
 
+def device_params(**kw):
+    """The model constants of `gal_lnprior` (defaults of reference pdf.py:476-
+    488, overridable by keyword) as the dict of fields `brutus_post_params`
+    carries; the truncated-normal age prior is reduced to (mean, sigma,
+    ln-normalisation) per component here on the host."""
+    d = dict(R_solar=8.2, Z_solar=0.025, R_thin=2.6, Z_thin=0.3, Rs_thin=2.0,
+             R_thick=2.0, Z_thick=0.9, f_thick=0.04, Rs_thick=2.0, Rs_halo=2.0,
+             q_halo_ctr=0.2, q_halo_inf=0.8, r_q_halo=6.0, eta_halo=4.2,
+             f_halo=0.005, feh_thin=-0.2, feh_thin_sigma=0.3, feh_thick=-0.7,
+             feh_thick_sigma=0.4, feh_halo=-1.6, feh_halo_sigma=0.5,
+             max_age=13.8, min_age=0., feh_age_ctr=-0.5, feh_age_scale=0.5,
+             nsigma_from_max_age=2., max_sigma=4., min_sigma=1.)
+    d.update(kw)
+    means = (d["feh_thin"], d["feh_thick"], d["feh_halo"])
+    out = {k: d[k] for k in ("R_solar", "Z_solar", "R_thin", "Z_thin", "Rs_thin",
+                             "R_thick", "Z_thick", "f_thick", "Rs_thick",
+                             "Rs_halo", "q_halo_ctr", "q_halo_inf", "r_q_halo",
+                             "eta_halo", "f_halo", "min_age", "max_age")}
+    out["feh_mean"] = means
+    out["feh_sigma"] = (d["feh_thin_sigma"], d["feh_thick_sigma"], d["feh_halo_sigma"])
+    am, asg, aln = [], [], []
+    for m in means:
+        mean = ((d["max_age"] - d["min_age"])
+                / (1. + np.exp((m - d["feh_age_ctr"]) / d["feh_age_scale"])) + d["min_age"])
+        sig = min(max((d["max_age"] - mean) / d["nsigma_from_max_age"], d["min_sigma"]),
+                  d["max_sigma"])
+        lo, hi = (d["min_age"] - mean) / sig, (d["max_age"] - mean) / sig
+        am.append(mean)
+        asg.append(sig)
+        aln.append(log(sig / 2.) + log(erf(hi / sqrt(2.)) - erf(lo / sqrt(2.))))
+    out["age_mean"], out["age_sigma"], out["age_lnnorm"] = tuple(am), tuple(asg), tuple(aln)
+    return out
+
+
 #: `lnpost` may pass the (Nsel,) label table for (Nmc, Nsel) distances instead
 #: of a tiled copy: every label use above broadcasts.
 gal_lnprior.broadcasts_labels = True
+#: marks the hook as the built-in model the device `lnpost` implements
+gal_lnprior.device_params = device_params

@@ -1,0 +1,138 @@
+"""Counter-based random state for the `lnpost` / resampling stage.
+
+The reference draws from one sequential `numpy.random.RandomState`
+(`utils.py:897`, `fitting.py:2039`, `:2053`).  MT19937 plus the legacy polar
+Gaussian is inherently serial: the position of every deviate depends on all the
+rejections before it.  `PhiloxRandomState` is a drop-in `rstate` object (it
+provides the `normal`, `choice` and `random_sample` methods the reference
+calls, so the *reference itself* runs unchanged with it) whose j-th normal and
+q-th uniform are pure functions of `(seed, j)` / `(seed, q)`:
+
+    Philox4x32-7, key = the 64-bit seed, counter = (index lo, index hi, retry, stream)
+    uniform   u = ((w0 >> 5) * 2**26 + (w1 >> 6)) / 2**53       (numpy's 53-bit recipe)
+    normals   pair p = j >> 1: Marsaglia polar method on (u1, u2) of counter
+              (p, retry), retry = 0, 1, ... until 0 < x1^2 + x2^2 < 1;
+              normal j is f*x1 (j even) or f*x2 (j odd), f = sqrt(-2 ln(r2) / r2)
+
+Because any deviate can be computed without the ones before it, the device can
+evaluate the Monte Carlo integral of every selected model of every object in
+parallel (`brutus_post_batch`) and still reproduce, deviate for deviate, what
+this numpy class -- and therefore the reference run with it -- produces.
+This file is the specification of that stream.
+"""
+import numpy as np
+
+__all__ = ["PhiloxRandomState", "philox4x32", "philox_uniform", "philox_normal"]
+
+_M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
+_W0, _W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
+_MASK = np.uint64(0xFFFFFFFF)
+ROUNDS = 7
+STREAM_NORMAL, STREAM_UNIFORM = 0, 1
+
+
+def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
+    """Philox4x32 on arrays of 32-bit words held in uint64; returns 4 arrays."""
+    c0, c1, c2, c3 = (np.asarray(x, dtype=np.uint64) & _MASK for x in (c0, c1, c2, c3))
+    k0 = np.uint64(k0) & _MASK
+    k1 = np.uint64(k1) & _MASK
+    for r in range(rounds):
+        if r > 0:
+            k0 = (k0 + _W0) & _MASK
+            k1 = (k1 + _W1) & _MASK
+        p0 = _M0 * c0
+        p1 = _M1 * c2
+        hi0, lo0 = p0 >> np.uint64(32), p0 & _MASK
+        hi1, lo1 = p1 >> np.uint64(32), p1 & _MASK
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+    return c0, c1, c2, c3
+
+
+def _u53(a, b):
+    return ((a >> np.uint64(5)) * 67108864.0 + (b >> np.uint64(6))) / 9007199254740992.0
+
+
+def philox_uniform(seed, index):
+    """Uniform deviates in [0, 1) number `index` (array) of the uniform stream."""
+    idx = np.asarray(index, dtype=np.uint64)
+    seed = np.uint64(seed)
+    o = philox4x32(idx & _MASK, idx >> np.uint64(32), np.zeros_like(idx),
+                   np.full_like(idx, STREAM_UNIFORM), seed & _MASK, seed >> np.uint64(32))
+    return _u53(o[0], o[1])
+
+
+def philox_normal(seed, index):
+    """Standard normal deviates number `index` (array) of the normal stream."""
+    idx = np.asarray(index, dtype=np.uint64).ravel()
+    seed = np.uint64(seed)
+    pair, which = idx >> np.uint64(1), (idx & np.uint64(1)).astype(bool)
+    out = np.empty(idx.shape, dtype=np.float64)
+    todo = np.arange(idx.size)
+    retry = 0
+    while todo.size:
+        p = pair[todo]
+        o = philox4x32(p & _MASK, p >> np.uint64(32), np.full_like(p, retry),
+                       np.full_like(p, STREAM_NORMAL), seed & _MASK, seed >> np.uint64(32))
+        x1 = 2.0 * _u53(o[0], o[1]) - 1.0
+        x2 = 2.0 * _u53(o[2], o[3]) - 1.0
+        r2 = x1 * x1 + x2 * x2
+        ok = (r2 < 1.0) & (r2 > 0.0)
+        with np.errstate(all="ignore"):
+            f = np.sqrt(-2.0 * np.log(r2[ok]) / r2[ok])
+        sel = todo[ok]
+        out[sel] = np.where(which[sel], f * x2[ok], f * x1[ok])
+        todo = todo[~ok]
+        retry += 1
+    return out.reshape(np.shape(index))
+
+
+class PhiloxRandomState(object):
+    """`rstate` object with the call surface the brutus path uses.
+
+    State is two positions (normals consumed, uniforms consumed); `seed` keys
+    the generator.  `normal` consumes `size` normals, `choice` consumes one
+    uniform per drawn sample, exactly in call order -- so a run is reproducible
+    and the consumption of a call can be predicted from its arguments alone.
+    """
+
+    def __init__(self, seed=0, n_normal=0, n_uniform=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.n_normal = int(n_normal)
+        self.n_uniform = int(n_uniform)
+
+    def normal(self, loc=0.0, scale=1.0, size=None):
+        n = 1 if size is None else int(np.prod(size))
+        z = philox_normal(self.seed, np.arange(self.n_normal, self.n_normal + n,
+                                               dtype=np.uint64))
+        self.n_normal += n
+        z = loc + scale * z
+        return float(z[0]) if size is None else z.reshape(size)
+
+    def random_sample(self, size=None):
+        n = 1 if size is None else int(np.prod(size))
+        u = philox_uniform(self.seed, np.arange(self.n_uniform, self.n_uniform + n,
+                                                dtype=np.uint64))
+        self.n_uniform += n
+        return float(u[0]) if size is None else u.reshape(size)
+
+    def choice(self, a, size=None, p=None):
+        """Legacy `RandomState.choice` semantics for an integer `a`, with
+        replacement: `searchsorted(cumsum(p) / sum, uniforms, side='right')`."""
+        a = int(a)
+        if p is None:
+            u = self.random_sample(size)
+            return np.minimum((np.asarray(u) * a).astype(np.int64), a - 1) \
+                if size is not None else min(int(u * a), a - 1)
+        cdf = np.cumsum(np.asarray(p, dtype=np.float64))
+        cdf /= cdf[-1]
+        u = self.random_sample(size)
+        idx = np.searchsorted(cdf, u, side='right')
+        return np.minimum(idx, a - 1) if size is not None else int(min(idx, a - 1))
+
+    def multivariate_normal(self, mean, cov, size=None):
+        mean = np.asarray(mean, dtype=np.float64)
+        n = 1 if size is None else int(np.prod(size))
+        L = np.linalg.cholesky(np.asarray(cov, dtype=np.float64))
+        z = self.normal(size=(n, mean.size))
+        out = mean + z @ L.T
+        return out[0] if size is None else out.reshape(tuple(np.atleast_1d(size)) + (mean.size,))

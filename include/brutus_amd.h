@@ -130,6 +130,62 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
                       int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
                       void *stream);
 
+/* ---- lnpost on the device ------------------------------------------------------
+ * Everything of fitting.lnpost after the first cut (fitting.py:1000-1107) and
+ * the resampling tail of BruteForce._fit (fitting.py:2021-2061), for the
+ * built-in priors: static lnprior + the Galactic model of pdf.gal_lnprior
+ * (pdf.py:476-749; geometry as in brutus_amd/galprior.py) + the parallax
+ * likelihood.  Random numbers follow brutus_amd/rng.py (PhiloxRandomState):
+ * normal j / uniform q are functions of (seed, j) / (seed, q), so the result is
+ * what the reference produces when it is handed that object as `rstate`.
+ *
+ * Input = the device-resident records brutus_fit_batch emitted.  Output per
+ * object s and draw q < ndraws:
+ *   d_out_idx  (nstar, ndraws) i32      resampled model index
+ *   d_out_vals (nstar, ndraws, 17) f64  scale, av, rv, cov_sar[9], lnprob,
+ *                                       dist, red, dred, logwt
+ *   h_star_out (nstar, 4) f64 (host)    levid, chi2min, sum of weights, Nsel
+ *   h_flags    (nstar,) i32 (host)      1 = more than nsel_max models survive the
+ *                                       second cut (fitting.py:1029-1036 would
+ *                                       re-sort them): do this object on the host
+ *   h_nbase (nstar + 1,) u64 (host, optional)  normal-stream position at which
+ *                                       each object starts; [nstar] = after the batch
+ * Object s consumes 3*nmc*min(Nsel_s, nsel_max) normals starting where object
+ * s-1 stopped (first at normal_base) and uniforms
+ * [uniform_base + s*K, uniform_base + (s+1)*K), K = ndraws * (1 + return_distreds). */
+typedef struct brutus_post_params {
+    int32_t nmc, ndraws, return_distreds, has_feh, has_loga;
+    int32_t per_object;   /* 1: object s draws from its own stream keyed
+                             seed + object0 + s, positions from 0 (order- and
+                             sharding-independent); 0: one shared stream */
+    double wt_thresh, avlim[2], rvlim[2];
+    int64_t nsel_max, object0;
+    uint64_t seed, normal_base, uniform_base;
+    double R_solar, Z_solar, R_thin, Z_thin, Rs_thin, R_thick, Z_thick, f_thick, Rs_thick;
+    double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
+    double feh_mean[3], feh_sigma[3];
+    double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+} brutus_post_params;
+
+size_t brutus_post_workspace_bytes(int nstar, int64_t capacity);
+int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                      const double *d_sel_vals, const int64_t *d_sel_off,
+                      const double *d_lnprior, const double *d_feh,
+                      const double *d_loga, const double *d_coords,
+                      const double *d_parallax, const double *d_parallax_err,
+                      const brutus_post_params *params, void *d_workspace,
+                      size_t workspace_bytes, int32_t *d_out_idx,
+                      double *d_out_vals, double *h_star_out, int32_t *h_flags,
+                      uint64_t *h_nbase, void *stream);
+
+/* Test hooks for the two building blocks above. */
+int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
+                     double *d_uniforms, void *stream);
+int brutus_debug_galprior(const brutus_post_params *params, int n,
+                          const double *d_dist, const double *d_coord,
+                          const double *d_feh, const double *d_loga, double *d_out,
+                          void *stream);
+
 /* ---- cluster mode ------------------------------------------------------------
  * Hot block of cluster.isochrone_loglike (cluster.py:336-414): for nobj objects
  * and npts isochrone points (all secondary-mass-fraction slices concatenated,

@@ -1,0 +1,154 @@
+"""GPU: `lnpost` + resampling on the device (brutus_post_batch) against the
+reference semantics.  The random stream is brutus_amd/rng.PhiloxRandomState, a
+valid `rstate` object for the reference/oracle, so the device result is compared
+with the ORACLE run on the same `rstate` -- indices bit-exact."""
+import numpy as np
+import pytest
+
+from helpers import relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_rng_matches_specification():
+    import torch
+    from brutus_amd import _lib
+    from brutus_amd.rng import philox_normal, philox_uniform
+    L = _lib.lib()
+    for seed, start in ((0, 0), (12345, 7), (2 ** 63 + 11, 2 ** 33 + 5)):
+        n = 20001
+        z = torch.empty(n, dtype=torch.float64, device="cuda")
+        u = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(L.brutus_debug_rng(seed, start, n, z.data_ptr(), u.data_ptr(), None))
+        torch.cuda.synchronize()
+        idx = np.arange(start, start + n, dtype=np.uint64)
+        assert np.array_equal(u.cpu().numpy(), philox_uniform(seed, idx))
+        zr = philox_normal(seed, idx)
+        assert np.max(np.abs(z.cpu().numpy() - zr) / np.abs(zr)) < 1e-14
+
+
+def _post_params(**kw):
+    from brutus_amd import _lib
+    from brutus_amd.galprior import device_params
+    pp = _lib.PostParams()
+    for k, v in device_params(**kw).items():
+        if isinstance(v, tuple):
+            getattr(pp, k)[:] = list(v)
+        else:
+            setattr(pp, k, v)
+    pp.has_feh = pp.has_loga = 1
+    return pp
+
+
+def test_device_galprior_matches_host():
+    import torch
+    from brutus_amd import _lib
+    from brutus_amd.galprior import gal_lnprior
+    L = _lib.lib()
+    rng = np.random.RandomState(3)
+    n = 5000
+    d = 10. ** rng.uniform(-2, 1.5, n)
+    lab = np.zeros(n, dtype=[("feh", "f8"), ("loga", "f8")])
+    lab["feh"] = rng.uniform(-3, 0.6, n)
+    lab["loga"] = rng.uniform(7.5, 10.2, n)
+    for coord in ((204.7, -19.2), (0., 90.), (33., 2.)):
+        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        _lib.check(L.brutus_debug_galprior(_post_params(), n, t(d).data_ptr(),
+                                           t(np.array(coord)).data_ptr(),
+                                           t(lab["feh"]).data_ptr(),
+                                           t(lab["loga"]).data_ptr(), out.data_ptr(), None))
+        torch.cuda.synchronize()
+        ref = gal_lnprior(d, coord, labels=lab)
+        assert relerr(ref, out.cpu().numpy()) < 1e-12
+
+
+def _setup(nmodel=6000, nstar=9, seed=31):
+    from brutus_amd import fitting, synth
+    from oracle import brutus_oracle as O
+    models, labels, lmask = synth.make_mist_like_grid(nmodel, 8, seed=seed)
+    st = synth.make_stars(models, nstar, seed=seed + 1)
+    st["mask"][1, 2] = False
+    BF = fitting.BruteForce(models, labels, lmask)
+    lnprior = O.static_lnprior(labels, lmask)
+    return BF, models, labels, st, lnprior
+
+
+NAMES = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds dreds "
+         "logwts").split()
+
+
+def _compare(dev, ref, tag):
+    assert np.array_equal(dev[0], ref[0]), "%s: resampled indices" % (tag,)
+    for n, a, b in zip(NAMES[1:], ref[1:], dev[1:]):
+        assert relerr(a, b) < 1e-8, (tag, n, relerr(a, b))
+
+
+def test_device_lnpost_shared_stream_vs_oracle():
+    """One sequential PhiloxRandomState over all objects, batches of 4."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup()
+    BF.batch_size = 4
+    rs = PhiloxRandomState(2024)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60,
+                       rstate=rs))
+    ro = PhiloxRandomState(2024)
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60)
+        _compare(dev[i], ref, i)
+    # the device advanced the caller's rstate exactly like the host would have
+    assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
+def test_device_lnpost_per_object_and_host_agree():
+    """seed0 + 'philox': per-object streams; the device path, the host path with
+    the same rstate objects and the oracle all agree, for any batching."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nstar=7, seed=41)
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=15,
+              lnprior=lnprior, lngalprior=gal_lnprior, data_coords=st["coords"],
+              Ndraws=40, seed0=500, rstate_per_object="philox")
+    BF.batch_size = 3
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    BF.batch_size = 7
+    dev2 = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    BF.device_lnpost = False
+    host = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    for i in range(7):
+        assert np.array_equal(dev[i][0], dev2[i][0])
+        _compare(dev[i], host[i], "host %d" % i)
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], PhiloxRandomState(500 + i), gal_lnprior,
+                         Nmc_prior=15, Ndraws=40)
+        _compare(dev[i], ref, "oracle %d" % i)
+
+
+def test_device_lnpost_nsel_max_falls_back_to_host():
+    """A tiny mem_lim makes Nsel_max smaller than the second-cut selection:
+    those objects take the host route, on the right stream positions."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nstar=4, seed=51)
+    mem_lim = 20 * 4e-4 * 300          # Nsel_max = 300
+    rs = PhiloxRandomState(9)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=30,
+                       rstate=rs, mem_lim=mem_lim))
+    ro = PhiloxRandomState(9)
+    for i in range(4):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=30,
+                         mem_lim=mem_lim)
+        _compare(dev[i], ref, i)
