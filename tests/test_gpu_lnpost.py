@@ -24,7 +24,11 @@ def test_device_rng_matches_specification():
         idx = np.arange(start, start + n, dtype=np.uint64)
         assert np.array_equal(u.cpu().numpy(), philox_uniform(seed, idx))
         zr = philox_normal(seed, idx)
-        assert np.max(np.abs(z.cpu().numpy() - zr) / np.abs(zr)) < 1e-14
+        # same accept/reject decisions (the uniforms are bit-identical); the
+        # deviates may differ in the last bits of log1p / sqrt (libm vs ocml)
+        zd = z.cpu().numpy()
+        assert np.max(np.abs(zd - zr) / np.abs(zr)) < 2e-15
+        assert np.mean(zd == zr) > 0.7
 
 
 def _post_params(**kw):
@@ -54,10 +58,10 @@ def test_device_galprior_matches_host():
     for coord in ((204.7, -19.2), (0., 90.), (33., 2.)):
         t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
         out = torch.empty(n, dtype=torch.float64, device="cuda")
-        _lib.check(L.brutus_debug_galprior(_post_params(), n, t(d).data_ptr(),
-                                           t(np.array(coord)).data_ptr(),
-                                           t(lab["feh"]).data_ptr(),
-                                           t(lab["loga"]).data_ptr(), out.data_ptr(), None))
+        td, tc, tf, tl = t(d), t(np.array(coord)), t(lab["feh"]), t(lab["loga"])
+        _lib.check(L.brutus_debug_galprior(_post_params(), n, td.data_ptr(),
+                                           tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
+                                           out.data_ptr(), None))
         torch.cuda.synchronize()
         ref = gal_lnprior(d, coord, labels=lab)
         assert relerr(ref, out.cpu().numpy()) < 1e-12
