@@ -122,6 +122,25 @@ def end_to_end(models, grid, stars, n, kw, with_par):
         dt2 = time.perf_counter() - t0
     res["per_object_seeds_pool"] = {"value": n2 / dt2, "unit": "stars/s", "stars": n2,
                                     "host_workers": workers}
+    # lnpost + resampling on the device (built-in priors, counter-based rstate)
+    from brutus_amd.rng import PhiloxRandomState
+    bf.host_workers = 0
+    n3 = len(stars["flux"])
+    bf.batch_size = 64
+    for rep in range(2):          # first pass warms the workspaces
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            bf.fit(stars["flux"][:n3], stars["err"][:n3], stars["mask"][:n3],
+                   np.arange(n3), os.path.join(tmp, "e2e"),
+                   parallax=stars["parallax"][:n3] if with_par else None,
+                   parallax_err=stars["parallax_err"][:n3] if with_par else None,
+                   data_coords=stars["coords"][:n3], lngalprior=gal_lnprior,
+                   rv_gauss=(3.32, 1e-6) if "rvlim" in kw else (3.32, 0.18),
+                   rstate=PhiloxRandomState(862), verbose=False)
+            dt3 = time.perf_counter() - t0
+    res["device_lnpost"] = {"value": n3 / dt3, "unit": "stars/s", "stars": n3,
+                            "note": "same fit() with rstate=PhiloxRandomState: second cut, "
+                                    "MC prior integral and resampling on the GPU"}
     return res
 
 

@@ -30,6 +30,7 @@
 // turns the masked max-step test (fitting.py:246-264) into two plain maxima.
 
 #include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -1622,6 +1623,14 @@ __device__ __forceinline__ void rec_range(const int64_t *__restrict__ off, int s
     if (a > lo + n) a = lo + n;
 }
 
+__device__ __forceinline__ void rec_range_n(int64_t lo, int64_t n, int c, int64_t &a, int64_t &b) {
+    const int64_t ntile = (n + TILE - 1) / TILE;
+    a = lo + (ntile * c / PCH) * TILE;
+    b = lo + (ntile * (c + 1) / PCH) * TILE;
+    if (b > lo + n) b = lo + n;
+    if (a > lo + n) a = lo + n;
+}
+
 // P1: lnp of the MLE point for the second cut (fitting.py:1000-1010)
 __global__ void __launch_bounds__(TILE)
 k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
@@ -1686,7 +1695,8 @@ k_post_count2(double ln_wt, const int64_t *__restrict__ sel_off, const double *_
 // rstate would have consumed), host-fallback flags.
 __global__ void k_post_offsets(PostParams pp, int nstar, const int64_t *__restrict__ counts,
                                int64_t *__restrict__ offsets, int64_t *__restrict__ off2,
-                               uint64_t *__restrict__ nbase, int32_t *__restrict__ flags) {
+                               uint64_t *__restrict__ nbase, int32_t *__restrict__ flags,
+                               int64_t *__restrict__ nsel) {
     __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
     const int s = threadIdx.x;
     int64_t n = 0;
@@ -1704,6 +1714,7 @@ __global__ void k_post_offsets(PostParams pp, int nstar, const int64_t *__restri
             nbase[q] = pp.per_object ? 0ull : nb;
             const int64_t used = m > pp.nsel_max ? pp.nsel_max : m;   // fitting.py:1029-1036
             flags[q] = m > pp.nsel_max ? 1 : 0;
+            nsel[q] = used;
             nb += (uint64_t)(3 * (int64_t)pp.nmc * used);
             run += m;
         }
@@ -1848,14 +1859,15 @@ __device__ __forceinline__ double mc_sample(const PostParams &pp, uint64_t seed,
 __global__ void __launch_bounds__(TILE)
 k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
           const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
-          const int64_t *__restrict__ off2, const uint64_t *__restrict__ nbase,
-          const int32_t *__restrict__ flags, const StarGeom *__restrict__ geom,
-          const double *__restrict__ feh, const double *__restrict__ loga, RecPost rp,
-          double *__restrict__ part_max, double *__restrict__ part_chi2) {
+          const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+          const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
+          const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+          const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
+          double *__restrict__ part_chi2) {
     __shared__ double slot[4];
     const int s = blockIdx.y, c = blockIdx.x;
     int64_t a, b;
-    rec_range(off2, s, c, a, b);
+    rec_range_n(off2[s], nsel[s], c, a, b);
     const StarGeom g = geom[s];
     const uint64_t nb = nbase[s];
     const uint64_t seed = star_seed(pp, s);
@@ -1911,14 +1923,15 @@ k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
 // P5: evidence and the cumulative weights of one object (fitting.py:2033-2038);
 // one workgroup per object, sequential 256-wide scan with carry.
 __global__ void __launch_bounds__(TILE)
-k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int32_t *__restrict__ flags,
-           const double *__restrict__ part_max, const double *__restrict__ part_chi2, RecPost rp,
-           double *__restrict__ cdf, double *__restrict__ star_out) {
+k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+           const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+           const double *__restrict__ part_chi2, RecPost rp, double *__restrict__ cdf,
+           double *__restrict__ star_out) {
     __shared__ double sh[TILE];
     __shared__ double carry;
     const int s = blockIdx.x;
     if (flags[s]) return;
-    const int64_t a = off2[s], b = off2[s + 1];
+    const int64_t a = off2[s], b = off2[s] + nsel[s];
     double mx = -INFINITY, cm = -INFINITY;
     for (int q = 0; q < PCH; ++q) {
         mx = fmax(mx, part_max[(int64_t)s * PCH + q]);
@@ -1967,15 +1980,16 @@ constexpr int POST_NOUT = 17;   // scale av rv cov[9] lnprob dist red dred logwt
 __global__ void __launch_bounds__(64)
 k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ sel_idx,
             const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
-            const int64_t *__restrict__ off2, const uint64_t *__restrict__ nbase,
-            const int32_t *__restrict__ flags, const StarGeom *__restrict__ geom,
-            const double *__restrict__ feh, const double *__restrict__ loga, RecPost rp,
-            const double *__restrict__ cdf, const double *__restrict__ star_out,
-            int32_t *__restrict__ out_idx, double *__restrict__ out_vals) {
+            const int64_t *__restrict__ off2, const int64_t *__restrict__ nselv,
+            const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
+            const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+            const double *__restrict__ loga, RecPost rp, const double *__restrict__ cdf,
+            const double *__restrict__ star_out, int32_t *__restrict__ out_idx,
+            double *__restrict__ out_vals) {
     const int s = blockIdx.y;
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= pp.ndraws || flags[s]) return;
-    const int64_t a = off2[s], nsel = off2[s + 1] - a;
+    const int64_t a = off2[s], nsel = nselv[s];
     if (nsel <= 0) return;
     const StarGeom g = geom[s];
     const uint64_t ub = star_ubase(pp, s);
@@ -2038,6 +2052,19 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     ov[14] = red;
     ov[15] = dred;
     ov[16] = lw;
+}
+
+// Nsel_max clipping (fitting.py:1029-1036): keep the nsel_max largest lnp in
+// DESCENDING order.  Rare; a device radix sort per affected object.
+__global__ void k_iota32(int32_t *p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+template <typename T>
+__global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
+                         const int32_t *__restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
 }
 
 // per-object geometry / parallax constants
@@ -2687,8 +2714,14 @@ struct PostWs {
     int64_t *counts, *offsets, *off2;
     uint64_t *nbase;
     int32_t *flags;
+    int64_t *nsel;
     StarGeom *geom;
     RecPost rp;
+    // Nsel_max path: radix-sort scratch
+    double *sort_keys;
+    int32_t *sort_in, *sort_perm;
+    void *sort_tmp;
+    size_t sort_tmp_bytes;
     size_t bytes;
 };
 
@@ -2711,6 +2744,7 @@ PostWs carve_post(char *base, int nstar, int64_t cap) {
     w.off2 = (int64_t *)take(8 * ((size_t)nstar + 1));
     w.nbase = (uint64_t *)take(8 * ((size_t)nstar + 1));
     w.flags = (int32_t *)take(4 * (size_t)nstar);
+    w.nsel = (int64_t *)take(8 * (size_t)nstar);
     w.geom = (StarGeom *)take(sizeof(StarGeom) * (size_t)nstar);
     w.star_out = (double *)take(8 * 4 * (size_t)nstar);
     w.rp.src = (int32_t *)take(4 * c);
@@ -2718,8 +2752,44 @@ PostWs carve_post(char *base, int nstar, int64_t cap) {
     w.rp.cov = (double *)take(8 * 6 * c);
     w.rp.chol = (double *)take(8 * 6 * c);
     w.cdf = (double *)take(8 * c);
+    w.sort_keys = (double *)take(8 * c);
+    w.sort_in = (int32_t *)take(4 * c);
+    w.sort_perm = (int32_t *)take(4 * c);
+    w.sort_tmp_bytes = 16 * c + (8u << 20);
+    w.sort_tmp = take(w.sort_tmp_bytes);
     w.bytes = off;
     return w;
+}
+
+// Keep the nsel_max best records of object s, best first (fitting.py:1029-1036).
+int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep, hipStream_t st) {
+    const unsigned nb = (unsigned)((n + 255) / 256);
+    hipLaunchKernelGGL(k_iota32, dim3(nb), dim3(256), 0, st, w.sort_in, n);
+    size_t need = 0;
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, w.rp.lnp + a, w.sort_keys,
+                                                         w.sort_in, w.sort_perm, (int)n, 0, 64, st));
+    if (need > w.sort_tmp_bytes)
+        return fail(BRUTUS_ENOMEM, "radix-sort scratch too small (%zu > %zu)", need, w.sort_tmp_bytes);
+    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(w.sort_tmp, need, w.rp.lnp + a, w.sort_keys,
+                                                         w.sort_in, w.sort_perm, (int)n, 0, 64, st));
+    const unsigned kb = (unsigned)((keep + 255) / 256);
+    // permute every per-record array through the (now free) lnp1-sized scratch
+    double *tmp = w.lnp1;
+    auto permute64 = [&](double *arr) -> int {
+        hipLaunchKernelGGL(k_gather<double>, dim3(kb), dim3(256), 0, st, tmp, arr + a, w.sort_perm, keep);
+        HIP_TRY(hipMemcpyAsync(arr + a, tmp, 8 * (size_t)keep, hipMemcpyDeviceToDevice, st));
+        return 0;
+    };
+    if (int rc = permute64(w.rp.lnp)) return rc;
+    for (int q = 0; q < 6; ++q) {
+        if (int rc = permute64(w.rp.cov + (size_t)q * cap)) return rc;
+        if (int rc = permute64(w.rp.chol + (size_t)q * cap)) return rc;
+    }
+    hipLaunchKernelGGL(k_gather<int32_t>, dim3(kb), dim3(256), 0, st, (int32_t *)tmp, w.rp.src + a,
+                       w.sort_perm, keep);
+    HIP_TRY(hipMemcpyAsync(w.rp.src + a, tmp, 4 * (size_t)keep, hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity) {
@@ -2763,23 +2833,40 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
     hipLaunchKernelGGL(k_post_count2, g2, blk, 0, st, log(pp.wt_thresh), d_sel_off, w.lnp1, w.part,
                        w.counts, w.mask);
     hipLaunchKernelGGL(k_post_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, pp, nstar, w.counts,
-                       w.offsets, w.off2, w.nbase, w.flags);
+                       w.offsets, w.off2, w.nbase, w.flags, w.nsel);
     hipLaunchKernelGGL(k_post_scatter2, g2, blk, 0, st, capacity, d_sel_idx, d_sel_vals, d_sel_off,
                        d_lnprior, w.mask, w.offsets, w.rp);
     tm.end();
+    {   // objects with more than nsel_max survivors: sort + clip on the device
+        std::vector<int32_t> hf(nstar);
+        std::vector<int64_t> ho(nstar + 1);
+        HIP_TRY(hipMemcpyAsync(hf.data(), w.flags, 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(ho.data(), w.off2, 8 * ((size_t)nstar + 1), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        bool any = false;
+        for (int s = 0; s < nstar; ++s)
+            if (hf[s]) {
+                any = true;
+                tm.begin("k_post_clip");
+                int rc = clip_to_nsel_max(w, capacity, ho[s], ho[s + 1] - ho[s], pp.nsel_max, st);
+                tm.end();
+                if (rc) return rc;
+            }
+        if (any) HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * (size_t)nstar, st));
+    }
     tm.begin("k_post_mc");
     hipLaunchKernelGGL(k_post_mc, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
-                       w.off2, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.part_max,
+                       w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.part_max,
                        w.part_chi2);
     tm.end();
     tm.begin("k_post_cdf");
-    hipLaunchKernelGGL(k_post_cdf, dim3(nstar), blk, 0, st, nstar, w.off2, w.flags, w.part_max,
-                       w.part_chi2, w.rp, w.cdf, w.star_out);
+    hipLaunchKernelGGL(k_post_cdf, dim3(nstar), blk, 0, st, nstar, w.off2, w.nsel, w.flags,
+                       w.part_max, w.part_chi2, w.rp, w.cdf, w.star_out);
     tm.end();
     tm.begin("k_post_draw");
     hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, nstar), dim3(64), 0, st, pp, nstar,
-                       capacity, d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nbase, w.flags, w.geom,
-                       d_feh, d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
+                       capacity, d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
+                       w.geom, d_feh, d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
     tm.end();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_star_out, w.star_out, 8 * 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));

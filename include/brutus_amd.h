@@ -145,9 +145,12 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
  *   d_out_vals (nstar, ndraws, 17) f64  scale, av, rv, cov_sar[9], lnprob,
  *                                       dist, red, dred, logwt
  *   h_star_out (nstar, 4) f64 (host)    levid, chi2min, sum of weights, Nsel
- *   h_flags    (nstar,) i32 (host)      1 = more than nsel_max models survive the
- *                                       second cut (fitting.py:1029-1036 would
- *                                       re-sort them): do this object on the host
+ *   h_flags    (nstar,) i32 (host)      0; an object with more than nsel_max
+ *                                       survivors of the second cut is clipped to
+ *                                       the nsel_max best, best first, by a device
+ *                                       radix sort (fitting.py:1029-1036); a
+ *                                       non-zero flag asks the caller to redo that
+ *                                       object on the host (not used at present)
  *   h_nbase (nstar + 1,) u64 (host, optional)  normal-stream position at which
  *                                       each object starts; [nstar] = after the batch
  * Object s consumes 3*nmc*min(Nsel_s, nsel_max) normals starting where object

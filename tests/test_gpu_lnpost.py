@@ -136,9 +136,10 @@ def test_device_lnpost_per_object_and_host_agree():
         _compare(dev[i], ref, "oracle %d" % i)
 
 
-def test_device_lnpost_nsel_max_falls_back_to_host():
+def test_device_lnpost_nsel_max_clip():
     """A tiny mem_lim makes Nsel_max smaller than the second-cut selection:
-    those objects take the host route, on the right stream positions."""
+    those objects are clipped to the Nsel_max best, best first, by a device
+    sort (fitting.py:1029-1036) and still match the oracle."""
     from brutus_amd.galprior import gal_lnprior
     from brutus_amd.rng import PhiloxRandomState
     from oracle import brutus_oracle as O
