@@ -1525,6 +1525,8 @@ struct PostParams {     // mirrors brutus_post_params
     double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
     double feh_mean[3], feh_sigma[3];
     double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+    // derived on the host side of the ABI call (not part of brutus_post_params)
+    double ln_f_thick, ln_f_halo, reff_solar;
 };
 
 // stream key and uniform base of object s: one shared sequential stream, or
@@ -1550,59 +1552,64 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
     return log(exp(a - m) + exp(b - m) + exp(c - m)) + m;
 }
 
-// per-model metallicity / age terms of the three components (pdf.py:380-473)
+// per-model metallicity / age densities of the three components (pdf.py:380-473),
+// as plain (not log) values: e^F_c, e^A_c
 __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, double loga,
                                             double (&Fc)[3], double (&Ac)[3]) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-        Fc[c] = 0.;
-        Ac[c] = 0.;
+        Fc[c] = 1.;
+        Ac[c] = 1.;
         if (pp.has_feh) {
             const double d = pp.feh_mean[c] - feh;
-            Fc[c] = -0.5 * (d * d / (pp.feh_sigma[c] * pp.feh_sigma[c]) +
-                            log(2. * M_PI * pp.feh_sigma[c] * pp.feh_sigma[c]));
+            Fc[c] = exp(-0.5 * (d * d / (pp.feh_sigma[c] * pp.feh_sigma[c]) +
+                                log(2. * M_PI * pp.feh_sigma[c] * pp.feh_sigma[c])));
         }
         if (pp.has_loga) {
             const double age = exp10(loga) / 1e9;
             const double xi = (age - pp.age_mean[c]) / pp.age_sigma[c];
             Ac[c] = (age < pp.min_age || age > pp.max_age)
-                        ? -INFINITY
-                        : -0.91893853320467274178 - 0.5 * xi * xi - pp.age_lnnorm[c];
+                        ? 0.
+                        : exp(-0.91893853320467274178 - 0.5 * xi * xi - pp.age_lnnorm[c]);
         }
     }
 }
 
-// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc]
+// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc].
+// With w_c = exp(comp_c - m) the three log-sum-exps of the reference collapse:
+//   lse(comp) + [lse(F + comp) - lse(comp)] + [lse(A + comp) - lse(comp)]
+//     = m + log( (sum w_c e^F_c) (sum w_c e^A_c) / sum w_c )
+// so a sample costs 4 exp + 2 log instead of 10 + 4; EF_c = e^F_c, EA_c = e^A_c
+// are per-model constants.
 __device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const StarGeom &g, double d,
-                                                  const double (&Fc)[3], const double (&Ac)[3]) {
-    const double vol = 2. * log(d + 1e-300);
+                                                  const double (&EF)[3], const double (&EA)[3]) {
     const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
     const double R2 = x * x + y * y;
     const double aZ = fabs(Z), aZs = fabs(pp.Z_solar);
     double comp[3];
     comp[0] = -((sqrt(R2 + pp.Rs_thin * pp.Rs_thin) - pp.R_solar) / pp.R_thin +
-                (aZ - aZs) / pp.Z_thin) + vol;
+                (aZ - aZs) / pp.Z_thin);
     comp[1] = -((sqrt(R2 + pp.Rs_thick * pp.Rs_thick) - pp.R_solar) / pp.R_thick +
-                (aZ - aZs) / pp.Z_thick) + vol + log(pp.f_thick);
+                (aZ - aZs) / pp.Z_thick) + pp.ln_f_thick;
     {
         const double rq2 = pp.r_q_halo * pp.r_q_halo;
         const double q = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
                                              exp(1. - sqrt(R2 + Z * Z + rq2) / pp.r_q_halo);
         const double reff = sqrt(R2 + (Z / q) * (Z / q) + pp.Rs_halo * pp.Rs_halo);
-        const double Rs2 = pp.R_solar * pp.R_solar, Zs = pp.Z_solar;
-        const double qs = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
-                                              exp(1. - sqrt(Rs2 + Zs * Zs + rq2) / pp.r_q_halo);
-        const double reff_s = sqrt(Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
-        comp[2] = -pp.eta_halo * log(reff / reff_s) + vol + log(pp.f_halo);
+        comp[2] = -pp.eta_halo * log(reff / pp.reff_solar) + pp.ln_f_halo;
     }
-    const double base = lse3(comp[0], comp[1], comp[2]);
-    double out = base;
-    // lse_c(F_c + comp_c - base) etc.: membership-weighted label priors
-    if (pp.has_feh)
-        out += lse3(Fc[0] + (comp[0] - base), Fc[1] + (comp[1] - base), Fc[2] + (comp[2] - base));
-    if (pp.has_loga)
-        out += lse3(Ac[0] + (comp[0] - base), Ac[1] + (comp[1] - base), Ac[2] + (comp[2] - base));
-    return out;
+    double m = comp[0] > comp[1] ? comp[0] : comp[1];
+    m = comp[2] > m ? comp[2] : m;
+    const double w0 = exp(comp[0] - m), w1 = exp(comp[1] - m), w2 = exp(comp[2] - m);
+    double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
+    if (pp.has_feh) num *= w0 * EF[0] + w1 * EF[1] + w2 * EF[2];
+    if (pp.has_loga) num *= w0 * EA[0] + w1 * EA[1] + w2 * EA[2];
+    const double S = w0 + w1 + w2;
+    const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
+    // divide by S^(npow - 1): one S stays for lse(comp) itself
+    if (npow == 2) num /= S;
+    else if (npow == 0) num *= S;
+    return m + log(num);
 }
 
 constexpr int PCH = 64;      // chunks per object for the record passes
@@ -1826,18 +1833,39 @@ k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const double *
     }
 }
 
+// Sequential reader of normals j0, j0+1, ...: each Philox pair is generated once.
+struct NormalReader {
+    uint64_t seed, p;
+    double z0, z1;
+    bool have;
+    __device__ __forceinline__ void init(uint64_t seed_) {
+        seed = seed_;
+        have = false;
+        p = 0;
+    }
+    __device__ __forceinline__ double at(uint64_t j) {
+        const uint64_t q = j >> 1;
+        if (!have || q != p) {
+            rng_normal_pair(seed, q, z0, z1);
+            p = q;
+            have = true;
+        }
+        return (j & 1) ? z1 : z0;
+    }
+};
+
 // One Monte Carlo sample t of kept record `o` of object s (fitting.py:1071-1093):
 // returns lnp_mc and the sample (dist, av, rv).  n = rank of the record in the
 // object's list: its normals sit at nbase + (3 n + k) nmc + t (utils.py:897).
-__device__ __forceinline__ double mc_sample(const PostParams &pp, uint64_t seed, const StarGeom &g,
-                                            uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
+__device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (&rd)[3],
+                                            const StarGeom &g, uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
                                             const double (&L)[6], const double (&Fc)[3],
                                             const double (&Ac)[3], double &dist, double &a_mc,
                                             double &r_mc, bool &inb) {
     const uint64_t j0 = nb + (uint64_t)((3 * n) * (int64_t)pp.nmc + t);
-    const double z0 = rng_normal(seed, j0);
-    const double z1 = rng_normal(seed, j0 + (uint64_t)pp.nmc);
-    const double z2 = rng_normal(seed, j0 + 2ull * (uint64_t)pp.nmc);
+    const double z0 = rd[0].at(j0);
+    const double z1 = rd[1].at(j0 + (uint64_t)pp.nmc);
+    const double z2 = rd[2].at(j0 + 2ull * (uint64_t)pp.nmc);
     const double s_mc = s0 + L[0] * z0;
     a_mc = a0 + (L[1] * z0 + L[2] * z1);
     r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
@@ -1887,10 +1915,12 @@ k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
                 const int64_t n = o - off2[s];
                 double m = -INFINITY, acc = 0.;
                 int ninb = 0;
+                NormalReader rd[3];
+                rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
                 for (int t = 0; t < pp.nmc; ++t) {
                     double d_, a_, r_;
                     bool inb;
-                    const double v = mc_sample(pp, seed, g, nb, n, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb);
+                    const double v = mc_sample(pp, rd, g, nb, n, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb);
                     if (inb) ++ninb;
                     if (v == v) {                       // logsumexp ignores nothing; NaN poisons
                         if (v > m) {
@@ -2028,22 +2058,24 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     const uint64_t nb = nbase[s];
     double m = -INFINITY;
     bool inb_;
+    NormalReader rd[3];
+    rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        const double v = mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
         if (v > m) m = v;
     }
     double z = 0.;
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        z += exp(mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_) - m);
+        z += exp(mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_) - m);
     }
     // wt = softmax(logwts); imc = searchsorted(cumsum(wt) / sum, u2, side='right')
     const double u2 = rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
     double run = 0., dist = 0., red = 0., dred = 0., lw = 0.;
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        const double v = mc_sample(pp, seed, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
         run += exp(v - m);
         dist = d_; red = a_; dred = r_; lw = v;
         if (run / z > u2) break;          // first cumulative weight above u2
@@ -2792,6 +2824,16 @@ int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep,
     return 0;
 }
 
+void fill_post_params(PostParams &pp, const brutus_post_params *params) {
+    memcpy(&pp, params, sizeof(brutus_post_params));
+    pp.ln_f_thick = log(pp.f_thick);
+    pp.ln_f_halo = log(pp.f_halo);
+    const double rq2 = pp.r_q_halo * pp.r_q_halo, Rs2 = pp.R_solar * pp.R_solar, Zs = pp.Z_solar;
+    const double qs = pp.q_halo_inf -
+                      (pp.q_halo_inf - pp.q_halo_ctr) * exp(1. - sqrt(Rs2 + Zs * Zs + rq2) / pp.r_q_halo);
+    pp.reff_solar = sqrt(Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
+}
+
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity) {
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1) return 0;
     return carve_post(nullptr, nstar, capacity).bytes;
@@ -2804,7 +2846,8 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                       const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
                       int32_t *h_flags, uint64_t *h_nbase, void *stream) {
-    static_assert(sizeof(PostParams) == sizeof(brutus_post_params), "post params layout");
+    static_assert(sizeof(PostParams) == sizeof(brutus_post_params) + 3 * sizeof(double),
+                  "post params layout");
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1)
         return fail(BRUTUS_EINVAL, "bad post dimensions");
     if (!d_sel_idx || !d_sel_vals || !d_sel_off || !d_lnprior || !d_coords || !params ||
@@ -2819,7 +2862,7 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         return fail(BRUTUS_ENOMEM, "post workspace too small: need %zu bytes, got %zu", w.bytes,
                     workspace_bytes);
     PostParams pp;
-    memcpy(&pp, params, sizeof(pp));
+    fill_post_params(pp, params);
     hipStream_t st = (hipStream_t)stream;
     Timer tm(st);
     const dim3 g2(PCH, nstar), blk(TILE);
@@ -2893,7 +2936,7 @@ int brutus_debug_galprior(const brutus_post_params *params, int n, const double 
     if (!params || !d_dist || !d_coord || !d_feh || !d_loga || !d_out || n <= 0)
         return fail(BRUTUS_EINVAL, "bad arguments");
     PostParams pp;
-    memcpy(&pp, params, sizeof(pp));
+    fill_post_params(pp, params);
     hipLaunchKernelGGL(k_debug_galprior, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream,
                        pp, n, d_dist, d_coord, d_feh, d_loga, d_out);
     HIP_TRY(hipGetLastError());
