@@ -125,16 +125,17 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     # lnpost + resampling on the device (built-in priors, counter-based rstate)
     from brutus_amd.rng import PhiloxRandomState
     bf.host_workers = 0
-    n3 = len(stars["flux"])
+    n3 = 1024
+    big = synth.make_stars(models, n3, seed=4242, with_parallax=with_par)
     bf.batch_size = 64
     for rep in range(2):          # first pass warms the workspaces
         with tempfile.TemporaryDirectory() as tmp:
             t0 = time.perf_counter()
-            bf.fit(stars["flux"][:n3], stars["err"][:n3], stars["mask"][:n3],
+            bf.fit(big["flux"], big["err"], big["mask"],
                    np.arange(n3), os.path.join(tmp, "e2e"),
-                   parallax=stars["parallax"][:n3] if with_par else None,
-                   parallax_err=stars["parallax_err"][:n3] if with_par else None,
-                   data_coords=stars["coords"][:n3], lngalprior=gal_lnprior,
+                   parallax=big["parallax"] if with_par else None,
+                   parallax_err=big["parallax_err"] if with_par else None,
+                   data_coords=big["coords"], lngalprior=gal_lnprior,
                    rv_gauss=(3.32, 1e-6) if "rvlim" in kw else (3.32, 0.18),
                    rstate=PhiloxRandomState(862), verbose=False)
             dt3 = time.perf_counter() - t0

@@ -649,6 +649,7 @@ class BruteForce(object):
         self.NLABELS = len(models_labels[0])
         self._grid = None
         self._engine_obj = None
+        self._engine_for = None
         #: stars per device batch (None = sized from the memory budget)
         self.batch_size = None
         #: run `lnpost` + resampling on the device when the priors are the
@@ -660,10 +661,11 @@ class BruteForce(object):
 
     # -- device state -------------------------------------------------------
     def _engine(self):
-        if self._engine_obj is None:
+        if self._engine_obj is None or self._engine_for != self.batch_size:
             if self._grid is None:
                 self._grid = DeviceGrid(self.models)
             self._engine_obj = _Engine(self._grid, max_batch=self.batch_size)
+            self._engine_for = self.batch_size
         return self._engine_obj
 
     def use_device_grid(self, grid):
