@@ -74,15 +74,19 @@ def gather_rows(local_rows, dst=0):
 
 
 def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
-                seed0=0, **fit_kwargs):
+                seed0=0, rng="philox", **fit_kwargs):
     """`BruteForce.fit` over all ranks of the default process group.
 
     Every rank fits the contiguous shard `shard_range(Ndata, rank, world)` on
     its own GPU (no collective on the data path); rank 0 gathers the per-object
     rows in rank order and writes `{save_file}.h5` in the reference layout.
-    Object `i` draws from `RandomState(seed0 + i)`, so the file is identical
-    for any number of ranks (the reference's single sequential stream,
-    fitting.py:2039-2053, would make results depend on the sharding).
+    Object `i` draws from its own stream keyed `seed0 + i`, so the file is
+    identical for any number of ranks (the reference's single sequential
+    stream, fitting.py:2039-2053, would make results depend on the sharding):
+    `rng="philox"` (default) uses `rng.PhiloxRandomState(seed0 + i)`, which
+    lets `lnpost` run on the GPU for the built-in priors; `rng="numpy"` uses
+    `numpy.random.RandomState(seed0 + i)` and the host stage (optionally
+    spread over `bf.host_workers` processes).
 
     `fit_kwargs` are `BruteForce.fit` keyword arguments.  Returns the number of
     objects this rank fitted.
@@ -123,7 +127,8 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         lnprior=lnprior, lngalprior=lngalprior, lndustprior=lndustprior,
         av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[lo:hi],
         Ndraws=Ndraws, return_distreds=save_dar_draws,
-        seed0=seed0 + lo, **fkw))
+        seed0=seed0 + lo,
+        rstate_per_object="philox" if rng == "philox" else None, **fkw))
     allrows = gather_rows(rows, dst=0)
     if rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,

@@ -44,7 +44,7 @@ def _worker(rank, world, port, tmp):
 
     class Stub(fitting.BruteForce):
         def _fit(self, data, data_err, data_mask, parallax=None, Ndraws=250,
-                 seed0=None, return_distreds=True, **kw):
+                 seed0=None, return_distreds=True, rstate_per_object=None, **kw):
             for i in range(data.shape[0]):
                 rs = np.random.RandomState(seed0 + i)
                 idx = rs.randint(0, 64, size=Ndraws)
