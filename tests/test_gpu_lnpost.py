@@ -157,3 +157,32 @@ def test_device_lnpost_nsel_max_clip():
                          st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=30,
                          mem_lim=mem_lim)
         _compare(dev[i], ref, i)
+
+
+def test_device_lnpost_vs_reference_golden():
+    """tests/golden/fit_philox.npz: the UPSTREAM `_fit` run with
+    `rstate=PhiloxRandomState(31337)` and `lngalprior=brutus_amd.galprior.
+    gal_lnprior` (tools/gen_golden.py).  The device lnpost must reproduce it:
+    indices bit-exact, floats <=1e-5, and leave the rstate where the reference
+    left it."""
+    import os
+    from helpers import GOLDEN
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    z = np.load(os.path.join(GOLDEN, "fit_philox.npz"))
+    models, labels, lmask = synth.make_mist_like_grid(int(z["grid_nmodel"]),
+                                                      int(z["grid_nfilt"]),
+                                                      seed=int(z["grid_seed"]))
+    BF = fitting.BruteForce(models, labels, lmask)
+    BF.batch_size = 3
+    rs = PhiloxRandomState(int(z["seed"]))
+    outs = list(BF._fit(z["flux"], z["err"], z["mask"], parallax=z["parallax"],
+                        parallax_err=z["parallax_err"], Nmc_prior=25,
+                        lnprior=z["lnprior"], lngalprior=gal_lnprior,
+                        data_coords=z["coords"], rstate=rs, Ndraws=80))
+    for i, out in enumerate(outs):
+        assert np.array_equal(out[0], z["sidxs"][i]), i
+        for n, got in zip(NAMES[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
+    assert (rs.n_normal, rs.n_uniform) == (int(z["n_normal"]), int(z["n_uniform"]))

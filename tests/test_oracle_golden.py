@@ -107,3 +107,26 @@ def test_fit_orion_catalogue_matches_reference():
         assert np.array_equal(out[0], z["sidxs"][i]), i
         for n, got in zip(names[1:], out[1:]):
             assert relerr(z[n][i], got) < 1e-8, (i, n)
+
+
+def test_fit_with_philox_rstate_matches_reference():
+    """The counter-based rstate (brutus_amd.rng) through the oracle against the
+    upstream run with the same object (tests/golden/fit_philox.npz)."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    z = np.load(os.path.join(GOLDEN, "fit_philox.npz"))
+    models, labels, lmask = synth.make_mist_like_grid(int(z["grid_nmodel"]),
+                                                      int(z["grid_nfilt"]),
+                                                      seed=int(z["grid_seed"]))
+    rs = PhiloxRandomState(int(z["seed"]))
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(z["flux"])):
+        out = O.fit_star(z["flux"][i], z["err"][i], z["mask"][i], models,
+                         z["lnprior"], labels, z["coords"][i], z["parallax"][i],
+                         z["parallax_err"][i], rs, gal_lnprior, Nmc_prior=25,
+                         Ndraws=80)
+        assert np.array_equal(out[0], z["sidxs"][i]), i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-8, (i, n)
+    assert (rs.n_normal, rs.n_uniform) == (int(z["n_normal"]), int(z["n_uniform"]))

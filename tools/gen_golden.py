@@ -344,6 +344,45 @@ def gen_orion():
                         **{k: np.array(v) for k, v in res.items()})
 
 
+def gen_fit_philox():
+    """The REFERENCE's `_fit` driven by `brutus_amd.rng.PhiloxRandomState` (a
+    valid `rstate` object: it has the `normal` / `choice` methods the reference
+    calls) and by `brutus_amd.galprior.gal_lnprior` as the `lngalprior` hook:
+    the pin for the device-side lnpost (brutus_post_batch).  One shared
+    sequential stream over all objects."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    models, labels, lmask = synth.make_mist_like_grid(3000, 8, seed=61)
+    st = synth.make_stars(models, 8, seed=62)
+    st['mask'][2, 1] = False
+    st['parallax'][5] = np.nan
+    st['parallax_err'][5] = np.nan
+    BF = F.BruteForce(models.astype(np.float64), labels, lmask)
+    sp = BF._setup(st['flux'].copy(), st['err'].copy(), st['mask'].copy(), None,
+                   data_coords=st['coords'], lngalprior=gal_lnprior,
+                   parallax=st['parallax'], parallax_err=st['parallax_err'])
+    lnprior = sp[5]
+    rs = PhiloxRandomState(31337)
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    res = {}
+    gen = BF._fit(st['flux'].copy(), st['err'].copy(), st['mask'].copy(),
+                  parallax=st['parallax'], parallax_err=st['parallax_err'],
+                  Nmc_prior=25, lnprior=lnprior.copy(), lngalprior=gal_lnprior,
+                  data_coords=st['coords'], rstate=rs, Ndraws=80)
+    for i, r in enumerate(gen):
+        for n, v in zip(names, r):
+            res.setdefault(n, []).append(np.asarray(v))
+        print("philox fit star", i, "levid", r[7])
+    np.savez_compressed(os.path.join(OUT, "fit_philox.npz"), grid_nmodel=3000,
+                        grid_nfilt=8, grid_seed=61, flux=st['flux'], err=st['err'],
+                        mask=st['mask'], parallax=st['parallax'],
+                        parallax_err=st['parallax_err'], coords=st['coords'],
+                        lnprior=lnprior, seed=31337, n_normal=rs.n_normal,
+                        n_uniform=rs.n_uniform,
+                        **{k: np.array(v) for k, v in res.items()})
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
@@ -352,6 +391,8 @@ if __name__ == "__main__":
         gen_cluster()
     if "orion" in which:
         gen_orion()
+    if "philox" in which:
+        gen_fit_philox()
     if "galprior" in which:
         gen_galprior_pieces()
     if "helpers" in which:
