@@ -80,6 +80,7 @@ SIGNATURES = {
     "brutus_enable_timing": (None, [C.c_int]),
     "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "brutus_debug_math": (C.c_int, [_i32, _vp, _vp, _i64, _vp]),
     "brutus_post_workspace_bytes": (_sz, [_i32, _i64]),
     "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,

@@ -474,6 +474,53 @@ __device__ __forceinline__ void stage_exp_table(double *lds_tbl) {
     if (threadIdx.x < 64) lds_tbl[threadIdx.x] = kExp2Tbl[threadIdx.x];
 }
 
+// e^x with the same table: n = rint(64 x / ln 2), r = x - n ln2/64 (two-term
+// Cody-Waite), degree-5 polynomial; ~13 f64 ops, <= 1 ulp + table rounding.
+__device__ __forceinline__ double fast_exp(double x, const double *__restrict__ tbl = kExp2Tbl) {
+    if (!(x > -745.)) return x == x ? 0. : x;        // underflow / -inf / NaN
+    const double n = rint(x * 92.332482616893657);   // 64 / ln 2
+    double r = fma(-n, 0.01083042469326756, x);      // ln2/64 head, 32 significant bits: n*hi exact
+    r = fma(-n, 2.9815858269852933e-12, r);
+    double pl = 8.3333333333333332e-03;
+    pl = fma(pl, r, 4.1666666666666664e-02);
+    pl = fma(pl, r, 1.6666666666666666e-01);
+    pl = fma(pl, r, 0.5);
+    pl = fma(pl, r, 1.0);
+    pl = fma(pl, r, 1.0);
+    const int ni = (int)n;
+    return ldexp(tbl[ni & 63] * pl, ni >> 6);
+}
+
+// ln x for finite x > 0: x = 2^e m, m in [sqrt(1/2), sqrt 2); ln m = 2 atanh(s),
+// s = (m - 1)/(m + 1), |s| <= 0.1716, odd series to s^21; ~30 f64 ops (ocml: ~98),
+// <= 1 ulp, well conditioned at x -> 1 (m - 1 is exact).
+__device__ __forceinline__ double fast_log(double x) {
+    if (!(x > 0.) || !(x < INFINITY)) return log(x);          // 0, negative, inf, NaN: ocml semantics
+    int e;
+    double m = frexp(x, &e);                                   // m in [0.5, 1)
+    if (m < 0.70710678118654752440) {
+        m *= 2.;
+        --e;
+    }
+    const double s = (m - 1.) / (m + 1.);
+    const double z = s * s;
+    double pl = 1. / 21.;
+    pl = fma(pl, z, 1. / 19.);
+    pl = fma(pl, z, 1. / 17.);
+    pl = fma(pl, z, 1. / 15.);
+    pl = fma(pl, z, 1. / 13.);
+    pl = fma(pl, z, 1. / 11.);
+    pl = fma(pl, z, 1. / 9.);
+    pl = fma(pl, z, 1. / 7.);
+    pl = fma(pl, z, 1. / 5.);
+    pl = fma(pl, z, 1. / 3.);
+    // ln m = 2 s + 2 s z pl ; ln x = e ln2_hi + (e ln2_lo + ln m)
+    const double lm = fma(2. * s * z, pl, 2. * s);
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+}
+
+
 __global__ void k_relayout(const float *__restrict__ aos, int64_t nmodel, int nfilt, int nb,
                            int64_t nmodel_pad, float *__restrict__ blob) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -726,6 +773,11 @@ __global__ void k_calib_stream(const float *__restrict__ in, double *__restrict_
 __global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = fast_exp10(x[i]);
+}
+__global__ void k_debug_math(int which, const double *__restrict__ x, double *__restrict__ y,
+                             int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) y[i] = which == 1 ? fast_exp(x[i]) : which == 2 ? fast_log(x[i]) : fast_exp10(x[i]);
 }
 
 __global__ void k_set_i32(int32_t *p, int n, int32_t v) {
@@ -1503,7 +1555,7 @@ __device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, doubl
         const double x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
         const double r2 = x1 * x1 + x2 * x2;
         if (r2 < 1.0 && r2 > 0.0) {
-            const double f = sqrt(-2.0 * log1p(r2 - 1.0) / r2);   // rng.py: well conditioned near 1
+            const double f = sqrt(-2.0 * fast_log(r2) / r2);   // rng.py: ln(r2), <= 1 ulp
             z0 = f * x1;
             z1 = f * x2;
             return;
@@ -1582,7 +1634,8 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
 // so a sample costs 4 exp + 2 log instead of 10 + 4; EF_c = e^F_c, EA_c = e^A_c
 // are per-model constants.
 __device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const StarGeom &g, double d,
-                                                  const double (&EF)[3], const double (&EA)[3]) {
+                                                  const double (&EF)[3], const double (&EA)[3],
+                                                  const double *__restrict__ tbl) {
     const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
     const double R2 = x * x + y * y;
     const double aZ = fabs(Z), aZs = fabs(pp.Z_solar);
@@ -1594,13 +1647,14 @@ __device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const St
     {
         const double rq2 = pp.r_q_halo * pp.r_q_halo;
         const double q = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
-                                             exp(1. - sqrt(R2 + Z * Z + rq2) / pp.r_q_halo);
+                                             fast_exp(1. - sqrt(R2 + Z * Z + rq2) / pp.r_q_halo, tbl);
         const double reff = sqrt(R2 + (Z / q) * (Z / q) + pp.Rs_halo * pp.Rs_halo);
-        comp[2] = -pp.eta_halo * log(reff / pp.reff_solar) + pp.ln_f_halo;
+        comp[2] = -pp.eta_halo * fast_log(reff / pp.reff_solar) + pp.ln_f_halo;
     }
     double m = comp[0] > comp[1] ? comp[0] : comp[1];
     m = comp[2] > m ? comp[2] : m;
-    const double w0 = exp(comp[0] - m), w1 = exp(comp[1] - m), w2 = exp(comp[2] - m);
+    const double w0 = fast_exp(comp[0] - m, tbl), w1 = fast_exp(comp[1] - m, tbl),
+                 w2 = fast_exp(comp[2] - m, tbl);
     double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
     if (pp.has_feh) num *= w0 * EF[0] + w1 * EF[1] + w2 * EF[2];
     if (pp.has_loga) num *= w0 * EA[0] + w1 * EA[1] + w2 * EA[2];
@@ -1609,7 +1663,7 @@ __device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const St
     // divide by S^(npow - 1): one S stays for lse(comp) itself
     if (npow == 2) num /= S;
     else if (npow == 0) num *= S;
-    return m + log(num);
+    return m + fast_log(num);
 }
 
 constexpr int PCH = 64;      // chunks per object for the record passes
@@ -1646,6 +1700,9 @@ k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
             const double *__restrict__ feh, const double *__restrict__ loga,
             double *__restrict__ lnp1, double *__restrict__ part) {
     __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int s = blockIdx.y, c = blockIdx.x;
     int64_t a, b;
     rec_range(sel_off, s, c, a, b);
@@ -1658,7 +1715,7 @@ k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
             double Fc[3], Ac[3];
             label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
             const double scale = sel_vals[2 * cap + r];
-            const double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, 1. / sqrt(scale), Fc, Ac);
+            const double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, 1. / sqrt(scale), Fc, Ac, s_tbl);
             lnp1[r] = v;
             if (v > m) m = v;
         }
@@ -1860,8 +1917,8 @@ struct NormalReader {
 __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (&rd)[3],
                                             const StarGeom &g, uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
                                             const double (&L)[6], const double (&Fc)[3],
-                                            const double (&Ac)[3], double &dist, double &a_mc,
-                                            double &r_mc, bool &inb) {
+                                            const double (&Ac)[3], const double *__restrict__ tbl,
+                                            double &dist, double &a_mc, double &r_mc, bool &inb) {
     const uint64_t j0 = nb + (uint64_t)((3 * n) * (int64_t)pp.nmc + t);
     const double z0 = rd[0].at(j0);
     const double z1 = rd[1].at(j0 + (uint64_t)pp.nmc);
@@ -1871,7 +1928,7 @@ __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (
     r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
     const double par = sqrt(s_mc);
     dist = 1. / par;
-    double v = gal_lnprior_dev(pp, g, dist, Fc, Ac);
+    double v = gal_lnprior_dev(pp, g, dist, Fc, Ac, tbl);
     if (g.has_par) {                                            // pdf.py:166-173
         const double dp = par - g.par;
         v += -0.5 * (dp * dp * g.par_ivar + g.par_lnorm);
@@ -1893,6 +1950,9 @@ k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
           const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
           double *__restrict__ part_chi2) {
     __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int s = blockIdx.y, c = blockIdx.x;
     int64_t a, b;
     rec_range_n(off2[s], nsel[s], c, a, b);
@@ -1920,14 +1980,14 @@ k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
                 for (int t = 0; t < pp.nmc; ++t) {
                     double d_, a_, r_;
                     bool inb;
-                    const double v = mc_sample(pp, rd, g, nb, n, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb);
+                    const double v = mc_sample(pp, rd, g, nb, n, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb);
                     if (inb) ++ninb;
                     if (v == v) {                       // logsumexp ignores nothing; NaN poisons
                         if (v > m) {
-                            acc = acc * exp(m - v) + 1.;
+                            acc = acc * fast_exp(m - v, s_tbl) + 1.;
                             m = v;
                         } else if (v > -INFINITY) {
-                            acc += exp(v - m);
+                            acc += fast_exp(v - m, s_tbl);
                         }
                     } else {
                         acc = nan("");
@@ -2016,6 +2076,9 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
             const double *__restrict__ loga, RecPost rp, const double *__restrict__ cdf,
             const double *__restrict__ star_out, int32_t *__restrict__ out_idx,
             double *__restrict__ out_vals) {
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int s = blockIdx.y;
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= pp.ndraws || flags[s]) return;
@@ -2062,20 +2125,20 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);
         if (v > m) m = v;
     }
     double z = 0.;
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        z += exp(mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_) - m);
+        z += exp(mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_) - m);
     }
     // wt = softmax(logwts); imc = searchsorted(cumsum(wt) / sum, u2, side='right')
     const double u2 = rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
     double run = 0., dist = 0., red = 0., dred = 0., lw = 0.;
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
-        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, d_, a_, r_, inb_);
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);
         run += exp(v - m);
         dist = d_; red = a_; dred = r_; lw = v;
         if (run / z > u2) break;          // first cumulative weight above u2
@@ -2139,7 +2202,7 @@ __global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict_
     g.has_par = 0;
     double Fc[3], Ac[3];
     label_terms(pp, feh[i], loga[i], Fc, Ac);
-    out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac);
+    out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac, kExp2Tbl);
 }
 
 // ---------------------------------------------------------------------------
@@ -2954,6 +3017,14 @@ int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream) 
     if (!d_x || !d_y || n <= 0) return fail(BRUTUS_EINVAL, "bad arguments");
     hipLaunchKernelGGL(k_debug_exp10, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, d_x, d_y, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n, void *stream) {
+    if (!d_x || !d_y || n <= 0 || which < 0 || which > 2) return fail(BRUTUS_EINVAL, "bad arguments");
+    hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, which, d_x, d_y, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

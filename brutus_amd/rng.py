@@ -12,7 +12,8 @@ q-th uniform are pure functions of `(seed, j)` / `(seed, q)`:
     uniform   u = ((w0 >> 5) * 2**26 + (w1 >> 6)) / 2**53       (numpy's 53-bit recipe)
     normals   pair p = j >> 1: Marsaglia polar method on (u1, u2) of counter
               (p, retry), retry = 0, 1, ... until 0 < x1^2 + x2^2 < 1;
-              normal j is f*x1 (j even) or f*x2 (j odd), f = sqrt(-2 log1p(r2 - 1) / r2)
+              normal j is f*x1 (j even) or f*x2 (j odd), f = sqrt(-2 ln(r2) / r2);
+              r2 = x1*x1 + x2*x2 rounded without fused multiply-add
 
 Because any deviate can be computed without the ones before it, the device can
 evaluate the Monte Carlo integral of every selected model of every object in
@@ -78,9 +79,7 @@ def philox_normal(seed, index):
         r2 = x1 * x1 + x2 * x2
         ok = (r2 < 1.0) & (r2 > 0.0)
         with np.errstate(all="ignore"):
-            # log1p(r2 - 1) == log(r2) but well conditioned for r2 -> 1, so that
-            # every libm / device math library returns the same bits (+-1 ulp)
-            f = np.sqrt(-2.0 * np.log1p(r2[ok] - 1.0) / r2[ok])
+            f = np.sqrt(-2.0 * np.log(r2[ok]) / r2[ok])
         sel = todo[ok]
         out[sel] = np.where(which[sel], f * x2[ok], f * x1[ok])
         todo = todo[~ok]

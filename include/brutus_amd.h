@@ -215,8 +215,11 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
                              void *stream);
 
-/* Test hook: y[i] = the kernels' 10^x (table + polynomial) for n inputs. */
+/* Test hooks: y[i] = the kernels' own 10^x / e^x / ln x for n inputs
+ * (which = 0, 1, 2 in brutus_debug_math). */
 int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
+int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n,
+                      void *stream);
 
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */
