@@ -127,7 +127,7 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     bf.host_workers = 0
     n3 = 1024
     big = synth.make_stars(models, n3, seed=4242, with_parallax=with_par)
-    bf.batch_size = 64
+    bf.batch_size = 128
     for rep in range(2):          # first pass warms the workspaces
         with tempfile.TemporaryDirectory() as tmp:
             t0 = time.perf_counter()
