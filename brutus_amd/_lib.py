@@ -81,7 +81,7 @@ SIGNATURES = {
     "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_math": (C.c_int, [_i32, _vp, _vp, _i64, _vp]),
-    "brutus_post_workspace_bytes": (_sz, [_i32, _i64]),
+    "brutus_post_workspace_bytes": (_sz, [_i32, _i64, _i32]),
     "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
@@ -104,6 +104,11 @@ def lib():
             "brutus_amd: HIP library %s not found. Build it with "
             "`python -c 'import __graft_entry__ as g; g.build()'` (needs hipcc). "
             "There is no CPU fallback." % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64, and a process must end
+    # up with ONE HIP runtime -- the one that owns the device pointers we are
+    # handed.  Loading ours first would bind /opt/rocm's copy and the second
+    # runtime then finds "no ROCm-capable device".
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(L, name)   # AttributeError if the .so is stale

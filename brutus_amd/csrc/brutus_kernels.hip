@@ -520,6 +520,76 @@ __device__ __forceinline__ double fast_log(double x) {
     return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
 }
 
+// 1/x, sqrt x, 1/sqrt x for normal-range x > 0 from the hardware seed
+// (v_rcp_f64 / v_rsq_f64) plus Newton steps: ~1 ulp, no denormal / overflow
+// rescue and no correct rounding, i.e. 5-9 instructions instead of the 13-17 of
+// an IEEE divide / sqrt.  Used where the result feeds a prior density, never
+// where a comparison must reproduce the reference bit for bit.
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.), r, r);
+    r = fma(fma(-x, r, 1.), r, r);
+    return r;
+}
+__device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &sq, double &rsq) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    h = fma(fma(-h, g, 0.5), h, h);        // h -> 1 / (2 sqrt x)
+    sq = x == 0. ? 0. : g;
+    rsq = 2. * h;
+}
+__device__ __forceinline__ double fast_sqrt(double x) {
+    double g, h;
+    fast_sqrt_rsqrt(x, g, h);
+    return g;
+}
+// fast_exp without the early-out branch (selects instead)
+__device__ __forceinline__ double fast_exp_bf(double x, const double *__restrict__ tbl) {
+    const double xc = fmax(x, -745.);                // also maps NaN to -745; fixed below
+    const double n = rint(xc * 92.332482616893657);
+    double r = fma(-n, 0.01083042469326756, xc);
+    r = fma(-n, 2.9815858269852933e-12, r);
+    double pl = 8.3333333333333332e-03;
+    pl = fma(pl, r, 4.1666666666666664e-02);
+    pl = fma(pl, r, 1.6666666666666666e-01);
+    pl = fma(pl, r, 0.5);
+    pl = fma(pl, r, 1.0);
+    pl = fma(pl, r, 1.0);
+    const int ni = (int)n;
+    const double v = ldexp(tbl[ni & 63] * pl, ni >> 6);
+    return x > -745. ? v : (x == x ? 0. : x);
+}
+// fast_log with the reciprocal above (a few ulp)
+__device__ __forceinline__ double fast_log_r(double x) {
+    // branch-free: normal-range x > 0 takes the series; 0 -> -inf, +inf -> +inf,
+    // negative / NaN -> NaN by selects (subnormal x is not rescued: ~2^-1022 only)
+    int e;
+    double m = frexp(x, &e);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? 2. * m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.) * fast_rcp(m + 1.);
+    const double z = s * s;
+    double pl = 1. / 21.;
+    pl = fma(pl, z, 1. / 19.);
+    pl = fma(pl, z, 1. / 17.);
+    pl = fma(pl, z, 1. / 15.);
+    pl = fma(pl, z, 1. / 13.);
+    pl = fma(pl, z, 1. / 11.);
+    pl = fma(pl, z, 1. / 9.);
+    pl = fma(pl, z, 1. / 7.);
+    pl = fma(pl, z, 1. / 5.);
+    pl = fma(pl, z, 1. / 3.);
+    const double lm = fma(2. * s * z, pl, 2. * s);
+    const double ed = (double)e;
+    const double v = fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
+    return x > 0. ? (x < INFINITY ? v : x) : (x == 0. ? -INFINITY : nan(""));
+}
 
 __global__ void k_relayout(const float *__restrict__ aos, int64_t nmodel, int nfilt, int nb,
                            int64_t nmodel_pad, float *__restrict__ blob) {
@@ -1521,8 +1591,9 @@ __device__ __forceinline__ Philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32
             k0 += 0x9E3779B9u;
             k1 += 0xBB67AE85u;
         }
-        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // v_mad_u64_u32
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
         c0 = n0;
         c1 = lo1;
@@ -1545,23 +1616,36 @@ __device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t q) {
     return u53(o.w[0], o.w[1]);
 }
 
-// pair p of the normal stream (rng.py: philox_normal): z0 = normal 2p, z1 = normal 2p+1
-__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, double &z0, double &z1) {
+// candidate `retry` of pair p of the normal stream (rng.py: philox_normal);
+// true if the polar method accepts it
+__device__ __forceinline__ bool rng_polar_candidate(uint64_t seed, uint64_t p, uint32_t retry,
+                                                    double &x1, double &x2) {
 #pragma clang fp contract(off)   // r2 must round like numpy's x1*x1 + x2*x2 (accept/reject!)
-    // The retry loop only draws candidates (lanes of a wave retry in lockstep:
-    // ~3.5 rounds for 64 lanes at 21 % rejection); ln / sqrt / divide run once.
-    double x1, x2, r2;
-    for (uint32_t retry = 0;; ++retry) {
-        const Philox4 o = philox4x32_7((uint32_t)p, (uint32_t)(p >> 32), retry, 0u, (uint32_t)seed,
-                                       (uint32_t)(seed >> 32));
-        x1 = 2.0 * u53(o.w[0], o.w[1]) - 1.0;
-        x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
-        r2 = x1 * x1 + x2 * x2;
-        if (r2 < 1.0 && r2 > 0.0) break;
-    }
-    const double f = sqrt(-2.0 * fast_log(r2) / r2);   // rng.py: ln(r2), <= 1 ulp
+    const Philox4 o = philox4x32_7((uint32_t)p, (uint32_t)(p >> 32), retry, 0u, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+    x1 = 2.0 * u53(o.w[0], o.w[1]) - 1.0;
+    x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
+    const double r2 = x1 * x1 + x2 * x2;
+    return r2 < 1.0 && r2 > 0.0;
+}
+// the two normals of an accepted candidate
+__device__ __forceinline__ void rng_polar_finish(double x1, double x2, double &z0, double &z1) {
+#pragma clang fp contract(off)
+    const double r2 = x1 * x1 + x2 * x2;
+    // rng.py: f = sqrt(-2 ln(r2) / r2).  ln, the divide and the root are the ~1 ulp
+    // Newton forms (the accept / reject decision above is what must be exact): the
+    // normals agree with numpy's to a few ulp at a third of the IEEE sequences' cost.
+    const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
     z0 = f * x1;
     z1 = f * x2;
+}
+// pair p of the normal stream: z0 = normal 2p, z1 = normal 2p+1
+__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, double &z0, double &z1) {
+    // The retry loop only draws candidates (lanes of a wave retry in lockstep:
+    // ~3.5 rounds for 64 lanes at 21 % rejection); ln / sqrt / divide run once.
+    double x1, x2;
+    for (uint32_t retry = 0; !rng_polar_candidate(seed, p, retry, x1, x2); ++retry) {}
+    rng_polar_finish(x1, x2, z0, z1);
 }
 __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t j) {
     double z0, z1;
@@ -1579,8 +1663,12 @@ struct PostParams {     // mirrors brutus_post_params
     double feh_mean[3], feh_sigma[3];
     double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
     // derived on the host side of the ABI call (not part of brutus_post_params)
-    double ln_f_thick, ln_f_halo, reff_solar;
+    double ln_f_thick, ln_f_halo, inv_reff_solar2;
+    double inv_R_thin, inv_Z_thin, inv_R_thick, inv_Z_thick, inv_r_q;
+    double Rs_thin2, Rs_thick2, Rs_halo2, rq2, abs_Z_solar;
+    double lnK, c0_thin, c0_thick, c0_halo;      // component constants relative to lnK
 };
+constexpr int POST_DERIVED = 17;
 
 // stream key and uniform base of object s: one shared sequential stream, or
 // (per_object) an own stream keyed seed + object index
@@ -1628,43 +1716,47 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
     }
 }
 
-// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc].
-// With w_c = exp(comp_c - m) the three log-sum-exps of the reference collapse:
+// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc],
+// as a plain density relative to e^lnK: gal_lnprior = lnK + ln(gal_prior_lin).
+// With T_c = exp(comp_c - lnK) the three log-sum-exps of the reference collapse:
 //   lse(comp) + [lse(F + comp) - lse(comp)] + [lse(A + comp) - lse(comp)]
-//     = m + log( (sum w_c e^F_c) (sum w_c e^A_c) / sum w_c )
-// so a sample costs 4 exp + 2 log instead of 10 + 4; EF_c = e^F_c, EA_c = e^A_c
-// are per-model constants.
+//     = lnK + ln( (sum T_c e^F_c) (sum T_c e^A_c) / sum T_c )
+// EF_c = e^F_c, EA_c = e^A_c are per-model constants.  lnK (fill_post_params) is
+// an upper bound of every comp_c, so no T_c overflows, and the halo's power law
+// keeps the sum away from underflow at any distance: no running maximum needed.
+// Cost per call: 3 exp + 1 log (halo power) + 3 sqrt + 2 reciprocals.
+__device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const StarGeom &g, double d,
+                                                const double (&EF)[3], const double (&EA)[3],
+                                                const double *__restrict__ tbl) {
+    const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
+    const double R2 = x * x + y * y;
+    const double dZ = fabs(Z) - pp.abs_Z_solar;
+    const double Rt = fast_sqrt(R2 + pp.Rs_thin2);
+    const double Rk = pp.Rs_thick2 == pp.Rs_thin2 ? Rt : fast_sqrt(R2 + pp.Rs_thick2);
+    // thin / thick disk: exp(-(R - R_sun)/R_c - (|Z| - |Z_sun|)/Z_c [+ ln f] - lnK)
+    const double T0 = fast_exp_bf(pp.c0_thin - (Rt * pp.inv_R_thin + dZ * pp.inv_Z_thin), tbl);
+    const double T1 = fast_exp_bf(pp.c0_thick - (Rk * pp.inv_R_thick + dZ * pp.inv_Z_thick), tbl);
+    // halo: f (reff / reff_sun)^-eta, reff^2 = R^2 + (Z/q)^2 + Rs^2, q(r) (pdf.py:341-365)
+    const double q = pp.q_halo_inf -
+                     (pp.q_halo_inf - pp.q_halo_ctr) *
+                         fast_exp_bf(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
+    const double zq = Z * fast_rcp(q);
+    const double T2 = fast_exp_bf(
+        pp.c0_halo - 0.5 * pp.eta_halo * fast_log_r((R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2), tbl);
+    double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
+    if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
+    if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
+    const double S = T0 + T1 + T2;
+    const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
+    // divide by S^(npow - 1): one S stays for lse(comp) itself
+    if (npow == 2) num *= fast_rcp(S);
+    else if (npow == 0) num *= S;
+    return num;
+}
 __device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const StarGeom &g, double d,
                                                   const double (&EF)[3], const double (&EA)[3],
                                                   const double *__restrict__ tbl) {
-    const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
-    const double R2 = x * x + y * y;
-    const double aZ = fabs(Z), aZs = fabs(pp.Z_solar);
-    double comp[3];
-    comp[0] = -((sqrt(R2 + pp.Rs_thin * pp.Rs_thin) - pp.R_solar) / pp.R_thin +
-                (aZ - aZs) / pp.Z_thin);
-    comp[1] = -((sqrt(R2 + pp.Rs_thick * pp.Rs_thick) - pp.R_solar) / pp.R_thick +
-                (aZ - aZs) / pp.Z_thick) + pp.ln_f_thick;
-    {
-        const double rq2 = pp.r_q_halo * pp.r_q_halo;
-        const double q = pp.q_halo_inf - (pp.q_halo_inf - pp.q_halo_ctr) *
-                                             fast_exp(1. - sqrt(R2 + Z * Z + rq2) / pp.r_q_halo, tbl);
-        const double reff = sqrt(R2 + (Z / q) * (Z / q) + pp.Rs_halo * pp.Rs_halo);
-        comp[2] = -pp.eta_halo * fast_log(reff / pp.reff_solar) + pp.ln_f_halo;
-    }
-    double m = comp[0] > comp[1] ? comp[0] : comp[1];
-    m = comp[2] > m ? comp[2] : m;
-    const double w0 = fast_exp(comp[0] - m, tbl), w1 = fast_exp(comp[1] - m, tbl),
-                 w2 = fast_exp(comp[2] - m, tbl);
-    double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
-    if (pp.has_feh) num *= w0 * EF[0] + w1 * EF[1] + w2 * EF[2];
-    if (pp.has_loga) num *= w0 * EA[0] + w1 * EA[1] + w2 * EA[2];
-    const double S = w0 + w1 + w2;
-    const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
-    // divide by S^(npow - 1): one S stays for lse(comp) itself
-    if (npow == 2) num /= S;
-    else if (npow == 0) num *= S;
-    return m + fast_log(num);
+    return pp.lnK + fast_log_r(gal_prior_lin(pp, g, d, EF, EA, tbl));
 }
 
 constexpr int PCH = 64;      // chunks per object for the record passes
@@ -1912,9 +2004,31 @@ struct NormalReader {
     }
 };
 
-// One Monte Carlo sample t of kept record `o` of object s (fitting.py:1071-1093):
-// returns lnp_mc and the sample (dist, av, rv).  n = rank of the record in the
-// object's list: its normals sit at nbase + (3 n + k) nmc + t (utils.py:897).
+// One Monte Carlo sample of a kept record (fitting.py:1071-1093) from its three
+// normals: sample t of the record of rank n in the object's list uses normals
+// nbase + (3 n + k) nmc + t, k = 0, 1, 2 (utils.py:897).  Returns (dist, av, rv),
+// whether it is inside the fit bounds, and its prior in split form:
+//   lnp_mc = lnK + ln(lin) + epar - par_lnorm / 2,   epar = -(par - par_obs)^2 ivar / 2 <= 0
+__device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGeom &g, double z0,
+                                              double z1, double z2, double s0, double a0, double r0,
+                                              const double (&L)[6], const double (&Fc)[3],
+                                              const double (&Ac)[3], const double *__restrict__ tbl,
+                                              double &dist, double &a_mc, double &r_mc, bool &inb,
+                                              double &lin, double &epar) {
+    const double s_mc = s0 + L[0] * z0;
+    a_mc = a0 + (L[1] * z0 + L[2] * z1);
+    r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
+    double par;
+    fast_sqrt_rsqrt(s_mc, par, dist);                           // parallax and distance (~1 ulp)
+    lin = gal_prior_lin(pp, g, dist, Fc, Ac, tbl);
+    const double dp = par - g.par;                              // pdf.py:166-173
+    epar = g.has_par ? -0.5 * (dp * dp * g.par_ivar) : 0.;
+    inb = s_mc >= 1e-20 && a_mc >= pp.avlim[0] && a_mc <= pp.avlim[1] &&
+          r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
+}
+
+// the same as one log value (-BIG outside the bounds, fitting.py:1086-1090),
+// drawing the normals on the fly
 __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (&rd)[3],
                                             const StarGeom &g, uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
                                             const double (&L)[6], const double (&Fc)[3],
@@ -1924,26 +2038,33 @@ __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (
     const double z0 = rd[0].at(j0);
     const double z1 = rd[1].at(j0 + (uint64_t)pp.nmc);
     const double z2 = rd[2].at(j0 + 2ull * (uint64_t)pp.nmc);
-    const double s_mc = s0 + L[0] * z0;
-    a_mc = a0 + (L[1] * z0 + L[2] * z1);
-    r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
-    const double par = sqrt(s_mc);
-    dist = 1. / par;
-    double v = gal_lnprior_dev(pp, g, dist, Fc, Ac, tbl);
-    if (g.has_par) {                                            // pdf.py:166-173
-        const double dp = par - g.par;
-        v += -0.5 * (dp * dp * g.par_ivar + g.par_lnorm);
-    }
-    inb = s_mc >= 1e-20 && a_mc >= pp.avlim[0] && a_mc <= pp.avlim[1] &&
-          r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
+    double lin, epar;
+    mc_sample_lin(pp, g, z0, z1, z2, s0, a0, r0, L, Fc, Ac, tbl, dist, a_mc, r_mc, inb, lin, epar);
+    double v = pp.lnK + fast_log_r(lin);
+    if (g.has_par) v += epar - 0.5 * g.par_lnorm;
     if (!inb) v = -BIG;
     return v;
 }
 
+// rows (polar pairs) of a k_post_mc staging slot: the 3 nmc normals of a record
+// span at most 3 nmc / 2 + 1 pairs
+__host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2; }
+
 // P4: Monte Carlo prior integral of every kept record (fitting.py:1068-1105)
 // and chi2min (fitting.py:2025-2034).  One lane per record.
-__global__ void __launch_bounds__(TILE)
-k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
+//
+// The 3 nmc normals of a record are one contiguous run of the stream, i.e.
+// ~3 nmc / 2 polar pairs.  A lane first walks its pairs with its own retry
+// counter and stores the two normals of each accepted candidate in its column
+// of `zs` (lane-interleaved rows of double2; 16-byte stores: the staging is
+// bound by L2 write requests, lanes drift apart in row) -- a
+// wave then spends ~1/0.785 Philox rounds per pair instead of the ~3.7 it takes
+// until all 64 lanes of a lockstep retry loop have accepted -- and afterwards
+// integrates, reading three normals per sample.
+//
+__global__ void __launch_bounds__(TILE, 3)
+k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ counter,
+          double2 *__restrict__ zs, const int32_t *__restrict__ sel_idx,
           const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
           const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
           const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
@@ -1952,83 +2073,135 @@ k_post_mc(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
           double *__restrict__ part_chi2) {
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
+    __shared__ unsigned int s_item;
     stage_exp_table(s_tbl);
-    __syncthreads();
-    const int s = blockIdx.y, c = blockIdx.x;
-    int64_t a, b;
-    rec_range_n(off2[s], nsel[s], c, a, b);
-    const StarGeom g = geom[s];
-    const uint64_t nb = nbase[s];
-    const uint64_t seed = star_seed(pp, s);
-    double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
-    if (!flags[s]) {
-        for (int64_t o0 = a; o0 < b; o0 += TILE) {
-            const int64_t o = o0 + threadIdx.x;
-            if (o < b) {
-                const int64_t r = sel_off[s] + rp.src[o];
-                const int64_t i = sel_idx[r];
-                double Fc[3], Ac[3], L[6];
-                label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
-#pragma unroll
-                for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
-                const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
-                             r0 = sel_vals[4 * cap + r];
+    double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int item = s_item;
+        if (item >= (unsigned int)nitem) break;
+        const int s = (int)(item / PCH), c = (int)(item % PCH);
+        int64_t a, b;
+        rec_range_n(off2[s], nsel[s], c, a, b);
+        const StarGeom g = geom[s];
+        const uint64_t nb = nbase[s];
+        const uint64_t seed = star_seed(pp, s);
+        double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
+        if (!flags[s]) {
+            for (int64_t o0 = a; o0 < b; o0 += TILE) {
+                const int64_t o = o0 + threadIdx.x;
+                const bool live = o < b;
                 const int64_t n = o - off2[s];
-                double m = -INFINITY, acc = 0.;
-                int ninb = 0;
-                NormalReader rd[3];
-                rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
-                for (int t = 0; t < pp.nmc; ++t) {
-                    double d_, a_, r_;
-                    bool inb;
-                    const double v = mc_sample(pp, rd, g, nb, n, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb);
-                    if (inb) ++ninb;
-                    if (v == v) {                       // logsumexp ignores nothing; NaN poisons
-                        if (v > m) {
-                            acc = acc * fast_exp(m - v, s_tbl) + 1.;
-                            m = v;
-                        } else if (v > -INFINITY) {
-                            acc += fast_exp(v - m, s_tbl);
+                // normals j_lo .. j_lo + 3 nmc - 1 of the stream = pairs p_lo .. p_hi;
+                // pair q - p_lo goes to row q - p_lo of the slot as one 16-byte store
+                const uint64_t j_lo = nb + (uint64_t)(3 * n * (int64_t)pp.nmc);
+                const uint64_t p_lo = j_lo >> 1;
+                {
+                    const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
+                    uint64_t p = live ? p_lo : p_hi + 1;
+                    uint32_t retry = 0;
+                    while (p <= p_hi) {
+                        double x1, x2;
+                        if (rng_polar_candidate(seed, p, retry, x1, x2)) {
+                            double z0, z1;
+                            rng_polar_finish(x1, x2, z0, z1);
+                            col[(int64_t)(p - p_lo) * TILE] = make_double2(z0, z1);
+                            ++p;
+                            retry = 0;
+                        } else {
+                            ++retry;
                         }
-                    } else {
-                        acc = nan("");
                     }
                 }
-                double lnp = rp.lnp[o] + ((log(acc) + m) - log((double)ninb));
-                if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
-                rp.lnp[o] = lnp;
-                if (lnp > mx) mx = lnp;
-                double chi2 = sel_vals[1 * cap + r];
-                if (g.has_par) {
-                    const double dp = sqrt(s0) - g.par;
-                    chi2 += dp * dp * g.par_ivar;
+                if (live) {
+                    const int64_t r = sel_off[s] + rp.src[o];
+                    const int64_t i = sel_idx[r];
+                    double Fc[3], Ac[3], L[6];
+                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+                    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
+                                 r0 = sel_vals[4 * cap + r];
+                    // sum_t lin_t e^{epar_t} over the in-bounds samples, with a
+                    // running maximum M of epar only (lin needs none); branch-free
+                    double M = -INFINITY, acc = 0.;
+                    int ninb = 0;
+                    const double *const zc = (const double *)col;
+                    const int jb = (int)(j_lo & 1);
+                    for (int t = 0; t < pp.nmc; ++t) {
+                        double d_, a_, r_, lin, epar;
+                        bool inb;
+                        // normal jj of the run: component jj & 1 of row jj >> 1
+                        const int j0 = jb + t, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
+                        mc_sample_lin(pp, g, zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
+                                      zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
+                                      zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)], s0, a0, r0, L, Fc, Ac,
+                                      s_tbl, d_, a_, r_, inb, lin, epar);
+                        ninb += inb ? 1 : 0;
+                        if (g.has_par) {
+                            const double dM = epar - M;
+                            const double ex = fast_exp_bf(-fabs(dM), s_tbl);
+                            const bool up = inb && dM > 0.;
+                            const double add = inb ? lin : 0.;
+                            acc = up ? fma(acc, ex, add) : (inb ? fma(add, ex, acc) : acc);
+                            M = up ? epar : M;
+                        } else {
+                            acc += inb ? lin : 0.;
+                        }
+                    }
+                    // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
+                    // sample in bounds the reference yields +inf -> not finite -> -BIG
+                    double lse = pp.lnK + log(acc);
+                    if (g.has_par) lse += M - 0.5 * g.par_lnorm;
+                    double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
+                    if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
+                    rp.lnp[o] = lnp;
+                    if (lnp > mx) mx = lnp;
+                    double chi2 = sel_vals[1 * cap + r];
+                    if (g.has_par) {
+                        const double dp = sqrt(s0) - g.par;
+                        chi2 += dp * dp * g.par_ivar;
+                    }
+                    if (-chi2 > cmin) cmin = -chi2;
                 }
-                if (-chi2 > cmin) cmin = -chi2;
             }
         }
+        block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
+        block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
     }
-    block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
-    block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
 }
 
-// P5: evidence and the cumulative weights of one object (fitting.py:2033-2038);
-// one workgroup per object, sequential 256-wide scan with carry.
-__global__ void __launch_bounds__(TILE)
-k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
-           const int32_t *__restrict__ flags, const double *__restrict__ part_max,
-           const double *__restrict__ part_chi2, RecPost rp, double *__restrict__ cdf,
-           double *__restrict__ star_out) {
-    __shared__ double sh[TILE];
-    __shared__ double carry;
-    const int s = blockIdx.x;
-    if (flags[s]) return;
-    const int64_t a = off2[s], b = off2[s] + nsel[s];
-    double mx = -INFINITY, cm = -INFINITY;
+// P5: evidence and the cumulative weights of one object (fitting.py:2033-2038),
+// chunk-parallel over grid (PCH, object):
+//   k_post_evid_part : per-chunk sums of exp(lnp - max)          -> levid
+//   k_post_wt_part   : per-chunk totals of wt = exp(lnp - levid)
+//   k_post_cdf       : chunk offset + in-chunk running sum       -> cdf
+// The chunk totals come from the very scan that later writes the cdf, so the
+// cdf is monotone across chunk boundaries bit for bit.
+__device__ __forceinline__ void post_star_max(const double *__restrict__ part_max,
+                                              const double *__restrict__ part_chi2, int s, double &mx,
+                                              double &cm) {
+    mx = -INFINITY;
+    cm = -INFINITY;
     for (int q = 0; q < PCH; ++q) {
         mx = fmax(mx, part_max[(int64_t)s * PCH + q]);
         cm = fmax(cm, part_chi2[(int64_t)s * PCH + q]);
     }
-    // levid = logsumexp(lnp)
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_evid_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+                 const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+                 const double *__restrict__ part_chi2, RecPost rp, double *__restrict__ part_e) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
     double acc = 0.;
     for (int64_t o = a + threadIdx.x; o < b; o += TILE) acc += exp(rp.lnp[o] - mx);
     sh[threadIdx.x] = acc;
@@ -2037,14 +2210,26 @@ k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int64_t *__restric
         if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
-    const double levid = log(sh[0]) + mx;
-    __syncthreads();
-    // running sum of wt = exp(lnp - levid)
-    if (threadIdx.x == 0) carry = 0.;
-    __syncthreads();
+    if (threadIdx.x == 0) part_e[(int64_t)s * PCH + c] = sh[0];
+}
+
+// log-evidence of object s from the chunk sums (same order in every caller)
+__device__ __forceinline__ double post_levid(const double *__restrict__ part_e, int s, double mx) {
+    double tot = 0.;
+    for (int q = 0; q < PCH; ++q) tot += part_e[(int64_t)s * PCH + q];
+    return log(tot) + mx;
+}
+
+// running sum of wt over records [a, b) starting from `carry0`; returns the
+// final carry (all threads).  WRITE: store the inclusive sums to cdf.
+template <bool WRITE>
+__device__ __forceinline__ double post_chunk_scan(const double *__restrict__ lnp, int64_t a, int64_t b,
+                                                  double levid, double carry0, double *sh,
+                                                  double *__restrict__ cdf) {
+    double carry = carry0;
     for (int64_t o0 = a; o0 < b; o0 += TILE) {
         const int64_t o = o0 + threadIdx.x;
-        const double w = o < b ? exp(rp.lnp[o] - levid) : 0.;
+        const double w = o < b ? exp(lnp[o] - levid) : 0.;
         sh[threadIdx.x] = w;
         __syncthreads();
         for (int st = 1; st < TILE; st <<= 1) {          // Hillis-Steele inclusive scan
@@ -2053,16 +2238,52 @@ k_post_cdf(int nstar, const int64_t *__restrict__ off2, const int64_t *__restric
             sh[threadIdx.x] += v;
             __syncthreads();
         }
-        if (o < b) cdf[o] = carry + sh[threadIdx.x];
-        __syncthreads();
-        if (threadIdx.x == TILE - 1) carry += sh[TILE - 1];
+        if (WRITE && o < b) cdf[o] = carry + sh[threadIdx.x];
+        carry += sh[TILE - 1];
         __syncthreads();
     }
-    if (threadIdx.x == 0) {
+    return carry;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_wt_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+               const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+               const double *__restrict__ part_chi2, const double *__restrict__ part_e, RecPost rp,
+               double *__restrict__ part_w) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
+    const double levid = post_levid(part_e, s, mx);
+    const double tot = post_chunk_scan<false>(rp.lnp, a, b, levid, 0., sh, nullptr);
+    if (threadIdx.x == 0) part_w[(int64_t)s * PCH + c] = tot;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_cdf(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+           const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+           const double *__restrict__ part_chi2, const double *__restrict__ part_e,
+           const double *__restrict__ part_w, RecPost rp, double *__restrict__ cdf,
+           double *__restrict__ star_out) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
+    const double levid = post_levid(part_e, s, mx);
+    double carry = 0.;                         // offset of this chunk: its predecessors' totals
+    for (int q = 0; q < c; ++q) carry += part_w[(int64_t)s * PCH + q];
+    carry = post_chunk_scan<true>(rp.lnp, a, b, levid, carry, sh, cdf);
+    if (c == PCH - 1 && threadIdx.x == 0) {
         star_out[4 * s + 0] = levid;
         star_out[4 * s + 1] = -cm;            // chi2min
         star_out[4 * s + 2] = carry;          // total weight (cdf normaliser)
-        star_out[4 * s + 3] = (double)(b - a);
+        star_out[4 * s + 3] = (double)nsel[s];
     }
 }
 
@@ -2805,7 +3026,7 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
 
 // ---- lnpost on the device ---------------------------------------------------
 struct PostWs {
-    double *lnp1, *part, *part_max, *part_chi2, *cdf, *star_out;
+    double *lnp1, *part, *part_w, *part_max, *part_chi2, *cdf, *star_out;
     unsigned long long *mask;
     int64_t *counts, *offsets, *off2;
     uint64_t *nbase;
@@ -2818,10 +3039,15 @@ struct PostWs {
     int32_t *sort_in, *sort_perm;
     void *sort_tmp;
     size_t sort_tmp_bytes;
+    // k_post_mc: work counter and staged normals
+    unsigned int *mc_counter;
+    double2 *mc_stage;
     size_t bytes;
 };
 
-PostWs carve_post(char *base, int nstar, int64_t cap) {
+constexpr int MC_SLOTS = 1024;     // persistent workgroups (= staging slots) of k_post_mc
+
+PostWs carve_post(char *base, int nstar, int64_t cap, int nmc) {
     PostWs w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -2835,6 +3061,7 @@ PostWs carve_post(char *base, int nstar, int64_t cap) {
     w.counts = (int64_t *)take(8 * (size_t)nstar * PCH);
     w.offsets = (int64_t *)take(8 * (size_t)nstar * PCH);
     w.part = (double *)take(8 * (size_t)nstar * PCH);
+    w.part_w = (double *)take(8 * (size_t)nstar * PCH);
     w.part_max = (double *)take(8 * (size_t)nstar * PCH);
     w.part_chi2 = (double *)take(8 * (size_t)nstar * PCH);
     w.off2 = (int64_t *)take(8 * ((size_t)nstar + 1));
@@ -2853,6 +3080,8 @@ PostWs carve_post(char *base, int nstar, int64_t cap) {
     w.sort_perm = (int32_t *)take(4 * c);
     w.sort_tmp_bytes = 16 * c + (8u << 20);
     w.sort_tmp = take(w.sort_tmp_bytes);
+    w.mc_counter = (unsigned int *)take(256);
+    w.mc_stage = (double2 *)take(sizeof(double2) * (size_t)MC_SLOTS * mc_npair_max(nmc) * TILE);
     w.bytes = off;
     return w;
 }
@@ -2895,12 +3124,31 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     const double rq2 = pp.r_q_halo * pp.r_q_halo, Rs2 = pp.R_solar * pp.R_solar, Zs = pp.Z_solar;
     const double qs = pp.q_halo_inf -
                       (pp.q_halo_inf - pp.q_halo_ctr) * exp(1. - sqrt(Rs2 + Zs * Zs + rq2) / pp.r_q_halo);
-    pp.reff_solar = sqrt(Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
+    pp.inv_reff_solar2 = 1. / (Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
+    pp.inv_R_thin = 1. / pp.R_thin;
+    pp.inv_Z_thin = 1. / pp.Z_thin;
+    pp.inv_R_thick = 1. / pp.R_thick;
+    pp.inv_Z_thick = 1. / pp.Z_thick;
+    pp.inv_r_q = 1. / pp.r_q_halo;
+    pp.Rs_thin2 = pp.Rs_thin * pp.Rs_thin;
+    pp.Rs_thick2 = pp.Rs_thick * pp.Rs_thick;
+    pp.Rs_halo2 = pp.Rs_halo * pp.Rs_halo;
+    pp.rq2 = rq2;
+    pp.abs_Z_solar = fabs(Zs);
+    // comp_c <= k_c: R >= 0, |Z| >= 0, reff^2 >= Rs_halo^2
+    const double k_thin = pp.R_solar * pp.inv_R_thin + pp.abs_Z_solar * pp.inv_Z_thin;
+    const double k_thick = pp.R_solar * pp.inv_R_thick + pp.abs_Z_solar * pp.inv_Z_thick + pp.ln_f_thick;
+    const double k_halo =
+        pp.ln_f_halo - 0.5 * pp.eta_halo * log(fmax(pp.Rs_halo2, 1e-12) * pp.inv_reff_solar2);
+    pp.lnK = fmax(fmax(k_thin, k_thick), k_halo);
+    pp.c0_thin = pp.R_solar * pp.inv_R_thin - pp.lnK;
+    pp.c0_thick = pp.R_solar * pp.inv_R_thick + pp.ln_f_thick - pp.lnK;
+    pp.c0_halo = pp.ln_f_halo - pp.lnK;
 }
 
-size_t brutus_post_workspace_bytes(int nstar, int64_t capacity) {
-    if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1) return 0;
-    return carve_post(nullptr, nstar, capacity).bytes;
+size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc) {
+    if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1 || nmc < 1) return 0;
+    return carve_post(nullptr, nstar, capacity, nmc).bytes;
 }
 
 int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
@@ -2910,7 +3158,7 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                       const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
                       int32_t *h_flags, uint64_t *h_nbase, void *stream) {
-    static_assert(sizeof(PostParams) == sizeof(brutus_post_params) + 3 * sizeof(double),
+    static_assert(sizeof(PostParams) == sizeof(brutus_post_params) + POST_DERIVED * sizeof(double),
                   "post params layout");
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1)
         return fail(BRUTUS_EINVAL, "bad post dimensions");
@@ -2921,7 +3169,7 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         return fail(BRUTUS_EINVAL, "nmc, ndraws and wt_thresh must be positive");
     if ((params->has_feh && !d_feh) || (params->has_loga && !d_loga))
         return fail(BRUTUS_EINVAL, "label arrays missing");
-    PostWs w = carve_post((char *)d_workspace, nstar, capacity);
+    PostWs w = carve_post((char *)d_workspace, nstar, capacity, params->nmc);
     if (w.bytes > workspace_bytes)
         return fail(BRUTUS_ENOMEM, "post workspace too small: need %zu bytes, got %zu", w.bytes,
                     workspace_bytes);
@@ -2962,13 +3210,22 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         if (any) HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * (size_t)nstar, st));
     }
     tm.begin("k_post_mc");
-    hipLaunchKernelGGL(k_post_mc, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
-                       w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.part_max,
-                       w.part_chi2);
+    {
+        const int nitem = PCH * nstar;
+        HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
+        hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
+                           capacity, nitem, w.mc_counter, w.mc_stage, d_sel_idx,
+                           d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh,
+                           d_loga, w.rp, w.part_max, w.part_chi2);
+    }
     tm.end();
     tm.begin("k_post_cdf");
-    hipLaunchKernelGGL(k_post_cdf, dim3(nstar), blk, 0, st, nstar, w.off2, w.nsel, w.flags,
-                       w.part_max, w.part_chi2, w.rp, w.cdf, w.star_out);
+    hipLaunchKernelGGL(k_post_evid_part, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max,
+                       w.part_chi2, w.rp, w.part);
+    hipLaunchKernelGGL(k_post_wt_part, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max,
+                       w.part_chi2, w.part, w.rp, w.part_w);
+    hipLaunchKernelGGL(k_post_cdf, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max, w.part_chi2,
+                       w.part, w.part_w, w.rp, w.cdf, w.star_out);
     tm.end();
     tm.begin("k_post_draw");
     hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, nstar), dim3(64), 0, st, pp, nstar,

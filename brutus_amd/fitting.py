@@ -258,7 +258,7 @@ class _Engine(object):
         (lnprior, feh, loga) device tensors (feh / loga may be None)."""
         torch, L, g = self.torch, self.L, self.grid
         cap = sel_idx.numel()
-        nbytes = L.brutus_post_workspace_bytes(nstar, cap)
+        nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
         if getattr(self, "_post_ws", None) is None or self._post_ws.numel() < nbytes:
             self._post_ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)

@@ -170,7 +170,7 @@ typedef struct brutus_post_params {
     double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
 } brutus_post_params;
 
-size_t brutus_post_workspace_bytes(int nstar, int64_t capacity);
+size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc);
 int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                       const double *d_sel_vals, const int64_t *d_sel_off,
                       const double *d_lnprior, const double *d_feh,

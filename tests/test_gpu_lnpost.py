@@ -24,11 +24,16 @@ def test_device_rng_matches_specification():
         idx = np.arange(start, start + n, dtype=np.uint64)
         assert np.array_equal(u.cpu().numpy(), philox_uniform(seed, idx))
         zr = philox_normal(seed, idx)
-        # same accept/reject decisions (the uniforms are bit-identical); the
-        # deviates may differ in the last bits of log1p / sqrt (libm vs ocml)
+        # same accept/reject decisions (the uniforms are bit-identical, and a
+        # wrong decision would shift a deviate by O(1)); the deviates differ
+        # from numpy's in the last bits: ln, divide and sqrt are ~1 ulp Newton
+        # forms on the device
         zd = z.cpu().numpy()
-        assert np.max(np.abs(zd - zr) / np.abs(zr)) < 2e-15
-        assert np.mean(zd == zr) > 0.7
+        err = np.abs(zd - zr) / np.abs(zr)
+        print("normals: max rel err %.2e, mean %.2e, bit-equal %.3f"
+              % (err.max(), err.mean(), np.mean(zd == zr)))
+        assert err.max() < 2e-15
+        assert err.mean() < 2.5e-16
 
 
 def _post_params(**kw):
