@@ -10,8 +10,9 @@ import os
 __all__ = ["lib", "Params", "PostParams", "check", "LIB_PATH", "BrutusError", "NVALS",
            "MAX_BATCH", "MAX_FILT"]
 
-LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)),
-                        "libbrutus_amd.so")
+# BRUTUS_AMD_LIB: another build of the same library (A/B kernel timing)
+LIB_PATH = os.environ.get("BRUTUS_AMD_LIB") or os.path.join(
+    os.path.dirname(os.path.abspath(__file__)), "libbrutus_amd.so")
 NVALS = 11
 MAX_BATCH = 256
 MAX_FILT = 32
