@@ -995,6 +995,120 @@ __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[N
     o.i22 = r_den;
 }
 
+// ---- pinned Rv (rvlim[0] == rvlim[1] == rv_gauss[0], BASELINE configs[1]) ----
+// The Rv step of every sweep is clamped to zero, so R_j = r0_j + rv dr_j is a
+// per-model constant and the magnitude phase is a 2-parameter (offset, Av)
+// problem: five weighted inner products of {1, R, y} instead of nine, and only
+// the Av half of a sweep.  Same formulas as gram_init / gram_sweep with rv fixed;
+// the Rv rows of the precision matrix are still reported (mle_fast_rf<FULL>).
+struct GramR {
+    double uR, RR, yR, uy, yy;
+};
+
+template <int NB>
+__device__ __forceinline__ void coef_R(const Coef<NB> &c, double rv, double (&R)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) R[j] = (double)c.r0[j] + rv * (double)c.dr[j];
+}
+
+template <int NB>
+__device__ __forceinline__ void gram_init_rf(const Coef<NB> &c, const double (&R)[NB],
+                                             const StarPrep &sp, GramR &G) {
+    double uR = 0., RR = 0., yR = 0., uy = 0., yy = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double w = sp.iW[j];
+        const double y = sp.g[j] - (double)c.m[j];
+        const double Rw = R[j] * w, yw = y * w;
+        uR += Rw;
+        RR += R[j] * Rw;
+        yR += R[j] * yw;
+        uy += yw;
+        yy += y * yw;
+    }
+    G.uR = uR; G.RR = RR; G.yR = yR; G.uy = uy; G.yy = yy;
+}
+
+// The Av half of fitting.py:176-243 (the Rv half moves nothing when rvmin == rvmax).
+__device__ __forceinline__ void gram_sweep_rf(const GramR &G, double S, const DevParams &p,
+                                              double &av, double &dav_o, double &logwt) {
+    const double rs = G.uy - av * G.uR;
+    const double ra = (G.yR - av * G.RR) + (p.av_mean - av) * p.av_ivar;
+    const double a_den = G.RR + p.av_ivar;
+    double dav = (S * ra - G.uR * rs) / (S * a_den - G.uR * G.uR);
+    if (dav < p.avmin - av) dav = p.avmin - av;
+    if (dav > p.avmax - av) dav = p.avmax - av;
+    av = av + dav;
+    const double chi2 = G.yy - av * (2. * G.yR - av * G.RR);
+    dav_o = dav;
+    logwt = -0.5 * chi2;
+}
+
+// mle_fast with R given.  FULL = false leaves out the Rv sums (i02, i12, i22,
+// r_num, r_ss), which only the reported precision matrix needs.
+template <int NB, bool TBL, bool FULL>
+__device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)[NB],
+                                            const double (&F0)[NB], const StarPrep &sp,
+                                            const DevParams &p, double av,
+                                            const double *__restrict__ tbl, Mle &o) {
+    const double fac = -0.92103403719761827361;
+    const double mav = -0.4 * av;
+    double F[NB];
+    double s_num = 0., s_den = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double f = F0[j] * (TBL ? fast_exp10(mav * R[j], tbl) : poly_exp10(mav * R[j]));
+        F[j] = f;
+        const double fw = f * sp.iV[j];
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    double sr_mix = 0., sa_mix = 0., ar_mix = 0., a_den = 0., r_den = 0.;
+    double a_num = 0., r_num = 0., chi2 = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double iv = sp.iV[j];
+        const double ff = fac * F[j];
+        double Rf = R[j] * ff;
+        const double Fs = F[j] * s;
+        const double res = sp.d[j] - Fs;
+        const double t = (Fs - res) * iv;
+        sa_mix += Rf * t;
+        Rf *= s;
+        a_den += Rf * Rf * iv;
+        const double rw = res * iv;
+        a_num += Rf * rw;
+        chi2 += res * rw;
+        if (FULL) {
+            double Df = (double)c.dr[j] * ff;
+            sr_mix += Df * t;
+            Df *= s;
+            const double red = (F[j] - F0[j]) * s;
+            ar_mix += Df * ((red - res) * iv);
+            r_den += Df * Df * iv;
+            r_num += Df * rw;
+        }
+    }
+    o.a_ss = a_den;
+    o.r_ss = r_den;
+    o.a_num = a_num;
+    o.r_num = r_num;
+    a_den += p.av_ivar;
+    r_den += p.rv_ivar;
+    a_den += p.a_reg;
+    r_den += p.r_reg;
+    o.scale = s;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = sa_mix;
+    o.i02 = sr_mix;
+    o.i11 = a_den;
+    o.i12 = ar_mix;
+    o.i22 = r_den;
+}
+
 // F0 of model i from the band-major table (coalesced) / of one model from its row.
 template <int NB>
 __device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t nmodel_pad,
@@ -1041,7 +1155,8 @@ __device__ __forceinline__ double first_cut_lnprob(const StarPrep &sp, double ln
 // Per (block.x, star) emits NV = 2*KS + 2 maxima into part[(bx * nstar + star) * NV + v]:
 //   v = 2k, 2k+1 : L_k, T_k for sweep k < KS   (only sweeps <= kfix are run)
 //   v = 2KS      : max lnl_p;  v = 2KS+1 : max lnprob_ns
-template <int NB, int KS, int FS_G>
+//   RVF              pinned-Rv specialisation (see GramR)
+template <int NB, int KS, int FS_G, bool RVF>
 __global__ void __launch_bounds__(TILE, 3)   // <=168 VGPRs: 3 waves/SIMD (LDS allows 3 blocks/CU)
 k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
         const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
@@ -1066,26 +1181,43 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         load_coef<NB>(grid, nmodel_pad, i, c);
         double F0[NB];
         load_F0<NB>(grid, nmodel_pad, i, F0);
+        double R[RVF ? NB : 1];
+        if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
         for (int g = 0; g < ng; ++g) {
             const int s = star_ids[g0 + g];
             const StarPrep &sp = stars[s];
-            Gram G;
-            gram_init<NB>(c, sp, G);
             double av = p.av_mean, rv = p.rv_mean;
             const int K = kfix[s];
             double *col = smax + (size_t)g * NV * TILE + threadIdx.x;
-            for (int k = 0; k < K; ++k) {
-                double dav, drv, lw;
-                gram_sweep(G, sp.S, p, av, rv, dav, drv, lw);
-                if (k < KS && live && lw == lw) {
-                    const bool big = (fabs(dav) >= p.mtol) || (fabs(drv) >= p.mtol);
-                    double *c0 = col + (size_t)(2 * k) * TILE;
-                    if (lw > c0[0]) c0[0] = lw;
-                    if (big && lw > c0[TILE]) c0[TILE] = lw;
-                }
-            }
             Mle m;
-            mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+            if constexpr (RVF) {
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double dav, lw;
+                    gram_sweep_rf(G, sp.S, p, av, dav, lw);
+                    if (k < KS && live && lw == lw) {
+                        double *c0 = col + (size_t)(2 * k) * TILE;
+                        if (lw > c0[0]) c0[0] = lw;
+                        if (fabs(dav) >= p.mtol && lw > c0[TILE]) c0[TILE] = lw;
+                    }
+                }
+                mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
+            } else {
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double dav, drv, lw;
+                    gram_sweep(G, sp.S, p, av, rv, dav, drv, lw);
+                    if (k < KS && live && lw == lw) {
+                        const bool big = (fabs(dav) >= p.mtol) || (fabs(drv) >= p.mtol);
+                        double *c0 = col + (size_t)(2 * k) * TILE;
+                        if (lw > c0[0]) c0[0] = lw;
+                        if (big && lw > c0[TILE]) c0[TILE] = lw;
+                    }
+                }
+                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+            }
             const double lnl = -0.5 * m.chi2;
             double lnlp = lnl;
             if (sp.has_par) {
@@ -1300,7 +1432,7 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
 // the state planes.  Writes the state/result planes at the survivors' positions
 // and, per work item, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
 // M = max final lnprob.
-template <int NB>
+template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
@@ -1325,15 +1457,26 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             double F0[NB];
             compute_F0_fast<NB>(c, F0);
             double av, rv, step, lnl_old;
+            double R[RVF ? NB : 1];
+            if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
             if (first) {
-                Gram G;
-                gram_init<NB>(c, sp, G);
                 av = p.av_mean;
                 rv = p.rv_mean;
                 const int K = k1[s];
-                for (int k = 0; k < K; ++k) {
-                    double a_, b_, c_;
-                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                if constexpr (RVF) {
+                    GramR G;
+                    gram_init_rf<NB>(c, R, sp, G);
+                    for (int k = 0; k < K; ++k) {
+                        double a_, c_;
+                        gram_sweep_rf(G, sp.S, p, av, a_, c_);
+                    }
+                } else {
+                    Gram G;
+                    gram_init<NB>(c, sp, G);
+                    for (int k = 0; k < K; ++k) {
+                        double a_, b_, c_;
+                        gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                    }
                 }
                 step = 1.0;
                 lnl_old = -BIG;
@@ -1344,18 +1487,25 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = -0.5 * pl.chi2[o];
             }
             Mle m;
-            mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            if constexpr (RVF) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
+            else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; it < niter; ++it) {
                 double dav = (m.a_num + (p.av_mean - av) * p.av_ivar) / (m.a_ss + p.av_ivar) * step;
-                double drv = (m.r_num + (p.rv_mean - rv) * p.rv_ivar) / (m.r_ss + p.rv_ivar) * step;
                 if (dav < p.avmin - av) dav = p.avmin - av;
                 if (dav > p.avmax - av) dav = p.avmax - av;
                 av += dav;
-                if (drv < p.rvmin - rv) drv = p.rvmin - rv;
-                if (drv > p.rvmax - rv) drv = p.rvmax - rv;
-                rv += drv;
-                mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+                if constexpr (RVF) {
+                    // the Rv step is clamped to zero; only the stored MLE needs the Rv sums
+                    if (it + 1 < niter) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
+                    else mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+                } else {
+                    double drv = (m.r_num + (p.rv_mean - rv) * p.rv_ivar) / (m.r_ss + p.rv_ivar) * step;
+                    if (drv < p.rvmin - rv) drv = p.rvmin - rv;
+                    if (drv > p.rvmax - rv) drv = p.rvmax - rv;
+                    rv += drv;
+                    mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+                }
                 lnl_new = -0.5 * m.chi2;
                 dl = fabs(lnl_new - lnl_old);
                 if (lnl_new < lnl_old) step /= 1.2;
@@ -1434,7 +1584,7 @@ __global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
 // Survivors of the cull are read from the result planes; the others are
 // re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
 // full-grid scan write eleven planes.
-template <int NB>
+template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
@@ -1463,16 +1613,28 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
             compute_F0_fast<NB>(c, F0);
-            Gram G;
-            gram_init<NB>(c, sp, G);
             double av = p.av_mean, rv = p.rv_mean;
             const int K = k1[s];
-            for (int k = 0; k < K; ++k) {
-                double a_, b_, c_;
-                gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
-            }
             Mle m;
-            mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            if constexpr (RVF) {
+                double R[NB];
+                coef_R<NB>(c, rv, R);
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double a_, c_;
+                    gram_sweep_rf(G, sp.S, p, av, a_, c_);
+                }
+                mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+            } else {
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double a_, b_, c_;
+                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                }
+                mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            }
             rec[0] = final_lnl(sp, p, m.chi2, false);
             rec[1] = m.chi2;
             rec[2] = m.scale;
@@ -2665,7 +2827,7 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
 constexpr int FS_TILES_PER_BLOCK = 8;
 constexpr int PERSIST_BLOCKS = 4096;
 
-template <int NB, int KS, int G>
+template <int NB, int KS, int G, bool RVF>
 int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> &ids,
                  const std::vector<int32_t> &kfix, const DevParams &p, Workspace &w, int accept,
                  hipStream_t st, Timer &tm) {
@@ -2678,7 +2840,7 @@ int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector
     constexpr int NV = 2 * KS + 2;
     const size_t shmem = (size_t)G * NV * TILE * sizeof(double);
     tm.begin("k_fscan");
-    hipLaunchKernelGGL((k_fscan<NB, KS, G>), dim3(nblkx, (nrun + G - 1) / G), dim3(TILE), shmem, st,
+    hipLaunchKernelGGL((k_fscan<NB, KS, G, RVF>), dim3(nblkx, (nrun + G - 1) / G), dim3(TILE), shmem, st,
                        grid, nmodel, nmodel_pad, nstar, nrun, w.ids, w.stars, p, w.kfix,
                        FS_TILES_PER_BLOCK, ntile, w.pl, w.part);
     tm.end();
@@ -2688,7 +2850,7 @@ int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector
     return 0;
 }
 
-template <int NB>
+template <int NB, bool RVF>
 int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParams &p, Workspace &w,
                     int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
                     hipStream_t st, Timer &tm) {
@@ -2704,7 +2866,7 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
                        w.mask, w.offsets, capacity, d_sel_idx);
     tm.end();
     tm.begin("k_emit");
-    hipLaunchKernelGGL(k_emit<NB>, dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
+    hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                        nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
                        w.wbase_sel, w.pl, capacity, d_sel_vals);
     tm.end();
@@ -2712,7 +2874,7 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     return 0;
 }
 
-template <int NB>
+template <int NB, bool RVF>
 int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, int max_iter,
              Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
              int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2, hipStream_t st, Timer &tm) {
@@ -2722,7 +2884,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     for (int s = 0; s < nstar; ++s) ids[s] = s;
 
     // ---- fused scan, speculating K1 = 2 --------------------------------------
-    if (int rc = launch_fscan<NB, 2, 4>(grid, nmodel, nstar, ids, kfix, p, w, 0, st, tm)) return rc;
+    if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, ids, kfix, p, w, 0, st, tm)) return rc;
     HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     std::vector<int32_t> listA, listB;
@@ -2732,11 +2894,11 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     }
     if (!listA.empty()) {   // converged after ONE sweep: redo those stars with one sweep
         for (int s : listA) kfix[s] = 1;
-        if (int rc = launch_fscan<NB, 2, 4>(grid, nmodel, nstar, listA, kfix, p, w, 1, st, tm)) return rc;
+        if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, listA, kfix, p, w, 1, st, tm)) return rc;
     }
     if (!listB.empty()) {   // needs more than two sweeps: probe up to eight
         for (int s : listB) kfix[s] = 8;
-        if (int rc = launch_fscan<NB, 8, 1>(grid, nmodel, nstar, listB, kfix, p, w, 0, st, tm)) return rc;
+        if (int rc = launch_fscan<NB, 8, 1, RVF>(grid, nmodel, nstar, listB, kfix, p, w, 0, st, tm)) return rc;
         HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         std::vector<int32_t> listC;
@@ -2749,7 +2911,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
             }
         }
         if (!listC.empty())
-            if (int rc = launch_fscan<NB, 2, 4>(grid, nmodel, nstar, listC, kfix, p, w, 1, st, tm)) return rc;
+            if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, listC, kfix, p, w, 1, st, tm)) return rc;
     }
 
     // ---- cull: ordered survivor lists -----------------------------------------
@@ -2769,7 +2931,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        hipLaunchKernelGGL(k_fflux<NB>, dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
+        hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                            nmodel_pad, nstar, w.stars, p, w.k1, w.k2, first, w.surv_idx, w.surv_off,
                            w.wbase_surv, w.pl, w.part);
         tm.end();
@@ -2787,7 +2949,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     // ---- first cut of lnpost + records ------------------------------------------
     hipLaunchKernelGGL(k_sel_thresh, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxns_part,
                        w.maxsurv, p.ln_wt, w.thr_sel);
-    if (int rc = run_select_emit<NB>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
+    if (int rc = run_select_emit<NB, RVF>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
                                      d_sel_off, st, tm))
         return rc;
     if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
@@ -2796,14 +2958,21 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     return 0;
 }
 
+// Rv pinned by its limits at the value every fit starts from: the (offset, Av)
+// specialisation computes the same thing
+inline bool rv_pinned(const DevParams &p) { return p.rvmin == p.rvmax && p.rv_mean == p.rvmin; }
+
 int dispatch_fast(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
                   int max_iter, Workspace &w, int64_t capacity, int32_t *d_sel_idx,
                   double *d_sel_vals, int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2,
                   hipStream_t st, Timer &tm) {
-#define BRUTUS_CASE(N)                                                                          \
-    case N:                                                                                     \
-        return run_fast<N>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx, d_sel_vals, \
-                           d_sel_off, h_k1, h_k2, st, tm);
+    const bool rvf = rv_pinned(p);
+#define BRUTUS_CASE(N)                                                                             \
+    case N:                                                                                        \
+        return rvf ? run_fast<N, true>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,   \
+                                       d_sel_vals, d_sel_off, h_k1, h_k2, st, tm)                  \
+                   : run_fast<N, false>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,  \
+                                        d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);
     switch (nb) {
         BRUTUS_CASE(8)
         BRUTUS_CASE(12)
@@ -2818,13 +2987,21 @@ int dispatch_fast(int nb, const float *grid, int64_t nmodel, int nstar, const De
 int dispatch_select_emit(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
                          Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
                          int64_t *d_sel_off, hipStream_t st, Timer &tm) {
+    const bool rvf = rv_pinned(p);
+#define BRUTUS_CASE(N)                                                                             \
+    case N:                                                                                        \
+        return rvf ? run_select_emit<N, true>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,      \
+                                              d_sel_vals, d_sel_off, st, tm)                       \
+                   : run_select_emit<N, false>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,     \
+                                               d_sel_vals, d_sel_off, st, tm);
     switch (nb) {
-        case 8: return run_select_emit<8>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals, d_sel_off, st, tm);
-        case 12: return run_select_emit<12>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals, d_sel_off, st, tm);
-        case 16: return run_select_emit<16>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals, d_sel_off, st, tm);
-        case 24: return run_select_emit<24>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals, d_sel_off, st, tm);
-        case 32: return run_select_emit<32>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals, d_sel_off, st, tm);
+        BRUTUS_CASE(8)
+        BRUTUS_CASE(12)
+        BRUTUS_CASE(16)
+        BRUTUS_CASE(24)
+        BRUTUS_CASE(32)
     }
+#undef BRUTUS_CASE
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
 

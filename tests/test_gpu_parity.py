@@ -190,6 +190,24 @@ def test_full_size_properties():
         assert relerr(full["chi2"][s][sel], r1[s]["chi2"]) < 1e-9
         assert relerr(full["av"][s][sel], r1[s]["av"]) < 1e-9
         assert relerr(full["scale"][s][sel], r1[s]["scale"]) < 1e-9
+    # BASELINE configs[1] (Av-only): the pinned-Rv kernels against the generic
+    # full-plane path, which keeps the three-parameter formulas
+    pin = fitting._make_params((0., 20.), (0., 1e6), (3.32, 3.32), (3.32, 0.18),
+                               3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    rp = eng.fit_batch(st["flux"][:4], st["err"][:4], st["mask"][:4],
+                       st["parallax"][:4], st["parallax_err"][:4], pin)
+    fp = eng.loglike_batch(st["flux"][:4], st["err"][:4], st["mask"][:4],
+                           st["parallax"][:4], st["parallax_err"][:4], pin)
+    for s in range(4):
+        sel = rp[s]["sel"]
+        assert sel.size > 0 and np.all(rp[s]["rv"] == 3.32)
+        assert relerr(fp["lnl"][s][sel], rp[s]["lnlike"]) < 1e-9
+        assert relerr(fp["chi2"][s][sel], rp[s]["chi2"]) < 1e-9
+        assert relerr(fp["scale"][s][sel], rp[s]["scale"]) < 1e-9
+        assert np.max(np.abs(fp["av"][s][sel] - rp[s]["av"])) < 1e-9
+        i6 = fitting._icov_from6(fp["icov6"][:, s, :])[sel]
+        d = np.sqrt(np.abs(np.einsum('nii->ni', i6)))
+        assert np.max(np.abs(rp[s]["icov"] - i6) / (d[:, :, None] * d[:, None, :])) < 1e-9
     # one star against the oracle at full size
     i = 0
     ref = O.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
