@@ -1,0 +1,90 @@
+// cluster_kernels.hpp -- cluster.isochrone_loglike hot block behind brutus_cluster_lnl
+// Part of the single translation unit brutus_kernels.hip (included there, in
+// this order: common, fastmath, grid_kernels, fit_kernels, cluster_kernels,
+// post_kernels); everything lives in that unit's anonymous namespace.
+#pragma once
+
+namespace {
+
+// ===========================================================================
+// cluster.isochrone_loglike hot block (reference cluster.py:336-414)
+// ===========================================================================
+// For every object o and every isochrone point c (all secondary-mass-fraction
+// slices concatenated): chi2 = nansum_b (phot_ob - flux_cb)^2 / err_ob^2 + chi2_p,
+// lnl = chi2-logpdf(chi2, n_o) or -(chi2 + lnorm_o)/2, then
+// lnl_o = logsumexp_c (lnl + lnw_c).  One lane = one object (its bands in
+// VGPRs), isochrone points are wave-uniform (scalar loads); the point axis is
+// split over blockIdx.y and merged by k_cluster_merge (online logsumexp).
+template <int NB>
+__global__ void __launch_bounds__(64)
+k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
+          const double *__restrict__ pts_lnw, const double *__restrict__ phot,
+          const double *__restrict__ ivar, const double *__restrict__ chi2_p,
+          const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
+          int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
+    const int o = blockIdx.x * 64 + threadIdx.x;
+    const bool live = o < nobj;
+    const int oo = live ? o : 0;
+    double d[NB], iv[NB];
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+        d[b] = b < nb ? phot[(int64_t)oo * nb + b] : 0.;
+        iv[b] = b < nb ? ivar[(int64_t)oo * nb + b] : 0.;
+    }
+    const double cp = chi2_p[oo], ln0 = lnorm[oo];
+    const double k = (double)ndim[oo];
+    const double c0 = -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.);
+    const double c1 = k / 2. - 1.;
+    const int p0 = blockIdx.y * pts_per_block;
+    const int p1 = min(npts, p0 + pts_per_block);
+    double m = -INFINITY, ssum = 0.;
+    for (int c = p0; c < p1; ++c) {
+        const double *f = pts_flux + (int64_t)c * nb;
+        double chi2 = 0.;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            if (b < nb) {
+                const double t = d[b] - f[b];
+                const double term = t * t * iv[b];
+                if (term == term) chi2 += term;          // nansum (cluster.py:381)
+            }
+        }
+        chi2 += cp;
+        double lnl;
+        if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
+            lnl = c0 + (c1 == 0. ? 0. : c1 * log(chi2)) - chi2 / 2.;
+        else
+            lnl = -0.5 * (chi2 + ln0);
+        if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
+        const double x = lnl + pts_lnw[c];
+        if (x > m) {
+            ssum = ssum * exp(m - x) + 1.;
+            m = x;
+        } else if (x > -INFINITY) {
+            ssum += exp(x - m);
+        }
+    }
+    if (live) {
+        part_m[(int64_t)blockIdx.y * nobj + o] = m;
+        part_s[(int64_t)blockIdx.y * nobj + o] = ssum;
+    }
+}
+
+__global__ void k_cluster_merge(int nobj, int nchunk, const double *__restrict__ part_m,
+                                const double *__restrict__ part_s, double *__restrict__ out) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= nobj) return;
+    double m = -INFINITY;
+    for (int c = 0; c < nchunk; ++c) {
+        const double x = part_m[(int64_t)c * nobj + o];
+        m = x > m ? x : m;
+    }
+    double ssum = 0.;
+    for (int c = 0; c < nchunk; ++c) {
+        const double x = part_m[(int64_t)c * nobj + o];
+        if (x > -INFINITY) ssum += part_s[(int64_t)c * nobj + o] * exp(x - m);
+    }
+    out[o] = m > -INFINITY ? m + log(ssum) : -INFINITY;
+}
+
+}  // namespace

@@ -1,0 +1,806 @@
+// fit_kernels.hpp -- fused scan + compact flux phase + record emit behind brutus_fit_batch
+// Part of the single translation unit brutus_kernels.hip (included there, in
+// this order: common, fastmath, grid_kernels, fit_kernels, cluster_kernels,
+// post_kernels); everything lives in that unit's anonymous namespace.
+#pragma once
+
+namespace {
+
+// ===========================================================================
+// FAST PATH (brutus_fit_batch): fused full-grid scan + compact flux phase
+// ===========================================================================
+// The magnitude phase is a weighted linear least-squares problem in
+// (offset, Av, Av*Rv) for every (star, model).  Instead of carrying the Nb
+// residuals through the sweeps as the reference does, the fast path forms the
+// ten weighted inner products of {1, r0, dr, y = mag_obs - mag_model} once and
+// runs every sweep (fitting.py:176-243) on those scalars: the update formulas
+// are algebraically identical, the results agree to rounding (~1e-14), and a
+// sweep costs ~45 flops instead of ~14*Nb.
+//
+// One fused kernel then does, per (star, model): Gram sums -> 2 speculative
+// sweeps with convergence statistics -> MLE at the sweep-2 state -> cull
+// statistic lnl_p and the "not a survivor" first-cut statistic lnprob_ns.
+// K1 = 2 for >90 % of stars; stars with a different K1 are re-run (a few
+// percent of the batch).  Only two full planes are written (16 B per pair).
+
+struct Gram {   // weighted inner products of {1, a=r0, b=dr, y}; weights 1/mags_var
+    double ua, ub, uy, aa, ab, bb, ay, by, yy;
+};
+
+template <int NB>
+__device__ __forceinline__ void gram_init(const Coef<NB> &c, const StarPrep &sp, Gram &G) {
+    double ua = 0., ub = 0., uy = 0., aa = 0., ab = 0., bb = 0., ay = 0., by = 0., yy = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double w = sp.iW[j];
+        const double a = (double)c.r0[j], b = (double)c.dr[j];
+        const double y = sp.g[j] - (double)c.m[j];
+        const double aw = a * w, bw = b * w, yw = y * w;
+        ua += aw;
+        ub += bw;
+        uy += yw;
+        aa += a * aw;
+        ab += a * bw;
+        bb += b * bw;
+        ay += a * yw;
+        by += b * yw;
+        yy += y * yw;
+    }
+    G.ua = ua; G.ub = ub; G.uy = uy; G.aa = aa; G.ab = ab; G.bb = bb;
+    G.ay = ay; G.by = by; G.yy = yy;
+}
+
+// One sweep of fitting.py:176-243 on the Gram scalars.  res = y - av*(a + rv*b).
+__device__ __forceinline__ void gram_sweep(const Gram &G, double S, const DevParams &p, double &av,
+                                           double &rv, double &dav_o, double &drv_o,
+                                           double &logwt) {
+    const double uR = G.ua + rv * G.ub;                       // sum w R
+    const double RR = G.aa + rv * (2. * G.ab + rv * G.bb);    // sum w R^2
+    const double yR = G.ay + rv * G.by;                       // sum w y R
+    double rs = G.uy - av * uR;                               // sum w res
+    const double ra = (yR - av * RR) + (p.av_mean - av) * p.av_ivar;
+    const double a_den = RR + p.av_ivar;
+    double dav = (S * ra - uR * rs) / (S * a_den - uR * uR);
+    if (dav < p.avmin - av) dav = p.avmin - av;
+    if (dav > p.avmax - av) dav = p.avmax - av;
+    av = av + dav;
+    const double r_den = G.bb * av * av + p.rv_ivar;
+    const double sr = G.ub * av;
+    rs = G.uy - av * uR;
+    const double bres = G.by - av * (G.ab + rv * G.bb);       // sum w res b
+    const double rr = av * bres + (p.rv_mean - rv) * p.rv_ivar;
+    double drv = (S * rr - sr * rs) / (S * r_den - sr * sr);
+    if (drv < p.rvmin - rv) drv = p.rvmin - rv;
+    if (drv > p.rvmax - rv) drv = p.rvmax - rv;
+    rv = rv + drv;
+    const double RR2 = G.aa + rv * (2. * G.ab + rv * G.bb);
+    const double yR2 = G.ay + rv * G.by;
+    const double chi2 = G.yy - av * (2. * yR2 - av * RR2);
+    dav_o = dav;
+    drv_o = drv;
+    logwt = -0.5 * chi2;
+}
+
+// MLE quantities as mle_eval, with F = F0 * 10^(-0.4 av R) through fast_exp10.
+template <int NB, bool TBL>
+__device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[NB],
+                                         const StarPrep &sp, const DevParams &p, double av,
+                                         double rv, const double *__restrict__ tbl, Mle &o) {
+    const double fac = -0.92103403719761827361;
+    const double mav = -0.4 * av;
+    double F[NB];
+    double s_num = 0., s_den = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double R = (double)c.r0[j] + rv * (double)c.dr[j];
+        const double f = F0[j] * (TBL ? fast_exp10(mav * R, tbl) : poly_exp10(mav * R));
+        F[j] = f;
+        const double fw = f * sp.iV[j];
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    double sr_mix = 0., sa_mix = 0., ar_mix = 0., a_den = 0., r_den = 0.;
+    double a_num = 0., r_num = 0., chi2 = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double iv = sp.iV[j];
+        const double D0 = (double)c.dr[j];
+        const double R0 = (double)c.r0[j] + rv * D0;
+        const double ff = fac * F[j];
+        double Rf = R0 * ff;
+        double Df = D0 * ff;
+        double red = F[j] - F0[j];
+        const double Fs = F[j] * s;
+        const double res = sp.d[j] - Fs;
+        const double t = (Fs - res) * iv;
+        sr_mix += Df * t;
+        sa_mix += Rf * t;
+        Rf *= s;
+        Df *= s;
+        red *= s;
+        ar_mix += Df * ((red - res) * iv);
+        a_den += Rf * Rf * iv;
+        r_den += Df * Df * iv;
+        const double rw = res * iv;
+        a_num += Rf * rw;
+        r_num += Df * rw;
+        chi2 += res * rw;
+    }
+    o.a_ss = a_den;
+    o.r_ss = r_den;
+    o.a_num = a_num;
+    o.r_num = r_num;
+    a_den += p.av_ivar;
+    r_den += p.rv_ivar;
+    a_den += p.a_reg;
+    r_den += p.r_reg;
+    o.scale = s;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = sa_mix;
+    o.i02 = sr_mix;
+    o.i11 = a_den;
+    o.i12 = ar_mix;
+    o.i22 = r_den;
+}
+
+// ---- pinned Rv (rvlim[0] == rvlim[1] == rv_gauss[0], BASELINE configs[1]) ----
+// The Rv step of every sweep is clamped to zero, so R_j = r0_j + rv dr_j is a
+// per-model constant and the magnitude phase is a 2-parameter (offset, Av)
+// problem: five weighted inner products of {1, R, y} instead of nine, and only
+// the Av half of a sweep.  Same formulas as gram_init / gram_sweep with rv fixed;
+// the Rv rows of the precision matrix are still reported (mle_fast_rf<FULL>).
+struct GramR {
+    double uR, RR, yR, uy, yy;
+};
+
+template <int NB>
+__device__ __forceinline__ void coef_R(const Coef<NB> &c, double rv, double (&R)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) R[j] = (double)c.r0[j] + rv * (double)c.dr[j];
+}
+
+template <int NB>
+__device__ __forceinline__ void gram_init_rf(const Coef<NB> &c, const double (&R)[NB],
+                                             const StarPrep &sp, GramR &G) {
+    double uR = 0., RR = 0., yR = 0., uy = 0., yy = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double w = sp.iW[j];
+        const double y = sp.g[j] - (double)c.m[j];
+        const double Rw = R[j] * w, yw = y * w;
+        uR += Rw;
+        RR += R[j] * Rw;
+        yR += R[j] * yw;
+        uy += yw;
+        yy += y * yw;
+    }
+    G.uR = uR; G.RR = RR; G.yR = yR; G.uy = uy; G.yy = yy;
+}
+
+// The Av half of fitting.py:176-243 (the Rv half moves nothing when rvmin == rvmax).
+__device__ __forceinline__ void gram_sweep_rf(const GramR &G, double S, const DevParams &p,
+                                              double &av, double &dav_o, double &logwt) {
+    const double rs = G.uy - av * G.uR;
+    const double ra = (G.yR - av * G.RR) + (p.av_mean - av) * p.av_ivar;
+    const double a_den = G.RR + p.av_ivar;
+    double dav = (S * ra - G.uR * rs) / (S * a_den - G.uR * G.uR);
+    if (dav < p.avmin - av) dav = p.avmin - av;
+    if (dav > p.avmax - av) dav = p.avmax - av;
+    av = av + dav;
+    const double chi2 = G.yy - av * (2. * G.yR - av * G.RR);
+    dav_o = dav;
+    logwt = -0.5 * chi2;
+}
+
+// mle_fast with R given.  FULL = false leaves out the Rv sums (i02, i12, i22,
+// r_num, r_ss), which only the reported precision matrix needs.
+template <int NB, bool TBL, bool FULL>
+__device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)[NB],
+                                            const double (&F0)[NB], const StarPrep &sp,
+                                            const DevParams &p, double av,
+                                            const double *__restrict__ tbl, Mle &o) {
+    const double fac = -0.92103403719761827361;
+    const double mav = -0.4 * av;
+    double F[NB];
+    double s_num = 0., s_den = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double f = F0[j] * (TBL ? fast_exp10(mav * R[j], tbl) : poly_exp10(mav * R[j]));
+        F[j] = f;
+        const double fw = f * sp.iV[j];
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    double sr_mix = 0., sa_mix = 0., ar_mix = 0., a_den = 0., r_den = 0.;
+    double a_num = 0., r_num = 0., chi2 = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double iv = sp.iV[j];
+        const double ff = fac * F[j];
+        double Rf = R[j] * ff;
+        const double Fs = F[j] * s;
+        const double res = sp.d[j] - Fs;
+        const double t = (Fs - res) * iv;
+        sa_mix += Rf * t;
+        Rf *= s;
+        a_den += Rf * Rf * iv;
+        const double rw = res * iv;
+        a_num += Rf * rw;
+        chi2 += res * rw;
+        if (FULL) {
+            double Df = (double)c.dr[j] * ff;
+            sr_mix += Df * t;
+            Df *= s;
+            const double red = (F[j] - F0[j]) * s;
+            ar_mix += Df * ((red - res) * iv);
+            r_den += Df * Df * iv;
+            r_num += Df * rw;
+        }
+    }
+    o.a_ss = a_den;
+    o.r_ss = r_den;
+    o.a_num = a_num;
+    o.r_num = r_num;
+    a_den += p.av_ivar;
+    r_den += p.rv_ivar;
+    a_den += p.a_reg;
+    r_den += p.r_reg;
+    o.scale = s;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = sa_mix;
+    o.i02 = sr_mix;
+    o.i11 = a_den;
+    o.i12 = ar_mix;
+    o.i22 = r_den;
+}
+
+// F0 of model i from the band-major table (coalesced) / of one model from its row.
+template <int NB>
+__device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t nmodel_pad,
+                                        int64_t i, double (&F0)[NB]) {
+    const double *t = reinterpret_cast<const double *>(grid + (int64_t)6 * NB * nmodel_pad);
+#pragma unroll
+    for (int j = 0; j < NB; ++j) F0[j] = t[(int64_t)j * nmodel_pad + i];
+}
+// The gather kernels are close to memory-bound and VGPR-limited, so they
+// recompute F0 with the table-free polynomial (<= 1 ulp from the tabulated
+// value) instead of reading 8*NB more bytes per model.
+template <int NB>
+__device__ __forceinline__ void compute_F0_fast(const Coef<NB> &c, double (&F0)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) F0[j] = poly_exp10(-0.4 * (double)c.m[j]);
+}
+
+// lnl as `loglike` returns it for a model the cull dropped / kept, and the
+// first-cut statistic lnprob (fitting.py:806-815, 976-985; pdf.py:209-218).
+__device__ __forceinline__ double final_lnl(const StarPrep &sp, const DevParams &p, double chi2,
+                                            bool survivor) {
+    if (p.dim_prior) return chi2 > 0. ? sp.c0 + sp.c1 * log(chi2) - chi2 / 2. : -INFINITY;
+    return survivor ? -0.5 * chi2 + sp.lnl_const : -0.5 * chi2;
+}
+__device__ __forceinline__ double first_cut_lnprob(const StarPrep &sp, double lnl, double scale,
+                                                   double i00) {
+    double lnprob = lnl;
+    if (sp.sp_on) {
+        const double serr2 = 1. / fabs(i00);
+        const double vt = sp.sp_var + serr2;
+        const double ds = scale - sp.sp_mean;
+        lnprob = lnl + -0.5 * (ds * ds / vt + log(2. * M_PI * vt));
+    }
+    if (!isfinite(lnprob)) lnprob = -BIG;
+    return lnprob;
+}
+
+// FS_G = stars per workgroup of the fused scan (LDS: FS_G * NV * 2 KiB)
+
+// Fused full-grid scan.  grid = (ceil(ntile / tiles_per_block), ceil(nrun / FS_G)).
+//   FS_G             stars per workgroup (LDS = FS_G * NV * 2 KiB)
+//   star_ids[nrun]   stars (indices into `stars`) handled by this launch
+//   kfix[star]       number of magnitude sweeps before the MLE
+// Per (block.x, star) emits NV = 2*KS + 2 maxima into part[(bx * nstar + star) * NV + v]:
+//   v = 2k, 2k+1 : L_k, T_k for sweep k < KS   (only sweeps <= kfix are run)
+//   v = 2KS      : max lnl_p;  v = 2KS+1 : max lnprob_ns
+//   RVF              pinned-Rv specialisation (see GramR)
+template <int NB, int KS, int FS_G, bool RVF>
+__global__ void __launch_bounds__(TILE, 3)   // <=168 VGPRs: 3 waves/SIMD (LDS allows 3 blocks/CU)
+k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+        const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
+        const int32_t *__restrict__ kfix, int tiles_per_block, int ntile, Planes pl,
+        double *__restrict__ part) {
+    constexpr int NV = 2 * KS + 2;
+    extern __shared__ double smax[];   // [FS_G][NV][TILE]
+    __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    const int g0 = blockIdx.y * FS_G;
+    const int ng = min(FS_G, nrun - g0);
+    for (int q = threadIdx.x; q < FS_G * NV * TILE; q += TILE) smax[q] = -INFINITY;
+    // each thread only ever touches its own column of smax: no barrier needed
+    const int t0 = blockIdx.x * tiles_per_block;
+    const int t1 = min(ntile, t0 + tiles_per_block);
+    for (int t = t0; t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        const bool live = i < nmodel;
+        Coef<NB> c;
+        load_coef<NB>(grid, nmodel_pad, i, c);
+        double F0[NB];
+        load_F0<NB>(grid, nmodel_pad, i, F0);
+        double R[RVF ? NB : 1];
+        if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
+        for (int g = 0; g < ng; ++g) {
+            const int s = star_ids[g0 + g];
+            const StarPrep &sp = stars[s];
+            double av = p.av_mean, rv = p.rv_mean;
+            const int K = kfix[s];
+            double *col = smax + (size_t)g * NV * TILE + threadIdx.x;
+            Mle m;
+            if constexpr (RVF) {
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double dav, lw;
+                    gram_sweep_rf(G, sp.S, p, av, dav, lw);
+                    if (k < KS && live && lw == lw) {
+                        double *c0 = col + (size_t)(2 * k) * TILE;
+                        if (lw > c0[0]) c0[0] = lw;
+                        if (fabs(dav) >= p.mtol && lw > c0[TILE]) c0[TILE] = lw;
+                    }
+                }
+                mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
+            } else {
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double dav, drv, lw;
+                    gram_sweep(G, sp.S, p, av, rv, dav, drv, lw);
+                    if (k < KS && live && lw == lw) {
+                        const bool big = (fabs(dav) >= p.mtol) || (fabs(drv) >= p.mtol);
+                        double *c0 = col + (size_t)(2 * k) * TILE;
+                        if (lw > c0[0]) c0[0] = lw;
+                        if (big && lw > c0[TILE]) c0[TILE] = lw;
+                    }
+                }
+                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+            }
+            const double lnl = -0.5 * m.chi2;
+            double lnlp = lnl;
+            if (sp.has_par) {
+                const double dp = sqrt(m.scale) - sp.par;
+                lnlp = lnl - 0.5 * (dp * dp * sp.par_ivar);
+            }
+            const double lnprob =
+                first_cut_lnprob(sp, final_lnl(sp, p, m.chi2, false), m.scale, m.i00);
+            if (live) {
+                const int64_t o = (int64_t)s * pl.nmodel + i;
+                pl.lnlp[o] = lnlp;
+                pl.lnprob[o] = lnprob;
+                double *c0 = col + (size_t)(2 * KS) * TILE;
+                if (lnlp > c0[0]) c0[0] = lnlp;          // NaN never wins
+                if (lnprob > c0[TILE]) c0[TILE] = lnprob;
+            }
+        }
+    }
+    for (int g = 0; g < ng; ++g) {
+        const int s = star_ids[g0 + g];
+        for (int v = 0; v < NV; ++v)
+            block_max_store(smax[((size_t)g * NV + v) * TILE + threadIdx.x], slot,
+                            part + ((int64_t)blockIdx.x * nstar + s) * NV + v);
+    }
+}
+
+// Reduce the fused-scan partials of the stars in `star_ids` and decide.
+//   accept == 0: derive K1 from (L_k, T_k); k1[s] = K1 (0 = not converged in KS)
+//   always: thr_cull[s] = max lnl_p + ln(init_thresh);  maxns[s] = max lnprob_ns
+__global__ void k_fdecide(int nblkx, int nstar, int nrun, const int32_t *__restrict__ star_ids,
+                          int KS, const double *__restrict__ part, DevParams p, int accept,
+                          int32_t *__restrict__ k1, double *__restrict__ thr_cull,
+                          double *__restrict__ maxns) {
+    __shared__ double sm[KCAP * 2 + 2][4];
+    const int s = star_ids[blockIdx.x];
+    const int NV = 2 * KS + 2;
+    double v[KCAP * 2 + 2];
+    for (int q = 0; q < NV; ++q) v[q] = -INFINITY;
+    for (int b = threadIdx.x; b < nblkx; b += blockDim.x) {
+        const double *pp = part + ((int64_t)b * nstar + s) * NV;
+        for (int q = 0; q < NV; ++q) v[q] = pp[q] > v[q] ? pp[q] : v[q];
+    }
+    for (int q = 0; q < NV; ++q) {
+        const double m = wave_max(v[q]);
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int q = 0; q < NV; ++q) {
+        double m = sm[q][0];
+        for (int w = 1; w < 4; ++w) m = sm[q][w] > m ? sm[q][w] : m;
+        v[q] = m;
+    }
+    if (!accept) {
+        int K1 = 0;
+        for (int k = 0; k < KS; ++k) {
+            const double L = v[2 * k] > -BIG ? v[2 * k] : -BIG;
+            if (!(v[2 * k + 1] > L + p.ln_init)) {
+                K1 = k + 1;
+                break;
+            }
+        }
+        k1[s] = K1;
+    }
+    thr_cull[s] = v[2 * KS] + p.ln_init;
+    maxns[s] = v[2 * KS + 1];
+}
+
+// Ordered compaction of one (nstar, nmodel) plane against a per-star threshold:
+// {i : plane[s][i] > thr[s]}.  grid = (NCHUNK, nstar).  Optionally also the
+// maximum of `other[s][i]` over the complement (models that fail the test).
+__global__ void __launch_bounds__(TILE)
+k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
+            const double *__restrict__ thr, const double *__restrict__ other,
+            int64_t *__restrict__ counts, double *__restrict__ other_max,
+            unsigned long long *__restrict__ mask) {
+    __shared__ int wsum[4];
+    __shared__ double slot[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
+    const double th = thr[s];
+    int n = 0;
+    double om = -INFINITY;
+    for (int t = t0; t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        bool hit = false;
+        if (i < nmodel) {
+            const int64_t o = (int64_t)s * nmodel + i;
+            if (plane[o] > th) {
+                hit = true;
+                ++n;
+            } else if (other) {
+                const double x = other[o];
+                if (x > om) om = x;
+            }
+        }
+        // one 64-bit membership word per wave: the scatter pass reads these
+        // instead of the 8-byte-per-model plane
+        const unsigned long long b = __ballot(hit);
+        if ((threadIdx.x & 63) == 0)
+            mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (other) block_max_store(om, slot, other_max + (int64_t)s * NCHUNK + c);
+}
+
+// Exclusive scan of counts[(s, c)] in (s, c) order; one workgroup, thread s owns star s.
+//   offsets[(s, c)], star_off[s] (star_off[nstar] = total), wbase[s] = first work
+//   item of star s when its list is cut into TILE-sized work items (wbase[nstar] = #items).
+__global__ void k_offsets(int nstar, const int64_t *__restrict__ counts,
+                          int64_t *__restrict__ offsets, int64_t *__restrict__ star_off,
+                          int32_t *__restrict__ wbase) {
+    __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
+    const int s = threadIdx.x;
+    int64_t n = 0;
+    if (s < nstar)
+        for (int c = 0; c < NCHUNK; ++c) n += counts[(int64_t)s * NCHUNK + c];
+    if (s < nstar) tot[s] = n;
+    __syncthreads();
+    if (s == 0) {
+        int64_t run = 0;
+        int32_t w = 0;
+        for (int q = 0; q < nstar; ++q) {
+            const int64_t m = tot[q];
+            tot[q] = run;
+            star_off[q] = run;
+            if (wbase) wbase[q] = w;
+            run += m;
+            w += (int32_t)((m + TILE - 1) / TILE);
+        }
+        star_off[nstar] = run;
+        if (wbase) wbase[nstar] = w;
+    }
+    __syncthreads();
+    if (s < nstar) {
+        int64_t run = tot[s];
+        for (int c = 0; c < NCHUNK; ++c) {
+            offsets[(int64_t)s * NCHUNK + c] = run;
+            run += counts[(int64_t)s * NCHUNK + c];
+        }
+    }
+}
+
+__global__ void __launch_bounds__(TILE)
+k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ mask,
+              const int64_t *__restrict__ offsets, int64_t capacity,
+              int32_t *__restrict__ out_idx) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
+    int64_t base = offsets[(int64_t)s * NCHUNK + c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int t = t0; t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        const unsigned long long b = mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + w];
+        const bool sel = (b >> lane) & 1ull;
+        const int rank = __popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(b);
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < w; ++q) woff += wsum[q];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (sel) {
+            const int64_t r = base + woff + rank;
+            if (r < capacity) out_idx[r] = (int32_t)i;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+// Map a work item (TILE consecutive entries of one star's compact list) to its star.
+__device__ __forceinline__ int star_of_item(const int32_t *__restrict__ wbase, int nstar, int item) {
+    int lo = 0, hi = nstar;   // largest s with wbase[s] <= item
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (wbase[mid] <= item) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+// Coefficients of ONE model from the model-major copy: 3*NB/4 16-byte loads.
+template <int NB>
+__device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int64_t nmodel_pad,
+                                            int64_t i, Coef<NB> &c) {
+    const float4 *row =
+        reinterpret_cast<const float4 *>(grid + (int64_t)3 * NB * nmodel_pad + i * (3 * NB));
+    float t[3 * NB];
+#pragma unroll
+    for (int q = 0; q < 3 * NB / 4; ++q) {
+        const float4 v = row[q];
+        t[4 * q] = v.x;
+        t[4 * q + 1] = v.y;
+        t[4 * q + 2] = v.z;
+        t[4 * q + 3] = v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        c.m[j] = t[3 * j];
+        c.r0[j] = t[3 * j + 1];
+        c.dr[j] = t[3 * j + 2];
+    }
+}
+
+// Flux phase on the compact survivor lists (fitting.py:758-803), persistent
+// workgroups looping over work items.  First launch: rebuild (av, rv) from K1
+// sweeps, two iterations from lnl_old = -1e300; continuation: one iteration from
+// the state planes.  Writes the state/result planes at the survivors' positions
+// and, per work item, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
+// M = max final lnprob.
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(TILE, 2)
+k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
+        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
+        const int32_t *__restrict__ k2state, int first, const int32_t *__restrict__ surv_idx,
+        const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
+        double *__restrict__ part) {
+    __shared__ double slot[4];
+    const int nitem = wbase[nstar];
+    const int niter = first ? 2 : 1;
+    for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
+        const int s = star_of_item(wbase, nstar, item);
+        if (k2state[s] < 0) continue;
+        const StarPrep &sp = stars[s];
+        const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
+        const bool live = q < surv_off[s + 1];
+        double L = -INFINITY, T = -INFINITY, M = -INFINITY;
+        if (live) {
+            const int64_t i = surv_idx[q];
+            const int64_t o = (int64_t)s * pl.nmodel + i;
+            Coef<NB> c;
+            gather_coef<NB>(grid, nmodel_pad, i, c);
+            double F0[NB];
+            compute_F0_fast<NB>(c, F0);
+            double av, rv, step, lnl_old;
+            double R[RVF ? NB : 1];
+            if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
+            if (first) {
+                av = p.av_mean;
+                rv = p.rv_mean;
+                const int K = k1[s];
+                if constexpr (RVF) {
+                    GramR G;
+                    gram_init_rf<NB>(c, R, sp, G);
+                    for (int k = 0; k < K; ++k) {
+                        double a_, c_;
+                        gram_sweep_rf(G, sp.S, p, av, a_, c_);
+                    }
+                } else {
+                    Gram G;
+                    gram_init<NB>(c, sp, G);
+                    for (int k = 0; k < K; ++k) {
+                        double a_, b_, c_;
+                        gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                    }
+                }
+                step = 1.0;
+                lnl_old = -BIG;
+            } else {
+                av = pl.av[o];
+                rv = pl.rv[o];
+                step = pl.step[o];
+                lnl_old = -0.5 * pl.chi2[o];
+            }
+            Mle m;
+            if constexpr (RVF) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
+            else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            double lnl_new = lnl_old, dl = 0.;
+            for (int it = 0; it < niter; ++it) {
+                double dav = (m.a_num + (p.av_mean - av) * p.av_ivar) / (m.a_ss + p.av_ivar) * step;
+                if (dav < p.avmin - av) dav = p.avmin - av;
+                if (dav > p.avmax - av) dav = p.avmax - av;
+                av += dav;
+                if constexpr (RVF) {
+                    // the Rv step is clamped to zero; only the stored MLE needs the Rv sums
+                    if (it + 1 < niter) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
+                    else mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+                } else {
+                    double drv = (m.r_num + (p.rv_mean - rv) * p.rv_ivar) / (m.r_ss + p.rv_ivar) * step;
+                    if (drv < p.rvmin - rv) drv = p.rvmin - rv;
+                    if (drv > p.rvmax - rv) drv = p.rvmax - rv;
+                    rv += drv;
+                    mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+                }
+                lnl_new = -0.5 * m.chi2;
+                dl = fabs(lnl_new - lnl_old);
+                if (lnl_new < lnl_old) step /= 1.2;
+                lnl_old = lnl_new;
+            }
+            store_mle(pl, o, m);
+            pl.av[o] = av;
+            pl.rv[o] = rv;
+            pl.step[o] = step;
+            const double lnl = final_lnl(sp, p, m.chi2, true);
+            const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
+            pl.lnl[o] = lnl;
+            pl.lnprob[o] = lnprob;
+            M = lnprob;
+            if (lnl_new == lnl_new) {
+                L = lnl_new;
+                if (dl > p.ltol) T = lnl_new;
+            }
+        }
+        double *out = part + (int64_t)item * 3;
+        block_max_store(L, slot, out);
+        block_max_store(T, slot, out + 1);
+        block_max_store(M, slot, out + 2);
+    }
+}
+
+// Per-star flux decision over the star's work items (one workgroup per star).
+__global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
+                               const double *__restrict__ part, double ln_sub,
+                               int32_t *__restrict__ k2state, double *__restrict__ maxsurv,
+                               int32_t *__restrict__ n_unconv) {
+    __shared__ double sm[3][4];
+    const int s = blockIdx.x;
+    if (k2state[s] < 0) return;
+    double v[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int it = wbase[s] + threadIdx.x; it < wbase[s + 1]; it += blockDim.x)
+        for (int q = 0; q < 3; ++q) {
+            const double x = part[(int64_t)it * 3 + q];
+            v[q] = x > v[q] ? x : v[q];
+        }
+    for (int q = 0; q < 3; ++q) {
+        const double m = wave_max(v[q]);
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = m;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int q = 0; q < 3; ++q) {
+        double m = sm[q][0];
+        for (int w = 1; w < 4; ++w) m = sm[q][w] > m ? sm[q][w] : m;
+        v[q] = m;
+    }
+    maxsurv[s] = v[2];
+    if (v[1] > v[0] + ln_sub) {      // lerr > ltol (fitting.py:798-799)
+        k2state[s] += 1;
+        atomicAdd(n_unconv, 1);
+    } else {
+        k2state[s] = -k2state[s] - 1;
+    }
+}
+
+__global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
+                             const double *__restrict__ maxsurv, double ln_wt,
+                             double *__restrict__ thr_sel) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstar) return;
+    // maximum of the final lnprob plane: survivors (flux phase) and the rest
+    double m = maxsurv[s];
+    for (int c = 0; c < NCHUNK; ++c) {
+        const double x = maxns_part[(int64_t)s * NCHUNK + c];
+        m = x > m ? x : m;
+    }
+    thr_sel[s] = m + ln_wt;
+}
+
+// Emit the records of the selected models (ordered lists from k_cmp_scatter).
+// Survivors of the cull are read from the result planes; the others are
+// re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
+// full-grid scan write eleven planes.
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(TILE, 2)
+k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
+       const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
+       const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
+       const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
+       int64_t capacity, double *__restrict__ sel_vals) {
+    const int nitem = wbase[nstar];
+    for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
+        const int s = star_of_item(wbase, nstar, item);
+        const StarPrep &sp = stars[s];
+        const int64_t q = sel_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
+        if (q >= sel_off[s + 1] || q >= capacity) continue;
+        const int64_t i = sel_idx[q];
+        const int64_t o = (int64_t)s * pl.nmodel + i;
+        double rec[BRUTUS_NVALS];
+        if (pl.lnlp[o] > thr_cull[s]) {
+            rec[0] = pl.lnl[o];
+            rec[1] = pl.chi2[o];
+            rec[2] = pl.scale[o];
+            rec[3] = pl.av[o];
+            rec[4] = pl.rv[o];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rec[5 + k] = pl.icov[k][o];
+        } else {
+            Coef<NB> c;
+            gather_coef<NB>(grid, nmodel_pad, i, c);
+            double F0[NB];
+            compute_F0_fast<NB>(c, F0);
+            double av = p.av_mean, rv = p.rv_mean;
+            const int K = k1[s];
+            Mle m;
+            if constexpr (RVF) {
+                double R[NB];
+                coef_R<NB>(c, rv, R);
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double a_, c_;
+                    gram_sweep_rf(G, sp.S, p, av, a_, c_);
+                }
+                mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+            } else {
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int k = 0; k < K; ++k) {
+                    double a_, b_, c_;
+                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                }
+                mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            }
+            rec[0] = final_lnl(sp, p, m.chi2, false);
+            rec[1] = m.chi2;
+            rec[2] = m.scale;
+            rec[3] = av;
+            rec[4] = rv;
+            rec[5] = m.i00;
+            rec[6] = m.i01;
+            rec[7] = m.i02;
+            rec[8] = m.i11;
+            rec[9] = m.i12;
+            rec[10] = m.i22;
+        }
+#pragma unroll
+        for (int k = 0; k < BRUTUS_NVALS; ++k) sel_vals[(int64_t)k * capacity + q] = rec[k];
+    }
+}
+
+}  // namespace

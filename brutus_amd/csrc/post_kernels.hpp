@@ -1,0 +1,865 @@
+// post_kernels.hpp -- device lnpost (second cut, MC prior integral, resampling) behind brutus_post_batch
+// Part of the single translation unit brutus_kernels.hip (included there, in
+// this order: common, fastmath, grid_kernels, fit_kernels, cluster_kernels,
+// post_kernels); everything lives in that unit's anonymous namespace.
+#pragma once
+
+namespace {
+
+// ===========================================================================
+// lnpost on the device (fitting.py:1000-1107 and the tail of _fit, :2021-2061)
+// for the built-in priors, with the counter-based random stream specified in
+// brutus_amd/rng.py (Philox4x32-7 + polar normals): any deviate is a pure
+// function of (seed, index), so every selected model of every object is
+// integrated in parallel and the result still equals, deviate for deviate, a
+// sequential run of the reference with that `rstate` object.
+// ===========================================================================
+struct Philox4 {
+    uint32_t w[4];
+};
+
+__device__ __forceinline__ Philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
+                                                uint32_t k0, uint32_t k1) {
+#pragma unroll
+    for (int r = 0; r < 7; ++r) {
+        if (r > 0) {
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        const uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;   // v_mad_u64_u32
+        const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+        const uint32_t n0 = hi1 ^ c1 ^ k0, n2 = hi0 ^ c3 ^ k1;
+        c0 = n0;
+        c1 = lo1;
+        c2 = n2;
+        c3 = lo0;
+    }
+    Philox4 o;
+    o.w[0] = c0; o.w[1] = c1; o.w[2] = c2; o.w[3] = c3;
+    return o;
+}
+
+__device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// q-th uniform of the uniform stream (rng.py: philox_uniform)
+__device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t q) {
+    const Philox4 o = philox4x32_7((uint32_t)q, (uint32_t)(q >> 32), 0u, 1u, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+    return u53(o.w[0], o.w[1]);
+}
+
+// candidate `retry` of pair p of the normal stream (rng.py: philox_normal);
+// true if the polar method accepts it
+__device__ __forceinline__ bool rng_polar_candidate(uint64_t seed, uint64_t p, uint32_t retry,
+                                                    double &x1, double &x2) {
+#pragma clang fp contract(off)   // r2 must round like numpy's x1*x1 + x2*x2 (accept/reject!)
+    const Philox4 o = philox4x32_7((uint32_t)p, (uint32_t)(p >> 32), retry, 0u, (uint32_t)seed,
+                                   (uint32_t)(seed >> 32));
+    x1 = 2.0 * u53(o.w[0], o.w[1]) - 1.0;
+    x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
+    const double r2 = x1 * x1 + x2 * x2;
+    return r2 < 1.0 && r2 > 0.0;
+}
+// the two normals of an accepted candidate
+__device__ __forceinline__ void rng_polar_finish(double x1, double x2, double &z0, double &z1) {
+#pragma clang fp contract(off)
+    const double r2 = x1 * x1 + x2 * x2;
+    // rng.py: f = sqrt(-2 ln(r2) / r2).  ln, the divide and the root are the ~1 ulp
+    // Newton forms (the accept / reject decision above is what must be exact): the
+    // normals agree with numpy's to a few ulp at a third of the IEEE sequences' cost.
+    const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
+    z0 = f * x1;
+    z1 = f * x2;
+}
+// pair p of the normal stream: z0 = normal 2p, z1 = normal 2p+1
+__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, double &z0, double &z1) {
+    // The retry loop only draws candidates (lanes of a wave retry in lockstep:
+    // ~3.5 rounds for 64 lanes at 21 % rejection); ln / sqrt / divide run once.
+    double x1, x2;
+    for (uint32_t retry = 0; !rng_polar_candidate(seed, p, retry, x1, x2); ++retry) {}
+    rng_polar_finish(x1, x2, z0, z1);
+}
+__device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t j) {
+    double z0, z1;
+    rng_normal_pair(seed, j >> 1, z0, z1);
+    return (j & 1) ? z1 : z0;
+}
+
+struct PostParams {     // mirrors brutus_post_params
+    int32_t nmc, ndraws, return_distreds, has_feh, has_loga, per_object;
+    double wt_thresh, avlim[2], rvlim[2];
+    int64_t nsel_max, object0;
+    uint64_t seed, normal_base, uniform_base;
+    double R_solar, Z_solar, R_thin, Z_thin, Rs_thin, R_thick, Z_thick, f_thick, Rs_thick;
+    double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
+    double feh_mean[3], feh_sigma[3];
+    double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+    // derived on the host side of the ABI call (not part of brutus_post_params)
+    double ln_f_thick, ln_f_halo, inv_reff_solar2;
+    double inv_R_thin, inv_Z_thin, inv_R_thick, inv_Z_thick, inv_r_q;
+    double Rs_thin2, Rs_thick2, Rs_halo2, rq2, abs_Z_solar;
+    double lnK, c0_thin, c0_thick, c0_halo;      // component constants relative to lnK
+};
+constexpr int POST_DERIVED = 17;
+
+// stream key and uniform base of object s: one shared sequential stream, or
+// (per_object) an own stream keyed seed + object index
+__device__ __forceinline__ uint64_t star_seed(const PostParams &pp, int s) {
+    return pp.per_object ? pp.seed + (uint64_t)(pp.object0 + s) : pp.seed;
+}
+__device__ __forceinline__ uint64_t star_ubase(const PostParams &pp, int s) {
+    return pp.per_object ? 0ull
+                         : pp.uniform_base + (uint64_t)s * (uint64_t)(pp.ndraws * (pp.return_distreds ? 2 : 1));
+}
+
+struct StarGeom {      // per object: sightline unit vector and parallax
+    double cb_cl, cb_sl, sb;     // cos b cos l, cos b sin l, sin b
+    double par, par_ivar, par_lnorm;
+    int has_par;
+};
+
+__device__ __forceinline__ double lse3(double a, double b, double c) {
+    double m = a > b ? a : b;
+    m = c > m ? c : m;
+    if (!(m > -INFINITY)) return m;          // all -inf (or NaN)
+    return log(exp(a - m) + exp(b - m) + exp(c - m)) + m;
+}
+
+// per-model metallicity / age densities of the three components (pdf.py:380-473),
+// as plain (not log) values: e^F_c, e^A_c
+__device__ __forceinline__ void label_terms(const PostParams &pp, double feh, double loga,
+                                            double (&Fc)[3], double (&Ac)[3]) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+        Fc[c] = 1.;
+        Ac[c] = 1.;
+        if (pp.has_feh) {
+            const double d = pp.feh_mean[c] - feh;
+            Fc[c] = exp(-0.5 * (d * d / (pp.feh_sigma[c] * pp.feh_sigma[c]) +
+                                log(2. * M_PI * pp.feh_sigma[c] * pp.feh_sigma[c])));
+        }
+        if (pp.has_loga) {
+            const double age = exp10(loga) / 1e9;
+            const double xi = (age - pp.age_mean[c]) / pp.age_sigma[c];
+            Ac[c] = (age < pp.min_age || age > pp.max_age)
+                        ? 0.
+                        : exp(-0.91893853320467274178 - 0.5 * xi * xi - pp.age_lnnorm[c]);
+        }
+    }
+}
+
+// gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc],
+// as a plain density relative to e^lnK: gal_lnprior = lnK + ln(gal_prior_lin).
+// With T_c = exp(comp_c - lnK) the three log-sum-exps of the reference collapse:
+//   lse(comp) + [lse(F + comp) - lse(comp)] + [lse(A + comp) - lse(comp)]
+//     = lnK + ln( (sum T_c e^F_c) (sum T_c e^A_c) / sum T_c )
+// EF_c = e^F_c, EA_c = e^A_c are per-model constants.  lnK (fill_post_params) is
+// an upper bound of every comp_c, so no T_c overflows, and the halo's power law
+// keeps the sum away from underflow at any distance: no running maximum needed.
+// Cost per call: 3 exp + 1 log (halo power) + 3 sqrt + 2 reciprocals.
+__device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const StarGeom &g, double d,
+                                                const double (&EF)[3], const double (&EA)[3],
+                                                const double *__restrict__ tbl) {
+    const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
+    const double R2 = x * x + y * y;
+    const double dZ = fabs(Z) - pp.abs_Z_solar;
+    const double Rt = fast_sqrt(R2 + pp.Rs_thin2);
+    const double Rk = pp.Rs_thick2 == pp.Rs_thin2 ? Rt : fast_sqrt(R2 + pp.Rs_thick2);
+    // thin / thick disk: exp(-(R - R_sun)/R_c - (|Z| - |Z_sun|)/Z_c [+ ln f] - lnK)
+    const double T0 = fast_exp_bf(pp.c0_thin - (Rt * pp.inv_R_thin + dZ * pp.inv_Z_thin), tbl);
+    const double T1 = fast_exp_bf(pp.c0_thick - (Rk * pp.inv_R_thick + dZ * pp.inv_Z_thick), tbl);
+    // halo: f (reff / reff_sun)^-eta, reff^2 = R^2 + (Z/q)^2 + Rs^2, q(r) (pdf.py:341-365)
+    const double q = pp.q_halo_inf -
+                     (pp.q_halo_inf - pp.q_halo_ctr) *
+                         fast_exp_bf(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
+    const double zq = Z * fast_rcp(q);
+    const double T2 = fast_exp_bf(
+        pp.c0_halo - 0.5 * pp.eta_halo * fast_log_r((R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2), tbl);
+    double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
+    if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
+    if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
+    const double S = T0 + T1 + T2;
+    const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
+    // divide by S^(npow - 1): one S stays for lse(comp) itself
+    if (npow == 2) num *= fast_rcp(S);
+    else if (npow == 0) num *= S;
+    return num;
+}
+__device__ __forceinline__ double gal_lnprior_dev(const PostParams &pp, const StarGeom &g, double d,
+                                                  const double (&EF)[3], const double (&EA)[3],
+                                                  const double *__restrict__ tbl) {
+    return pp.lnK + fast_log_r(gal_prior_lin(pp, g, d, EF, EA, tbl));
+}
+
+constexpr int PCH = 64;      // chunks per object for the record passes
+
+// first membership word of object s (objects' 256-record tiles do not share words)
+__device__ __forceinline__ int64_t mask_base(const int64_t *__restrict__ off, int s) {
+    return ((off[s] + 63) >> 6) + 8 * (int64_t)s;
+}
+
+// record range of workgroup (chunk c, star s): 256-aligned slices of [off[s], off[s+1])
+__device__ __forceinline__ void rec_range(const int64_t *__restrict__ off, int s, int c, int64_t &a,
+                                          int64_t &b) {
+    const int64_t lo = off[s], n = off[s + 1] - lo;
+    const int64_t ntile = (n + TILE - 1) / TILE;
+    a = lo + (ntile * c / PCH) * TILE;
+    b = lo + (ntile * (c + 1) / PCH) * TILE;
+    if (b > lo + n) b = lo + n;
+    if (a > lo + n) a = lo + n;
+}
+
+__device__ __forceinline__ void rec_range_n(int64_t lo, int64_t n, int c, int64_t &a, int64_t &b) {
+    const int64_t ntile = (n + TILE - 1) / TILE;
+    a = lo + (ntile * c / PCH) * TILE;
+    b = lo + (ntile * (c + 1) / PCH) * TILE;
+    if (b > lo + n) b = lo + n;
+    if (a > lo + n) a = lo + n;
+}
+
+// P1: lnp of the MLE point for the second cut (fitting.py:1000-1010)
+__global__ void __launch_bounds__(TILE)
+k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
+            const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+            const StarGeom *__restrict__ geom, const double *__restrict__ lnprior,
+            const double *__restrict__ feh, const double *__restrict__ loga,
+            double *__restrict__ lnp1, double *__restrict__ part) {
+    __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    const int s = blockIdx.y, c = blockIdx.x;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    const StarGeom g = geom[s];
+    double m = -INFINITY;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        if (r < b) {
+            const int64_t i = sel_idx[r];
+            double Fc[3], Ac[3];
+            label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+            const double scale = sel_vals[2 * cap + r];
+            const double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, 1. / sqrt(scale), Fc, Ac, s_tbl);
+            lnp1[r] = v;
+            if (v > m) m = v;
+        }
+    }
+    block_max_store(m, slot, part + (int64_t)s * PCH + c);
+}
+
+// P2a: second cut (fitting.py:1013-1016): count + membership words
+__global__ void __launch_bounds__(TILE)
+k_post_count2(double ln_wt, const int64_t *__restrict__ sel_off, const double *__restrict__ lnp1,
+              const double *__restrict__ part, int64_t *__restrict__ counts,
+              unsigned long long *__restrict__ mask) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    double mx = -INFINITY;
+    for (int q = 0; q < PCH; ++q) {
+        const double v = part[(int64_t)s * PCH + q];
+        mx = v > mx ? v : mx;
+    }
+    const double thr = mx + ln_wt;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    int n = 0;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        const bool hit = r < b && lnp1[r] > thr;
+        n += hit ? 1 : 0;
+        const unsigned long long bl = __ballot(hit);
+        if ((threadIdx.x & 63) == 0)
+            mask[mask_base(sel_off, s) + ((r0 - sel_off[s]) >> 6) + (threadIdx.x >> 6)] = bl;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)s * PCH + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// P2b: offsets of the second-cut lists; normal-stream base of every object
+// (3 * nmc normals per kept model, objects in order: exactly what a sequential
+// rstate would have consumed), host-fallback flags.
+__global__ void k_post_offsets(PostParams pp, int nstar, const int64_t *__restrict__ counts,
+                               int64_t *__restrict__ offsets, int64_t *__restrict__ off2,
+                               uint64_t *__restrict__ nbase, int32_t *__restrict__ flags,
+                               int64_t *__restrict__ nsel) {
+    __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
+    const int s = threadIdx.x;
+    int64_t n = 0;
+    if (s < nstar)
+        for (int c = 0; c < PCH; ++c) n += counts[(int64_t)s * PCH + c];
+    if (s < nstar) tot[s] = n;
+    __syncthreads();
+    if (s == 0) {
+        int64_t run = 0;
+        uint64_t nb = pp.normal_base;
+        for (int q = 0; q < nstar; ++q) {
+            const int64_t m = tot[q];
+            tot[q] = run;
+            off2[q] = run;
+            nbase[q] = pp.per_object ? 0ull : nb;
+            const int64_t used = m > pp.nsel_max ? pp.nsel_max : m;   // fitting.py:1029-1036
+            flags[q] = m > pp.nsel_max ? 1 : 0;
+            nsel[q] = used;
+            nb += (uint64_t)(3 * (int64_t)pp.nmc * used);
+            run += m;
+        }
+        off2[nstar] = run;
+        nbase[nstar] = nb;
+    }
+    __syncthreads();
+    if (s < nstar) {
+        int64_t run = tot[s];
+        for (int c = 0; c < PCH; ++c) {
+            offsets[(int64_t)s * PCH + c] = run;
+            run += counts[(int64_t)s * PCH + c];
+        }
+    }
+}
+
+// P2c: ordered scatter of the kept records + per-record preparation
+// (fitting.py:1023, 1039-1065): lnp0 = lnlike + lnprior, covariance by the
+// adjugate, PSD repair, Cholesky factor of cov + 1e-30 I.
+struct RecPost {      // arrays over second-cut records (capacity = first-cut capacity)
+    int32_t *src;     // position in the first-cut record arrays
+    double *lnp;      // lnp0, later the final lnp
+    double *cov;      // [6][cap]
+    double *chol;     // [6][cap]  L00 L10 L11 L20 L21 L22
+};
+
+__device__ __forceinline__ bool inv3_sym(const double (&A)[6], double (&C)[6]) {
+    // A, C: 00 01 02 11 12 22.  Adjugate by row cross products, determinant as
+    // the mean of the three row.cofactor-row dots (utils.py:71-114).
+    const double a00 = A[0], a01 = A[1], a02 = A[2], a11 = A[3], a12 = A[4], a22 = A[5];
+    const double c00 = a11 * a22 - a12 * a12, c01 = a12 * a02 - a01 * a22, c02 = a01 * a12 - a11 * a02;
+    const double c11 = a22 * a00 - a02 * a02, c12 = a02 * a01 - a12 * a00;
+    const double c22 = a00 * a11 - a01 * a01;
+    const double d0 = c00 * a00 + c01 * a01 + c02 * a02;
+    const double d1 = c01 * a01 + c11 * a11 + c12 * a12;
+    const double d2 = c02 * a02 + c12 * a12 + c22 * a22;
+    const double det = (d0 + d1 + d2) / 3.;
+    C[0] = c00 / det; C[1] = c01 / det; C[2] = c02 / det;
+    C[3] = c11 / det; C[4] = c12 / det; C[5] = c22 / det;
+    return true;
+}
+
+__device__ __forceinline__ bool is_pd3(const double (&C)[6]) {
+    // all eigenvalues > 0 (fitting.py:1042) <=> leading principal minors > 0
+    const double m2 = C[0] * C[3] - C[1] * C[1];
+    const double m3 = C[0] * (C[3] * C[5] - C[4] * C[4]) - C[1] * (C[1] * C[5] - C[4] * C[2]) +
+                      C[2] * (C[1] * C[4] - C[3] * C[2]);
+    return C[0] > 0. && m2 > 0. && m3 > 0.;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const double *__restrict__ sel_vals,
+                const int64_t *__restrict__ sel_off, const double *__restrict__ lnprior,
+                const unsigned long long *__restrict__ mask, const int64_t *__restrict__ offsets,
+                RecPost rp) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    int64_t a, b;
+    rec_range(sel_off, s, c, a, b);
+    int64_t base = offsets[(int64_t)s * PCH + c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int64_t r0 = a; r0 < b; r0 += TILE) {
+        const int64_t r = r0 + threadIdx.x;
+        const unsigned long long bl = mask[mask_base(sel_off, s) + ((r0 - sel_off[s]) >> 6) + w];
+        const bool sel = (bl >> lane) & 1ull;
+        const int rank = __popcll(bl & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[w] = __popcll(bl);
+        __syncthreads();
+        int woff = 0;
+        for (int q = 0; q < w; ++q) woff += wsum[q];
+        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        if (sel) {
+            const int64_t o = base + woff + rank;
+            rp.src[o] = (int32_t)(r - sel_off[s]);
+            rp.lnp[o] = sel_vals[r] + lnprior[sel_idx[r]];
+            double A[6], C[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + r];
+            inv3_sym(A, C);
+            const double scale = sel_vals[2 * cap + r];
+            const double width = 0.02;
+            double count = 1.;
+            for (int it = 0; it < 200 && !is_pd3(C); ++it) {       // fitting.py:1045-1065
+                const double sf = scale * width;
+                const bool i1 = C[0] <= 0., i2 = C[3] <= 0., i3 = C[5] <= 0.;
+                if (i1 || (!i2 && !i3)) A[0] += count / (sf * sf);
+                if (i2 || (!i1 && !i3)) A[3] += count / (width * width);
+                if (i3 || (!i1 && !i2)) A[5] += count / (width * width);
+                inv3_sym(A, C);
+                count *= 2.;
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) rp.cov[(int64_t)k * cap + o] = C[k];
+            // Cholesky of cov + 1e-30 I (utils.py:892-894)
+            const double l00 = sqrt(C[0] + 1e-30);
+            const double l10 = C[1] / l00, l20 = C[2] / l00;
+            const double l11 = sqrt(C[3] + 1e-30 - l10 * l10);
+            const double l21 = (C[4] - l20 * l10) / l11;
+            const double l22 = sqrt(C[5] + 1e-30 - l20 * l20 - l21 * l21);
+            rp.chol[0 * cap + o] = l00;
+            rp.chol[1 * cap + o] = l10;
+            rp.chol[2 * cap + o] = l11;
+            rp.chol[3 * cap + o] = l20;
+            rp.chol[4 * cap + o] = l21;
+            rp.chol[5 * cap + o] = l22;
+        }
+        base += tot;
+        __syncthreads();
+    }
+}
+
+// Sequential reader of normals j0, j0+1, ...: each Philox pair is generated once.
+struct NormalReader {
+    uint64_t seed, p;
+    double z0, z1;
+    bool have;
+    __device__ __forceinline__ void init(uint64_t seed_) {
+        seed = seed_;
+        have = false;
+        p = 0;
+    }
+    __device__ __forceinline__ double at(uint64_t j) {
+        const uint64_t q = j >> 1;
+        if (!have || q != p) {
+            rng_normal_pair(seed, q, z0, z1);
+            p = q;
+            have = true;
+        }
+        return (j & 1) ? z1 : z0;
+    }
+};
+
+// One Monte Carlo sample of a kept record (fitting.py:1071-1093) from its three
+// normals: sample t of the record of rank n in the object's list uses normals
+// nbase + (3 n + k) nmc + t, k = 0, 1, 2 (utils.py:897).  Returns (dist, av, rv),
+// whether it is inside the fit bounds, and its prior in split form:
+//   lnp_mc = lnK + ln(lin) + epar - par_lnorm / 2,   epar = -(par - par_obs)^2 ivar / 2 <= 0
+__device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGeom &g, double z0,
+                                              double z1, double z2, double s0, double a0, double r0,
+                                              const double (&L)[6], const double (&Fc)[3],
+                                              const double (&Ac)[3], const double *__restrict__ tbl,
+                                              double &dist, double &a_mc, double &r_mc, bool &inb,
+                                              double &lin, double &epar) {
+    const double s_mc = s0 + L[0] * z0;
+    a_mc = a0 + (L[1] * z0 + L[2] * z1);
+    r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
+    double par;
+    fast_sqrt_rsqrt(s_mc, par, dist);                           // parallax and distance (~1 ulp)
+    lin = gal_prior_lin(pp, g, dist, Fc, Ac, tbl);
+    const double dp = par - g.par;                              // pdf.py:166-173
+    epar = g.has_par ? -0.5 * (dp * dp * g.par_ivar) : 0.;
+    inb = s_mc >= 1e-20 && a_mc >= pp.avlim[0] && a_mc <= pp.avlim[1] &&
+          r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
+}
+
+// the same as one log value (-BIG outside the bounds, fitting.py:1086-1090),
+// drawing the normals on the fly
+__device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (&rd)[3],
+                                            const StarGeom &g, uint64_t nb, int64_t n, int t, double s0, double a0, double r0,
+                                            const double (&L)[6], const double (&Fc)[3],
+                                            const double (&Ac)[3], const double *__restrict__ tbl,
+                                            double &dist, double &a_mc, double &r_mc, bool &inb) {
+    const uint64_t j0 = nb + (uint64_t)((3 * n) * (int64_t)pp.nmc + t);
+    const double z0 = rd[0].at(j0);
+    const double z1 = rd[1].at(j0 + (uint64_t)pp.nmc);
+    const double z2 = rd[2].at(j0 + 2ull * (uint64_t)pp.nmc);
+    double lin, epar;
+    mc_sample_lin(pp, g, z0, z1, z2, s0, a0, r0, L, Fc, Ac, tbl, dist, a_mc, r_mc, inb, lin, epar);
+    double v = pp.lnK + fast_log_r(lin);
+    if (g.has_par) v += epar - 0.5 * g.par_lnorm;
+    if (!inb) v = -BIG;
+    return v;
+}
+
+// rows (polar pairs) of a k_post_mc staging slot: the 3 nmc normals of a record
+// span at most 3 nmc / 2 + 1 pairs
+__host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2; }
+
+// P4: Monte Carlo prior integral of every kept record (fitting.py:1068-1105)
+// and chi2min (fitting.py:2025-2034).  One lane per record.
+//
+// The 3 nmc normals of a record are one contiguous run of the stream, i.e.
+// ~3 nmc / 2 polar pairs.  A lane first walks its pairs with its own retry
+// counter and stores the two normals of each accepted candidate in its column
+// of `zs` (lane-interleaved rows of double2; 16-byte stores: the staging is
+// bound by L2 write requests, lanes drift apart in row) -- a
+// wave then spends ~1/0.785 Philox rounds per pair instead of the ~3.7 it takes
+// until all 64 lanes of a lockstep retry loop have accepted -- and afterwards
+// integrates, reading three normals per sample.
+//
+__global__ void __launch_bounds__(TILE, 3)
+k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ counter,
+          double2 *__restrict__ zs, const int32_t *__restrict__ sel_idx,
+          const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+          const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+          const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
+          const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+          const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
+          double *__restrict__ part_chi2) {
+    __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    __shared__ unsigned int s_item;
+    stage_exp_table(s_tbl);
+    double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int item = s_item;
+        if (item >= (unsigned int)nitem) break;
+        const int s = (int)(item / PCH), c = (int)(item % PCH);
+        int64_t a, b;
+        rec_range_n(off2[s], nsel[s], c, a, b);
+        const StarGeom g = geom[s];
+        const uint64_t nb = nbase[s];
+        const uint64_t seed = star_seed(pp, s);
+        double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
+        if (!flags[s]) {
+            for (int64_t o0 = a; o0 < b; o0 += TILE) {
+                const int64_t o = o0 + threadIdx.x;
+                const bool live = o < b;
+                const int64_t n = o - off2[s];
+                // normals j_lo .. j_lo + 3 nmc - 1 of the stream = pairs p_lo .. p_hi;
+                // pair q - p_lo goes to row q - p_lo of the slot as one 16-byte store
+                const uint64_t j_lo = nb + (uint64_t)(3 * n * (int64_t)pp.nmc);
+                const uint64_t p_lo = j_lo >> 1;
+                {
+                    const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
+                    uint64_t p = live ? p_lo : p_hi + 1;
+                    uint32_t retry = 0;
+                    while (p <= p_hi) {
+                        double x1, x2;
+                        if (rng_polar_candidate(seed, p, retry, x1, x2)) {
+                            double z0, z1;
+                            rng_polar_finish(x1, x2, z0, z1);
+                            col[(int64_t)(p - p_lo) * TILE] = make_double2(z0, z1);
+                            ++p;
+                            retry = 0;
+                        } else {
+                            ++retry;
+                        }
+                    }
+                }
+                if (live) {
+                    const int64_t r = sel_off[s] + rp.src[o];
+                    const int64_t i = sel_idx[r];
+                    double Fc[3], Ac[3], L[6];
+                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+                    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
+                                 r0 = sel_vals[4 * cap + r];
+                    // sum_t lin_t e^{epar_t} over the in-bounds samples, with a
+                    // running maximum M of epar only (lin needs none); branch-free
+                    double M = -INFINITY, acc = 0.;
+                    int ninb = 0;
+                    const double *const zc = (const double *)col;
+                    const int jb = (int)(j_lo & 1);
+                    for (int t = 0; t < pp.nmc; ++t) {
+                        double d_, a_, r_, lin, epar;
+                        bool inb;
+                        // normal jj of the run: component jj & 1 of row jj >> 1
+                        const int j0 = jb + t, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
+                        mc_sample_lin(pp, g, zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
+                                      zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
+                                      zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)], s0, a0, r0, L, Fc, Ac,
+                                      s_tbl, d_, a_, r_, inb, lin, epar);
+                        ninb += inb ? 1 : 0;
+                        if (g.has_par) {
+                            const double dM = epar - M;
+                            const double ex = fast_exp_bf(-fabs(dM), s_tbl);
+                            const bool up = inb && dM > 0.;
+                            const double add = inb ? lin : 0.;
+                            acc = up ? fma(acc, ex, add) : (inb ? fma(add, ex, acc) : acc);
+                            M = up ? epar : M;
+                        } else {
+                            acc += inb ? lin : 0.;
+                        }
+                    }
+                    // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
+                    // sample in bounds the reference yields +inf -> not finite -> -BIG
+                    double lse = pp.lnK + log(acc);
+                    if (g.has_par) lse += M - 0.5 * g.par_lnorm;
+                    double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
+                    if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
+                    rp.lnp[o] = lnp;
+                    if (lnp > mx) mx = lnp;
+                    double chi2 = sel_vals[1 * cap + r];
+                    if (g.has_par) {
+                        const double dp = sqrt(s0) - g.par;
+                        chi2 += dp * dp * g.par_ivar;
+                    }
+                    if (-chi2 > cmin) cmin = -chi2;
+                }
+            }
+        }
+        block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
+        block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
+    }
+}
+
+// P5: evidence and the cumulative weights of one object (fitting.py:2033-2038),
+// chunk-parallel over grid (PCH, object):
+//   k_post_evid_part : per-chunk sums of exp(lnp - max)          -> levid
+//   k_post_wt_part   : per-chunk totals of wt = exp(lnp - levid)
+//   k_post_cdf       : chunk offset + in-chunk running sum       -> cdf
+// The chunk totals come from the very scan that later writes the cdf, so the
+// cdf is monotone across chunk boundaries bit for bit.
+__device__ __forceinline__ void post_star_max(const double *__restrict__ part_max,
+                                              const double *__restrict__ part_chi2, int s, double &mx,
+                                              double &cm) {
+    mx = -INFINITY;
+    cm = -INFINITY;
+    for (int q = 0; q < PCH; ++q) {
+        mx = fmax(mx, part_max[(int64_t)s * PCH + q]);
+        cm = fmax(cm, part_chi2[(int64_t)s * PCH + q]);
+    }
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_evid_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+                 const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+                 const double *__restrict__ part_chi2, RecPost rp, double *__restrict__ part_e) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
+    double acc = 0.;
+    for (int64_t o = a + threadIdx.x; o < b; o += TILE) acc += exp(rp.lnp[o] - mx);
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    for (int st = TILE / 2; st > 0; st >>= 1) {
+        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) part_e[(int64_t)s * PCH + c] = sh[0];
+}
+
+// log-evidence of object s from the chunk sums (same order in every caller)
+__device__ __forceinline__ double post_levid(const double *__restrict__ part_e, int s, double mx) {
+    double tot = 0.;
+    for (int q = 0; q < PCH; ++q) tot += part_e[(int64_t)s * PCH + q];
+    return log(tot) + mx;
+}
+
+// running sum of wt over records [a, b) starting from `carry0`; returns the
+// final carry (all threads).  WRITE: store the inclusive sums to cdf.
+template <bool WRITE>
+__device__ __forceinline__ double post_chunk_scan(const double *__restrict__ lnp, int64_t a, int64_t b,
+                                                  double levid, double carry0, double *sh,
+                                                  double *__restrict__ cdf) {
+    double carry = carry0;
+    for (int64_t o0 = a; o0 < b; o0 += TILE) {
+        const int64_t o = o0 + threadIdx.x;
+        const double w = o < b ? exp(lnp[o] - levid) : 0.;
+        sh[threadIdx.x] = w;
+        __syncthreads();
+        for (int st = 1; st < TILE; st <<= 1) {          // Hillis-Steele inclusive scan
+            const double v = threadIdx.x >= st ? sh[threadIdx.x - st] : 0.;
+            __syncthreads();
+            sh[threadIdx.x] += v;
+            __syncthreads();
+        }
+        if (WRITE && o < b) cdf[o] = carry + sh[threadIdx.x];
+        carry += sh[TILE - 1];
+        __syncthreads();
+    }
+    return carry;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_wt_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+               const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+               const double *__restrict__ part_chi2, const double *__restrict__ part_e, RecPost rp,
+               double *__restrict__ part_w) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
+    const double levid = post_levid(part_e, s, mx);
+    const double tot = post_chunk_scan<false>(rp.lnp, a, b, levid, 0., sh, nullptr);
+    if (threadIdx.x == 0) part_w[(int64_t)s * PCH + c] = tot;
+}
+
+__global__ void __launch_bounds__(TILE)
+k_post_cdf(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+           const int32_t *__restrict__ flags, const double *__restrict__ part_max,
+           const double *__restrict__ part_chi2, const double *__restrict__ part_e,
+           const double *__restrict__ part_w, RecPost rp, double *__restrict__ cdf,
+           double *__restrict__ star_out) {
+    __shared__ double sh[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    if (flags[s]) return;
+    int64_t a, b;
+    rec_range_n(off2[s], nsel[s], c, a, b);
+    double mx, cm;
+    post_star_max(part_max, part_chi2, s, mx, cm);
+    const double levid = post_levid(part_e, s, mx);
+    double carry = 0.;                         // offset of this chunk: its predecessors' totals
+    for (int q = 0; q < c; ++q) carry += part_w[(int64_t)s * PCH + q];
+    carry = post_chunk_scan<true>(rp.lnp, a, b, levid, carry, sh, cdf);
+    if (c == PCH - 1 && threadIdx.x == 0) {
+        star_out[4 * s + 0] = levid;
+        star_out[4 * s + 1] = -cm;            // chi2min
+        star_out[4 * s + 2] = carry;          // total weight (cdf normaliser)
+        star_out[4 * s + 3] = (double)nsel[s];
+    }
+}
+
+// P6: resampling (fitting.py:2037-2057).  One lane per (object, draw).
+constexpr int POST_NOUT = 17;   // scale av rv cov[9] lnprob dist red dred logwt
+__global__ void __launch_bounds__(64)
+k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ sel_idx,
+            const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
+            const int64_t *__restrict__ off2, const int64_t *__restrict__ nselv,
+            const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
+            const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+            const double *__restrict__ loga, RecPost rp, const double *__restrict__ cdf,
+            const double *__restrict__ star_out, int32_t *__restrict__ out_idx,
+            double *__restrict__ out_vals) {
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    const int s = blockIdx.y;
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= pp.ndraws || flags[s]) return;
+    const int64_t a = off2[s], nsel = nselv[s];
+    if (nsel <= 0) return;
+    const StarGeom g = geom[s];
+    const uint64_t ub = star_ubase(pp, s);
+    const uint64_t seed = star_seed(pp, s);
+    // choice(Nsel, p=wt): searchsorted(cdf / cdf[-1], u, side='right')
+    const double total = star_out[4 * s + 2];
+    const double u = rng_uniform(seed, ub + (uint64_t)q);
+    int64_t lo = 0, hi = nsel;
+    while (lo < hi) {
+        const int64_t mid = (lo + hi) >> 1;
+        if (cdf[a + mid] / total <= u) lo = mid + 1; else hi = mid;
+    }
+    if (lo >= nsel) lo = nsel - 1;
+    const int64_t o = a + lo;
+    const int64_t r = sel_off[s] + rp.src[o];
+    const int64_t i = sel_idx[r];
+    out_idx[(int64_t)s * pp.ndraws + q] = (int32_t)i;
+    double *ov = out_vals + ((int64_t)s * pp.ndraws + q) * POST_NOUT;
+    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r], r0 = sel_vals[4 * cap + r];
+    ov[0] = s0;
+    ov[1] = a0;
+    ov[2] = r0;
+    double C[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) C[k] = rp.cov[(int64_t)k * cap + o];
+    ov[3] = C[0]; ov[4] = C[1]; ov[5] = C[2];
+    ov[6] = C[1]; ov[7] = C[3]; ov[8] = C[4];
+    ov[9] = C[2]; ov[10] = C[4]; ov[11] = C[5];
+    ov[12] = rp.lnp[o];
+    if (!pp.return_distreds) return;
+    // second stage (fitting.py:2049-2057): pick one of the record's nmc samples
+    double Fc[3], Ac[3], L[6];
+    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+    const uint64_t nb = nbase[s];
+    double m = -INFINITY;
+    bool inb_;
+    NormalReader rd[3];
+    rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);
+        if (v > m) m = v;
+    }
+    double z = 0.;
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        z += exp(mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_) - m);
+    }
+    // wt = softmax(logwts); imc = searchsorted(cumsum(wt) / sum, u2, side='right')
+    const double u2 = rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
+    double run = 0., dist = 0., red = 0., dred = 0., lw = 0.;
+    for (int t = 0; t < pp.nmc; ++t) {
+        double d_, a_, r_;
+        const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);
+        run += exp(v - m);
+        dist = d_; red = a_; dred = r_; lw = v;
+        if (run / z > u2) break;          // first cumulative weight above u2
+    }
+    ov[13] = dist;
+    ov[14] = red;
+    ov[15] = dred;
+    ov[16] = lw;
+}
+
+// Nsel_max clipping (fitting.py:1029-1036): keep the nsel_max largest lnp in
+// DESCENDING order.  Rare; a device radix sort per affected object.
+__global__ void k_iota32(int32_t *p, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = (int32_t)i;
+}
+template <typename T>
+__global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
+                         const int32_t *__restrict__ perm, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) dst[i] = src[perm[i]];
+}
+
+// per-object geometry / parallax constants
+__global__ void k_post_geom(int nstar, const double *__restrict__ coords,
+                            const double *__restrict__ par, const double *__restrict__ perr,
+                            StarGeom *__restrict__ geom) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstar) return;
+    const double l = coords[2 * s] * (M_PI / 180.), b = coords[2 * s + 1] * (M_PI / 180.);
+    StarGeom g;
+    g.cb_cl = cos(b) * cos(l);
+    g.cb_sl = cos(b) * sin(l);
+    g.sb = sin(b);
+    const double p = par ? par[s] : nan(""), pe = perr ? perr[s] : nan("");
+    g.has_par = (isfinite(p) && isfinite(pe)) ? 1 : 0;
+    g.par = g.has_par ? p : 0.;
+    g.par_ivar = g.has_par ? 1. / (pe * pe) : 0.;
+    g.par_lnorm = g.has_par ? log(2. * M_PI * pe * pe) : 0.;
+    geom[s] = g;
+}
+
+__global__ void k_debug_normals(uint64_t seed, uint64_t start, int64_t n, double *__restrict__ z,
+                                double *__restrict__ u) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    z[i] = rng_normal(seed, start + (uint64_t)i);
+    u[i] = rng_uniform(seed, start + (uint64_t)i);
+}
+
+__global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict__ dist,
+                                 const double *__restrict__ coords, const double *__restrict__ feh,
+                                 const double *__restrict__ loga, double *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    StarGeom g;
+    const double l = coords[0] * (M_PI / 180.), b = coords[1] * (M_PI / 180.);
+    g.cb_cl = cos(b) * cos(l);
+    g.cb_sl = cos(b) * sin(l);
+    g.sb = sin(b);
+    g.has_par = 0;
+    double Fc[3], Ac[3];
+    label_terms(pp, feh[i], loga[i], Fc, Ac);
+    out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac, kExp2Tbl);
+}
+
+}  // namespace
