@@ -35,7 +35,10 @@ def parse():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=64, help="stars per step per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="2 / 3: the grid-likelihood path (BASELINE configs[1] / [2]); "
+                         "5: cluster.isochrone_loglike (configs[4], supplementary line)")
+    ap.add_argument("--cluster-stars", type=int, default=5000)
     ap.add_argument("--nmodel", type=int, default=750000)
     ap.add_argument("--nfilt", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
@@ -164,8 +167,106 @@ def measured_traffic(kernel, batch, config):
     return None
 
 
+def bench_cluster(args):
+    """BASELINE configs[4]: one `isochrone_loglike` evaluation = 5 000 objects x
+    12 bands against 15 mass-fraction slices x 2 000 EEP points (SURVEY 8d,
+    config 5).  A step is one whole call (host unpacking + isochrone table +
+    device block).  Does not shard: with --gpus N every rank evaluates its own
+    replica (an MCMC over theta would run one chain per GPU)."""
+    import ctypes as C
+    import torch
+    import torch.distributed as dist
+    from brutus_amd import _lib, cluster, synth
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    L = _lib.lib()
+    iso = synth.TableIsochrone(nbands=args.nfilt, neep=2000)
+    nobj = args.cluster_stars
+    phot, err, par, perr = synth.make_cluster(iso, nobj, seed=11 + rank)
+    theta0 = np.array([-0.1, 9.6, 0.2, 3.3, 850., 0.05])
+
+    def call(k):
+        th = theta0 + np.array([1e-3, 1e-3, 1e-3, 0., 0.5, 0.]) * (k % 7)
+        return cluster.isochrone_loglike(th, iso, phot, err, parallax=par,
+                                         parallax_err=perr, device=dev)
+    for k in range(args.warmup):
+        call(k)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        val = call(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    # device block alone (HIP events on the launch stream)
+    L.brutus_enable_timing(1)
+    call(0)
+    n = C.c_int(0)
+    names = (C.c_char_p * 8)()
+    ms = (C.c_float * 8)()
+    L.brutus_last_timing(C.byref(n), names, ms, 8)
+    L.brutus_enable_timing(0)
+    k_ms = dict((names[j].decode(), float(ms[j])) for j in range(n.value)).get("k_cluster")
+    npts = 2000 + 14 * int(np.sum(iso.eep_grid <= 480.))     # evolved points only in slice 0
+    pairs = float(nobj) * npts
+    line = {
+        "metric": "isochrone_loglike evaluations/s (5k stars x 12 bands x 15 SMF x 2000 EEP)",
+        "value": world * args.steps / dt, "unit": "evaluations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": "configs[4]: cluster.isochrone_loglike, %d objects, %d bands, "
+                               "15 x 2000 isochrone table (%d live points)" % (nobj, args.nfilt, npts),
+                   "parallelism": "replicas only, %d rank(s)" % world,
+                   "timed_region": "whole isochrone_loglike call: host arrays in, lnl_tot out"},
+        "star_points_per_s": world * pairs * args.steps / dt,
+    }
+    if k_ms:
+        # the block re-reads only the 2.9 MB point table per 64-object workgroup:
+        # it is bound by f64 VALU issue, the HBM figure is shown for completeness
+        alg = 8. * (npts * (args.nfilt + 1) + nobj * (2 * args.nfilt + 3))
+        flops = pairs * (3. * args.nfilt + 40.)
+        line["roofline"] = {"bound": "hbm", "kernel": "k_cluster", "achieved": alg / (k_ms * 1e-3) / 1e9,
+                            "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
+                            "traffic": None, "avg_launch_ms": k_ms,
+                            "valu_f64_tflops": flops / (k_ms * 1e-3) / 1e12,
+                            "valu_f64_peak_tflops": 78.6,
+                            "device_star_points_per_s": pairs / (k_ms * 1e-3)}
+    if rank == 0 and args.cpu_seconds > 0:
+        from oracle import brutus_oracle as O
+        sub = max(16, min(nobj, int(100 * args.cpu_seconds / 10.)))
+        t0 = time.perf_counter()
+        O.isochrone_loglike(theta0, iso, phot[:sub], err[:sub], parallax=par[:sub],
+                            parallax_err=perr[:sub])
+        dc = time.perf_counter() - t0
+        line["cpu_baseline"] = {"value": (sub / dc) / nobj, "unit": "evaluations/s",
+                                "cores": 1, "kind": "port",
+                                "sample": "oracle numpy restatement on %d of the %d objects "
+                                          "(%.1f s), scaled to a full evaluation" % (sub, nobj, dc)}
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     args = parse()
+    if args.config == 5:
+        return bench_cluster(args)
     import torch
     import torch.distributed as dist
     from brutus_amd import _lib, fitting, synth

@@ -22,6 +22,27 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
           const double *__restrict__ ivar, const double *__restrict__ chi2_p,
           const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
           int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
+    // This workgroup's slice of the point table, staged once as
+    // [point][NB fluxes (0 beyond nb) | lnw | "has a NaN band"]: the loop then reads
+    // it with broadcast ds_reads instead of a chain of dependent scalar loads.
+    extern __shared__ double s_pts[];
+    __shared__ double s_tbl[64];
+    constexpr int STRIDE = NB + 2;
+    stage_exp_table(s_tbl);
+    const int p0 = blockIdx.y * pts_per_block;
+    const int np = min(npts, p0 + pts_per_block) - p0;
+    for (int c = threadIdx.x; c < np; c += 64) {
+        const double *src = pts_flux + (int64_t)(p0 + c) * nb;
+        bool hole = false;
+        for (int b = 0; b < NB; ++b) {
+            const double v = b < nb ? src[b] : 0.;
+            hole = hole || (v != v);
+            s_pts[c * STRIDE + b] = v;
+        }
+        s_pts[c * STRIDE + NB] = pts_lnw[p0 + c];
+        s_pts[c * STRIDE + NB + 1] = hole ? 1. : 0.;
+    }
+    __syncthreads();
     const int o = blockIdx.x * 64 + threadIdx.x;
     const bool live = o < nobj;
     const int oo = live ? o : 0;
@@ -35,34 +56,45 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     const double k = (double)ndim[oo];
     const double c0 = -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.);
     const double c1 = k / 2. - 1.;
-    const int p0 = blockIdx.y * pts_per_block;
-    const int p1 = min(npts, p0 + pts_per_block);
     double m = -INFINITY, ssum = 0.;
-    for (int c = p0; c < p1; ++c) {
-        const double *f = pts_flux + (int64_t)c * nb;
-        double chi2 = 0.;
+    for (int c = 0; c < np; ++c) {
+        const double *f = s_pts + c * STRIDE;
+        double fb[NB];
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            if (b < nb) {
-                const double t = d[b] - f[b];
+        for (int b = 0; b < NB; ++b) fb[b] = f[b];
+        double chi2 = 0.;
+        // nansum (cluster.py:381): d and iv are finite (masked bands carry iv = 0),
+        // so a term is NaN exactly when the point lacks band b -- rare, and the
+        // same for every lane
+        if (f[NB + 1] == 0.) {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double t = d[b] - fb[b];
+                chi2 += t * t * iv[b];
+            }
+        } else {
+#pragma unroll
+            for (int b = 0; b < NB; ++b) {
+                const double t = d[b] - fb[b];
                 const double term = t * t * iv[b];
-                if (term == term) chi2 += term;          // nansum (cluster.py:381)
+                chi2 += term == term ? term : 0.;
             }
         }
         chi2 += cp;
         double lnl;
         if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
-            lnl = c0 + (c1 == 0. ? 0. : c1 * log(chi2)) - chi2 / 2.;
+            lnl = c0 + (c1 == 0. ? 0. : c1 * fast_log_r(chi2)) - chi2 / 2.;
         else
             lnl = -0.5 * (chi2 + ln0);
         if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
-        const double x = lnl + pts_lnw[c];
-        if (x > m) {
-            ssum = ssum * exp(m - x) + 1.;
-            m = x;
-        } else if (x > -INFINITY) {
-            ssum += exp(x - m);
-        }
+        // online logsumexp, one exponential per point
+        const double x = lnl + f[NB];
+        const double dx = x - m;
+        const double e = fast_exp_bf(-fabs(dx), s_tbl);
+        const bool up = dx > 0.;
+        const bool fin = x > -INFINITY;
+        ssum = up ? fma(ssum, e, 1.) : (fin ? ssum + e : ssum);
+        m = up ? x : m;
     }
     if (live) {
         part_m[(int64_t)blockIdx.y * nobj + o] = m;

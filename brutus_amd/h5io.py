@@ -448,7 +448,8 @@ class ResultsFile(object):
             a["samps_dist"][i] = results[9]
             a["samps_red"][i] = results[10]
             a["samps_dred"][i] = results[11]
-            a["samps_logp"][i] = results[12]
+            with np.errstate(over="ignore"):     # -1e300 (out-of-bounds draw) -> -inf in f32, as h5py does
+                a["samps_logp"][i] = results[12]
         if getattr(self, "_dirty", None) is not None:
             # resumed file: rows arrive in arbitrary positions
             self._dirty.add(i)

@@ -142,3 +142,64 @@ def make_mist_like_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
     for n in ('mini', 'eep', 'feh'):
         labels_mask[n] = True
     return models, labels, labels_mask
+
+
+class TableIsochrone(object):
+    """A co-eval population as a precomputed SED table:
+    `mags[smf index]` is `(Neep, Nbands)` absolute magnitudes on `eep_grid`,
+    `mini` the initial-mass grid.  Provides the one method
+    `cluster.isochrone_loglike` needs from reference `seds.Isochrone`
+    (`get_seds`, cluster.py:339-344); reddening and distance are applied here
+    on the host, the (object x point) block runs on the device."""
+
+    def __init__(self, nbands=12, neep=2000, smf_grid=None, seed=7):
+        rng = np.random.RandomState(seed)
+        self.smf_grid = np.asarray(
+            (0., 0.2, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8, 0.85, 0.9,
+             0.95, 1.0) if smf_grid is None else smf_grid, dtype=float)
+        self.eep_grid = np.linspace(202., 808., neep)
+        x = (self.eep_grid - 202.) / 606.
+        self.mini = 0.25 + 1.5 * x + 0.02 * x * x
+        lam = np.linspace(0., 1., nbands)
+        M = 9.5 - 8.5 * x
+        col = (0.9 - 0.7 * x)[:, None] * (2.5 * (1. - lam) ** 1.5 - 0.7)[None, :]
+        base = M[:, None] + col + 0.01 * rng.normal(size=(neep, nbands))
+        self.rvec = 1.25 - 1.1 * lam
+        self.mags = []
+        for smf in self.smf_grid:           # unresolved equal-age secondary
+            self.mags.append(base - 2.5 * np.log10(1. + smf ** 3.5))
+
+    def get_seds(self, feh=0., loga=9., av=0., rv=3.3, eep=None, smf=0.,
+                 dist=1000., mini_bound=0.08, eep_binary_max=480.,
+                 corr_params=None):
+        k = int(np.argmin(np.abs(self.smf_grid - smf)))
+        eep = self.eep_grid if eep is None else np.asarray(eep, dtype=float)
+        mag = np.empty((eep.size, self.rvec.size))
+        for b in range(self.rvec.size):
+            mag[:, b] = np.interp(eep, self.eep_grid, self.mags[k][:, b])
+        mini = np.interp(eep, self.eep_grid, self.mini)
+        mag = mag + 0.25 * feh - 0.15 * (loga - 9.)
+        mag = mag + av * (self.rvec + 0.02 * (rv - 3.3))[None, :]
+        mag = mag + 5. * np.log10(dist / 10.)
+        mag[mini < mini_bound] = np.nan
+        return mag, {"mini": mini}, {"mini": mini * smf}
+
+
+def make_cluster(iso, nobj, seed=11, frac_no_parallax=0.3, frac_nan_band=0.05):
+    """`nobj` members of the population `iso` at 850 pc with 3 % photometry,
+    a few NaN bands and NaN parallaxes (what reference cluster.py expects:
+    fluxes in maggies, parallaxes in mas)."""
+    rng = np.random.RandomState(seed)
+    eep = rng.uniform(230., 760., nobj)
+    mag, _, _ = iso.get_seds(feh=-0.1, loga=9.6, av=0.2, rv=3.3, eep=eep, smf=0.,
+                             dist=850.)
+    flux = 10. ** (-0.4 * mag)
+    err = 0.03 * flux
+    phot = flux + rng.normal(size=flux.shape) * err
+    hole = rng.uniform(size=phot.shape) < frac_nan_band
+    hole[:, 0] = False
+    phot[hole] = np.nan
+    par = 1e3 / 850. + rng.normal(size=nobj) * 0.05
+    perr = np.full(nobj, 0.05)
+    par[rng.uniform(size=nobj) < frac_no_parallax] = np.nan
+    return phot, err, par, perr
