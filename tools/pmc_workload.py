@@ -31,7 +31,7 @@ eng = fitting._Engine(grid, max_batch=B, mem_budget=64e9)
 up = eng._upload(st["flux"], st["err"], st["mask"],
                  st["parallax"] if config == 3 else None,
                  st["parallax_err"] if config == 3 else None)
-cap = 32 << 20
+cap = max(32 << 20, B * 600000)
 bufs = (torch.empty(cap, dtype=torch.int32, device=dev),
         torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
 for _ in range(3):
