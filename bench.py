@@ -169,6 +169,21 @@ def measured_traffic(kernel, batch, config):
     return None
 
 
+def _local_device(local_rank):
+    """BRUTUS_BENCH_ONE_DEVICE=1: every rank on cuda:0 -- lets the N > 1 code
+    path be exercised on a one-GPU box (with BRUTUS_BENCH_BACKEND=gloo; RCCL
+    refuses two ranks on one device).  Never set for a measurement."""
+    return 0 if os.environ.get("BRUTUS_BENCH_ONE_DEVICE") == "1" else local_rank
+
+
+def _init_pg(dist, rank, world, dev):
+    backend = os.environ.get("BRUTUS_BENCH_BACKEND", "nccl")      # nccl = RCCL on ROCm
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
+
+
 def bench_cluster(args):
     """BASELINE configs[4]: one `isochrone_loglike` evaluation = 5 000 objects x
     12 bands against 15 mass-fraction slices x 2 000 EEP points (SURVEY 8d,
@@ -182,11 +197,12 @@ def bench_cluster(args):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = _local_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        _init_pg(dist, rank, world, dev)
     L = _lib.lib()
     iso = synth.TableIsochrone(nbands=args.nfilt, neep=2000)
     nobj = args.cluster_stars
@@ -279,12 +295,12 @@ def main():
     if args.gpus != world:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run for --gpus > 1")
+    local_rank = _local_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world,
-                                device_id=dev)
+        _init_pg(dist, rank, world, dev)
 
     L = _lib.lib()
     nmodel, nfilt = args.nmodel, args.nfilt

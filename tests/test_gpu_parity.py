@@ -374,6 +374,29 @@ def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
                                   3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
     recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
                          st["parallax_err"], params)
+    # the pinned-Rv instantiation of the same band count
+    pin = fitting._make_params((0., 20.), (0., 1e6), (3.32, 3.32), (3.32, 0.18),
+                               3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    rpin = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
+                         st["parallax_err"], pin)
+    for i in range(min(nstar, 3)):
+        par, pe = st["parallax"][i], st["parallax_err"][i]
+        tr = {}
+        lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+            st["flux"][i], st["err"][i], st["mask"][i], models, parallax=par,
+            parallax_err=pe, rvlim=(3.32, 3.32), trace=tr)
+        with np.errstate(all="ignore"):
+            lnprob = lnl + scale_parallax_lnprior(
+                sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), par, pe)
+        lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+        sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
+        assert rpin[i]["K1"] == tr["K1"] and rpin[i]["K2"] == tr["K2"], i
+        assert np.array_equal(sel, rpin[i]["sel"]), i
+        assert relerr(lnl[sel], rpin[i]["lnlike"]) < RTOL
+        assert relerr(av[sel], rpin[i]["av"]) < 1e-7
+        d = np.sqrt(np.abs(np.einsum('nii->ni', icov[sel])))
+        assert np.max(np.abs(rpin[i]["icov"] - icov[sel])
+                      / (d[:, :, None] * d[:, None, :])) < RTOL
     for i in range(min(nstar, 6)):
         par, pe = st["parallax"][i], st["parallax_err"][i]
         ref = c_oracle.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
