@@ -264,7 +264,7 @@ def bench_cluster(args):
                             "valu_f64_tflops": flops / (k_ms * 1e-3) / 1e12,
                             "valu_f64_peak_tflops": 78.6,
                             "device_star_points_per_s": pairs / (k_ms * 1e-3)}
-    if rank == 0 and args.cpu_seconds > 0:
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import brutus_oracle as O
         sub = max(16, min(nobj, int(100 * args.cpu_seconds / 10.)))
         t0 = time.perf_counter()
