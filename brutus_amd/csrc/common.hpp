@@ -100,6 +100,32 @@ __device__ __forceinline__ void block_max_store(double v, double *slot, double *
     __syncthreads();
 }
 
+// Three maxima at once (one barrier pair instead of three); `slot` = 12 doubles,
+// out[0..2].  Double-buffered by the caller's loop parity is not needed: the
+// trailing barrier protects the slots before the next use.
+__device__ __forceinline__ void block_max_store3(double a, double b, double c, double *slot,
+                                                 double *out) {
+    a = wave_max(a);
+    b = wave_max(b);
+    c = wave_max(c);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    if (lane == 0) {
+        slot[w] = a;
+        slot[4 + w] = b;
+        slot[8 + w] = c;
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const double *q = slot + 4 * threadIdx.x;
+        double m = q[0];
+        m = q[1] > m ? q[1] : m;
+        m = q[2] > m ? q[2] : m;
+        m = q[3] > m ? q[3] : m;
+        out[threadIdx.x] = m;
+    }
+    __syncthreads();
+}
+
 template <int NB>
 struct Coef {
     float m[NB], r0[NB], dr[NB];

@@ -590,7 +590,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int32_t *__restrict__ k2state, int first, const int32_t *__restrict__ surv_idx,
         const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
         double *__restrict__ part) {
-    __shared__ double slot[4];
+    __shared__ double slot[12];
     const int nitem = wbase[nstar];
     const int niter = first ? 2 : 1;
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
@@ -677,9 +677,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             }
         }
         double *out = part + (int64_t)item * 3;
-        block_max_store(L, slot, out);
-        block_max_store(T, slot, out + 1);
-        block_max_store(M, slot, out + 2);
+        block_max_store3(L, T, M, slot, out);
     }
 }
 
