@@ -173,22 +173,22 @@ struct Timer {
     void begin(const char *name) {
         if (!g_timing) return;
         hipEvent_t a, b;
-        hipEventCreate(&a);
-        hipEventCreate(&b);
-        hipEventRecord(a, st);
+        (void)hipEventCreate(&a);
+        (void)hipEventCreate(&b);
+        (void)hipEventRecord(a, st);
         ev.push_back({name, {a, b}});
     }
     void end() {
         if (!g_timing) return;
-        hipEventRecord(ev.back().second.second, st);
+        (void)hipEventRecord(ev.back().second.second, st);
     }
     void collect() {
         if (!g_timing) return;
         g_last_timing.clear();
         for (auto &e : ev) {
-            hipEventSynchronize(e.second.second);
+            (void)hipEventSynchronize(e.second.second);
             float ms = 0.f;
-            hipEventElapsedTime(&ms, e.second.first, e.second.second);
+            (void)hipEventElapsedTime(&ms, e.second.first, e.second.second);
             bool found = false;
             for (auto &t : g_last_timing)
                 if (t.name == e.first) {
@@ -197,8 +197,8 @@ struct Timer {
                     found = true;
                 }
             if (!found) g_last_timing.push_back({e.first, ms, 1});
-            hipEventDestroy(e.second.first);
-            hipEventDestroy(e.second.second);
+            (void)hipEventDestroy(e.second.first);
+            (void)hipEventDestroy(e.second.second);
         }
         ev.clear();
     }

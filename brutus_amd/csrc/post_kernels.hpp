@@ -642,7 +642,7 @@ k_post_evid_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ n
     sh[threadIdx.x] = acc;
     __syncthreads();
     for (int st = TILE / 2; st > 0; st >>= 1) {
-        if (threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
+        if ((int)threadIdx.x < st) sh[threadIdx.x] += sh[threadIdx.x + st];
         __syncthreads();
     }
     if (threadIdx.x == 0) part_e[(int64_t)s * PCH + c] = sh[0];
@@ -668,7 +668,7 @@ __device__ __forceinline__ double post_chunk_scan(const double *__restrict__ lnp
         sh[threadIdx.x] = w;
         __syncthreads();
         for (int st = 1; st < TILE; st <<= 1) {          // Hillis-Steele inclusive scan
-            const double v = threadIdx.x >= st ? sh[threadIdx.x - st] : 0.;
+            const double v = (int)threadIdx.x >= st ? sh[threadIdx.x - st] : 0.;
             __syncthreads();
             sh[threadIdx.x] += v;
             __syncthreads();

@@ -520,7 +520,6 @@ def test_fit_orion_catalogue_vs_reference_golden():
 
 def test_cabi_error_codes():
     """The C ABI reports bad arguments / small buffers instead of crashing."""
-    import ctypes as C
     import torch
     from brutus_amd import _lib, fitting, synth
     L = _lib.lib()
