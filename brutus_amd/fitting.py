@@ -658,6 +658,9 @@ class BruteForce(object):
         #: host processes for the `lnpost` stage when objects have their own
         #: RNG seed (`_fit(seed0=...)`, `parallel.fit_sharded`); 0/1 = in-process
         self.host_workers = 0
+        #: device `lnpost` mode: scan batch k+1 on a second stream while `lnpost`
+        #: of batch k runs (costs a second workspace)
+        self.scan_ahead = True
 
     # -- device state -------------------------------------------------------
     def _engine(self):
@@ -1023,15 +1026,50 @@ class BruteForce(object):
         gp = lngalprior.device_params()
         K = Ndraws * (2 if return_distreds else 1)
         Ndata = data.shape[0]
-        for a in range(0, Ndata, step):
+        starts = list(range(0, Ndata, step))
+        # The grid scan of batch k+1 runs ahead on its own stream / engine
+        # (workspace + record buffers) in a helper thread while this thread runs
+        # `lnpost` of batch k and the caller consumes the rows: the two stages
+        # share nothing but the read-only grid, and the random-stream positions
+        # only chain the `lnpost` calls, which stay in order here.
+        ahead = len(starts) > 1 and self.scan_ahead
+        if ahead:
+            import concurrent.futures
+            e2 = getattr(self, "_engine_obj2", None)
+            if e2 is None or e2.batch != eng.batch or e2.grid is not eng.grid:
+                self._engine_obj2 = _Engine(eng.grid, max_batch=eng.batch)
+            engines = (eng, self._engine_obj2)
+            streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+        else:
+            engines, streams, pool = (eng, eng), (None, None), None
+
+        def scan(k):
+            a = starts[k]
+            b = min(Ndata, a + step)
+            en = engines[k % 2]
+            with torch.cuda.device(dev):
+                if streams[k % 2] is None:
+                    f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
+                                                    parallax[a:b], parallax_err[a:b])
+                    return en.records_device(f, e, m, p, pe, hp, params)
+                with torch.cuda.stream(streams[k % 2]):
+                    f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
+                                                    parallax[a:b], parallax_err[a:b])
+                    out = en.records_device(f, e, m, p, pe, hp, params)
+                    streams[k % 2].synchronize()
+                    return out
+
+        fut = pool.submit(scan, 0) if ahead else None
+        for kb, a in enumerate(starts):
             b = min(Ndata, a + step)
             S = b - a
             with torch.cuda.device(dev):
-                f, e, m, p, pe, hp = eng._upload(data[a:b], data_err[a:b],
-                                                 data_mask[a:b], parallax[a:b],
-                                                 parallax_err[a:b])
-                (sel_idx, sel_vals, sel_off, off, ndim, k1,
-                 k2) = eng.records_device(f, e, m, p, pe, hp, params)
+                if ahead:
+                    (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = fut.result()
+                    fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
+                else:
+                    (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = scan(kb)
                 pp = _lib.PostParams()
                 pp.nmc, pp.ndraws = int(Nmc_prior), int(Ndraws)
                 pp.return_distreds = 1 if return_distreds else 0
