@@ -643,14 +643,11 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
     const int ppb = (npts + CLUSTER_CHUNKS - 1) / CLUSTER_CHUNKS;
     const int nchunk = (npts + ppb - 1) / ppb;
     const dim3 g((nobj + 63) / 64, nchunk);
-    const size_t shmem = sizeof(double) * (size_t)ppb * (nb + 2);
-    if (shmem > 60000)
-        return fail(BRUTUS_EINVAL, "isochrone table too large: %d points x %d bands", npts, nfilt);
     Timer tm(st);
     tm.begin("k_cluster");
 #define BRUTUS_CL(N)                                                                              \
     case N:                                                                                       \
-        hipLaunchKernelGGL(k_cluster<N>, g, dim3(64), shmem, st, nobj, nfilt, npts, d_pts_flux,   \
+        hipLaunchKernelGGL(k_cluster<N>, g, dim3(64), 0, st, nobj, nfilt, npts, d_pts_flux,       \
                            d_pts_lnw, d_phot, d_ivar, d_chi2_p, d_lnorm, d_ndim, dim_prior, ppb,  \
                            pm, ps);                                                               \
         break;

@@ -22,27 +22,17 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
           const double *__restrict__ ivar, const double *__restrict__ chi2_p,
           const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
           int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
-    // This workgroup's slice of the point table, staged once as
-    // [point][NB fluxes (0 beyond nb) | lnw | "has a NaN band"]: the loop then reads
-    // it with broadcast ds_reads instead of a chain of dependent scalar loads.
-    extern __shared__ double s_pts[];
-    __shared__ double s_tbl[64];
+    // This workgroup's slice of the point table goes through LDS in sub-slices of
+    // SUB points, each staged as [point][NB fluxes (0 beyond nb) | lnw | "has a NaN
+    // band"]: the loop then reads it with broadcast ds_reads instead of a chain of
+    // dependent scalar loads.
     constexpr int STRIDE = NB + 2;
+    constexpr int SUB = 12288 / (STRIDE * 8);          // 12 KB per 64-lane workgroup: 3+ waves per SIMD
+    __shared__ double s_pts[SUB * STRIDE];
+    __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     const int p0 = blockIdx.y * pts_per_block;
-    const int np = min(npts, p0 + pts_per_block) - p0;
-    for (int c = threadIdx.x; c < np; c += 64) {
-        const double *src = pts_flux + (int64_t)(p0 + c) * nb;
-        bool hole = false;
-        for (int b = 0; b < NB; ++b) {
-            const double v = b < nb ? src[b] : 0.;
-            hole = hole || (v != v);
-            s_pts[c * STRIDE + b] = v;
-        }
-        s_pts[c * STRIDE + NB] = pts_lnw[p0 + c];
-        s_pts[c * STRIDE + NB + 1] = hole ? 1. : 0.;
-    }
-    __syncthreads();
+    const int p1 = min(npts, p0 + pts_per_block);
     const int o = blockIdx.x * 64 + threadIdx.x;
     const bool live = o < nobj;
     const int oo = live ? o : 0;
@@ -57,44 +47,60 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     const double c0 = -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.);
     const double c1 = k / 2. - 1.;
     double m = -INFINITY, ssum = 0.;
-    for (int c = 0; c < np; ++c) {
-        const double *f = s_pts + c * STRIDE;
-        double fb[NB];
-#pragma unroll
-        for (int b = 0; b < NB; ++b) fb[b] = f[b];
-        double chi2 = 0.;
-        // nansum (cluster.py:381): d and iv are finite (masked bands carry iv = 0),
-        // so a term is NaN exactly when the point lacks band b -- rare, and the
-        // same for every lane
-        if (f[NB + 1] == 0.) {
-#pragma unroll
+    for (int q0 = p0; q0 < p1; q0 += SUB) {
+        const int np = min(SUB, p1 - q0);
+        __syncthreads();                                   // previous sub-slice fully consumed
+        for (int c = threadIdx.x; c < np; c += 64) {
+            const double *src = pts_flux + (int64_t)(q0 + c) * nb;
+            bool hole = false;
             for (int b = 0; b < NB; ++b) {
-                const double t = d[b] - fb[b];
-                chi2 += t * t * iv[b];
+                const double v = b < nb ? src[b] : 0.;
+                hole = hole || (v != v);
+                s_pts[c * STRIDE + b] = v;
             }
-        } else {
-#pragma unroll
-            for (int b = 0; b < NB; ++b) {
-                const double t = d[b] - fb[b];
-                const double term = t * t * iv[b];
-                chi2 += term == term ? term : 0.;
-            }
+            s_pts[c * STRIDE + NB] = pts_lnw[q0 + c];
+            s_pts[c * STRIDE + NB + 1] = hole ? 1. : 0.;
         }
-        chi2 += cp;
-        double lnl;
-        if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
-            lnl = c0 + (c1 == 0. ? 0. : c1 * fast_log_r(chi2)) - chi2 / 2.;
-        else
-            lnl = -0.5 * (chi2 + ln0);
-        if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
-        // online logsumexp, one exponential per point
-        const double x = lnl + f[NB];
-        const double dx = x - m;
-        const double e = fast_exp_bf(-fabs(dx), s_tbl);
-        const bool up = dx > 0.;
-        const bool fin = x > -INFINITY;
-        ssum = up ? fma(ssum, e, 1.) : (fin ? ssum + e : ssum);
-        m = up ? x : m;
+        __syncthreads();
+        for (int c = 0; c < np; ++c) {
+            const double *f = s_pts + c * STRIDE;
+            double fb[NB];
+    #pragma unroll
+            for (int b = 0; b < NB; ++b) fb[b] = f[b];
+            double chi2 = 0.;
+            // nansum (cluster.py:381): d and iv are finite (masked bands carry iv = 0),
+            // so a term is NaN exactly when the point lacks band b -- rare, and the
+            // same for every lane
+            if (f[NB + 1] == 0.) {
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const double t = d[b] - fb[b];
+                    chi2 += t * t * iv[b];
+                }
+            } else {
+    #pragma unroll
+                for (int b = 0; b < NB; ++b) {
+                    const double t = d[b] - fb[b];
+                    const double term = t * t * iv[b];
+                    chi2 += term == term ? term : 0.;
+                }
+            }
+            chi2 += cp;
+            double lnl;
+            if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
+                lnl = c0 + (c1 == 0. ? 0. : c1 * fast_log_r(chi2)) - chi2 / 2.;
+            else
+                lnl = -0.5 * (chi2 + ln0);
+            if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
+            // online logsumexp, one exponential per point
+            const double x = lnl + f[NB];
+            const double dx = x - m;
+            const double e = fast_exp_bf(-fabs(dx), s_tbl);
+            const bool up = dx > 0.;
+            const bool fin = x > -INFINITY;
+            ssum = up ? fma(ssum, e, 1.) : (fin ? ssum + e : ssum);
+            m = up ? x : m;
+        }
     }
     if (live) {
         part_m[(int64_t)blockIdx.y * nobj + o] = m;

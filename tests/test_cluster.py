@@ -64,6 +64,23 @@ def test_hip_config5_size_vs_oracle():
     assert np.isfinite(a[0]) and a[1].shape == (5000,)
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("nbands", [5, 16, 20])
+def test_hip_band_counts_full_table_vs_oracle(nbands):
+    """Band counts that need padding (5 -> 8, 20 -> 24) and the default
+    15 x 2000 isochrone table, which no longer fits one LDS stage at >= 16
+    bands: the kernel walks it in sub-slices."""
+    from brutus_amd import cluster
+    from oracle import brutus_oracle as O
+    iso, phot, err, par, perr = make_cluster_data(60, nbands, 7)
+    a = cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par,
+                                  parallax_err=perr, return_lnls=True)
+    c = O.isochrone_loglike(THETA, iso, phot, err, parallax=par,
+                            parallax_err=perr, return_lnls=True)
+    assert relerr(c[1], a[1]) < 1e-9
+    assert abs(a[0] - c[0]) < 1e-8 * abs(c[0])
+
+
 def test_errors_match_reference_messages():
     from brutus_amd import cluster
     iso, phot, err, par, perr = make_cluster_data(20, 6, 3)
