@@ -276,6 +276,14 @@ __device__ __forceinline__ void compute_F0_fast(const Coef<NB> &c, double (&F0)[
 #pragma unroll
     for (int j = 0; j < NB; ++j) F0[j] = poly_exp10(-0.4 * (double)c.m[j]);
 }
+// ... or with the table-driven form where registers allow: bit-identical to the
+// tabulated F0 the scan reads
+template <int NB>
+__device__ __forceinline__ void compute_F0_tbl(const Coef<NB> &c, const double *__restrict__ tbl,
+                                               double (&F0)[NB]) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) F0[j] = fast_exp10(-0.4 * (double)c.m[j], tbl);
+}
 
 // lnl as `loglike` returns it for a model the cull dropped / kept, and the
 // first-cut statistic lnprob (fitting.py:806-815, 976-985; pdf.py:209-218).
@@ -591,6 +599,9 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
         double *__restrict__ part) {
     __shared__ double slot[12];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int nitem = wbase[nstar];
     const int niter = first ? 2 : 1;
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
@@ -606,7 +617,8 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
-            compute_F0_fast<NB>(c, F0);
+            if constexpr (RVF) compute_F0_tbl<NB>(c, s_tbl, F0);
+            else compute_F0_fast<NB>(c, F0);
             double av, rv, step, lnl_old;
             double R[RVF ? NB : 1];
             if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
@@ -638,7 +650,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = -0.5 * pl.chi2[o];
             }
             Mle m;
-            if constexpr (RVF) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
+            if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; it < niter; ++it) {
@@ -648,8 +660,8 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 av += dav;
                 if constexpr (RVF) {
                     // the Rv step is clamped to zero; only the stored MLE needs the Rv sums
-                    if (it + 1 < niter) mle_fast_rf<NB, false, false>(c, R, F0, sp, p, av, nullptr, m);
-                    else mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+                    if (it + 1 < niter) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
+                    else mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
                 } else {
                     double drv = (m.r_num + (p.rv_mean - rv) * p.rv_ivar) / (m.r_ss + p.rv_ivar) * step;
                     if (drv < p.rvmin - rv) drv = p.rvmin - rv;
@@ -740,6 +752,9 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
        const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
        const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
        int64_t capacity, double *__restrict__ sel_vals) {
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
     const int nitem = wbase[nstar];
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
         const int s = star_of_item(wbase, nstar, item);
@@ -761,7 +776,8 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
-            compute_F0_fast<NB>(c, F0);
+            if constexpr (RVF) compute_F0_tbl<NB>(c, s_tbl, F0);
+            else compute_F0_fast<NB>(c, F0);
             double av = p.av_mean, rv = p.rv_mean;
             const int K = k1[s];
             Mle m;
@@ -774,7 +790,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
                     double a_, c_;
                     gram_sweep_rf(G, sp.S, p, av, a_, c_);
                 }
-                mle_fast_rf<NB, false, true>(c, R, F0, sp, p, av, nullptr, m);
+                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
             } else {
                 Gram G;
                 gram_init<NB>(c, sp, G);
