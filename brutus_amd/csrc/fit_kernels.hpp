@@ -287,9 +287,14 @@ __device__ __forceinline__ void compute_F0_tbl(const Coef<NB> &c, const double *
 
 // lnl as `loglike` returns it for a model the cull dropped / kept, and the
 // first-cut statistic lnprob (fitting.py:806-815, 976-985; pdf.py:209-218).
+// FASTLOG: ln through fast_log_r (~45 instructions instead of ocml's ~90; a few
+// ulp) -- the pinned-Rv kernels, which have the registers for it.
+template <bool FASTLOG = false>
 __device__ __forceinline__ double final_lnl(const StarPrep &sp, const DevParams &p, double chi2,
                                             bool survivor) {
-    if (p.dim_prior) return chi2 > 0. ? sp.c0 + sp.c1 * log(chi2) - chi2 / 2. : -INFINITY;
+    if (p.dim_prior)
+        return chi2 > 0. ? sp.c0 + sp.c1 * (FASTLOG ? fast_log_r(chi2) : log(chi2)) - chi2 / 2.
+                         : -INFINITY;
     return survivor ? -0.5 * chi2 + sp.lnl_const : -0.5 * chi2;
 }
 __device__ __forceinline__ double first_cut_lnprob(const StarPrep &sp, double lnl, double scale,
@@ -384,7 +389,7 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnlp = lnl - 0.5 * (dp * dp * sp.par_ivar);
             }
             const double lnprob =
-                first_cut_lnprob(sp, final_lnl(sp, p, m.chi2, false), m.scale, m.i00);
+                first_cut_lnprob(sp, final_lnl<RVF>(sp, p, m.chi2, false), m.scale, m.i00);
             if (live) {
                 const int64_t o = (int64_t)s * pl.nmodel + i;
                 pl.lnlp[o] = lnlp;
@@ -678,7 +683,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             pl.av[o] = av;
             pl.rv[o] = rv;
             pl.step[o] = step;
-            const double lnl = final_lnl(sp, p, m.chi2, true);
+            const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
             const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
             pl.lnl[o] = lnl;
             pl.lnprob[o] = lnprob;
@@ -800,7 +805,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
                 }
                 mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             }
-            rec[0] = final_lnl(sp, p, m.chi2, false);
+            rec[0] = final_lnl<RVF>(sp, p, m.chi2, false);
             rec[1] = m.chi2;
             rec[2] = m.scale;
             rec[3] = av;
