@@ -157,7 +157,8 @@ __device__ __forceinline__ double fast_sqrt(double x) {
 // fast_exp without the early-out branch (selects instead)
 __device__ __forceinline__ double fast_exp_bf(double x, const double *__restrict__ tbl) {
     const double xc = fmax(x, -745.);                // also maps NaN to -745; fixed below
-    const double n = rint(xc * 92.332482616893657);
+    const double ns = fma(xc, 92.332482616893657, 6755399441055744.0);   // 1.5 * 2^52 shift
+    const double n = ns - 6755399441055744.0;
     double r = fma(-n, 0.01083042469326756, xc);
     r = fma(-n, 2.9815858269852933e-12, r);
     double pl = 8.3333333333333332e-03;
@@ -166,7 +167,7 @@ __device__ __forceinline__ double fast_exp_bf(double x, const double *__restrict
     pl = fma(pl, r, 0.5);
     pl = fma(pl, r, 1.0);
     pl = fma(pl, r, 1.0);
-    const int ni = (int)n;
+    const int ni = __double2loint(ns);
     const double v = ldexp(tbl[ni & 63] * pl, ni >> 6);
     return x > -745. ? v : (x == x ? 0. : x);
 }
