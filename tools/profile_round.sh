@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 for cfg in 2 3; do
   rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_cfg${cfg} -o t -- python $R/bench.py --config $cfg \
       --steps 8 --warmup 2 --batch $B --streams 1 --cpu-seconds 0 --e2e-stars 0 \
-      > $O/${tag}_bench_under_rocprof_cfg${cfg}.json 2> $O/${tag}_trace_cfg${cfg}.log
+      > $O/${tag}_bench_under_rocprof_cfg${cfg}_b${B}.json 2> $O/${tag}_trace_cfg${cfg}.log
 done
 for cfg in 2 3; do
   for ctr in FETCH_SIZE WRITE_SIZE; do
@@ -32,5 +32,5 @@ for cfg in 2 3; do
   python tools/rocpd_summary.py $(db ${tag}_pmc_WRITE_SIZE_cfg${cfg}) > $O/${tag}_pmc_write_cfg${cfg}_b${B}.txt
   python tools/pmc_to_json.py $(db ${tag}_pmc_FETCH_SIZE_cfg${cfg}) $(db ${tag}_pmc_WRITE_SIZE_cfg${cfg}) $cfg $B 268435456 $O/${tag}_pmc_traffic.json
 done
-tail -1 $O/${tag}_bench_under_rocprof_cfg2.json | cut -c1-400
+tail -1 $O/${tag}_bench_under_rocprof_cfg2_b${B}.json | cut -c1-400
 head -12 $O/${tag}_kernel_trace_cfg2_b${B}.txt
