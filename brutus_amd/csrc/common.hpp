@@ -49,6 +49,7 @@ struct StarPrep {
     double c0, c1;      // chi-square logpdf constants    (utils.py:169-170)
     double par, par_ivar;        // parallax, 1/err^2 for the cull (fitting.py:749-756)
     double sp_mean, sp_var;      // pdf.py:252-255 scale-space parallax Gaussian
+    double D2;          // sum_j d_j^2 / V_j (single-pass chi2 of the fused scan)
     int ndim;
     int has_par;        // finite parallax & error
     int sp_on;          // p/err > 4 (pdf.py:209)

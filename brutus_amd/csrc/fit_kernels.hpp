@@ -260,6 +260,37 @@ __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)
     o.i22 = r_den;
 }
 
+// The three MLE quantities the fused scan needs (scale, chi2, i00 = sum F^2/V) in
+// ONE pass over the bands: with s = sum(d F / V) / sum(F^2 / V),
+//   chi2 = sum (d - s F)^2 / V = D2 - 2 s sum(d F / V) + s^2 sum(F^2 / V),
+// D2 = sum d^2 / V being a per-star constant (StarPrep::D2).  No per-band flux
+// array stays live (24 VGPRs at 12 bands) and the second band loop goes away.
+// The expansion cancels ~4 digits (D2 ~ 1e4-1e5 against chi2 ~ 10): chi2 is good
+// to ~1e-11 absolute -- it only feeds the cull / first-cut decisions here; every
+// reported value comes from the two-pass form (mle_fast*).
+template <int NB, bool RVF>
+__device__ __forceinline__ void mle_scan(const Coef<NB> &c, const double (&R)[RVF ? NB : 1],
+                                         const double (&F0)[NB], const StarPrep &sp, double av,
+                                         double rv, const double *__restrict__ tbl, Mle &o) {
+    const double mav = -0.4 * av;
+    double s_num = 0., s_den = 0.;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        double Rj;
+        if constexpr (RVF) Rj = R[j];
+        else Rj = (double)c.r0[j] + rv * (double)c.dr[j];
+        const double f = F0[j] * fast_exp10(mav * Rj, tbl);
+        const double fw = f * sp.iV[j];
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    o.scale = s;
+    o.i00 = s_den;
+    o.chi2 = fma(-s, s_num, sp.D2) + s * fma(s, s_den, -s_num);
+}
+
 // F0 of model i from the band-major table (coalesced) / of one model from its row.
 template <int NB>
 __device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t nmodel_pad,
@@ -366,7 +397,7 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                         if (fabs(dav) >= p.mtol && lw > c0[TILE]) c0[TILE] = lw;
                     }
                 }
-                mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
+                mle_scan<NB, true>(c, R, F0, sp, av, rv, s_tbl, m);
             } else {
                 Gram G;
                 gram_init<NB>(c, sp, G);
@@ -380,7 +411,7 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                         if (big && lw > c0[TILE]) c0[TILE] = lw;
                     }
                 }
-                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                mle_scan<NB, false>(c, R, F0, sp, av, rv, s_tbl, m);
             }
             const double lnl = -0.5 * m.chi2;
             double lnlp = lnl;

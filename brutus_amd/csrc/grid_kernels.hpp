@@ -193,7 +193,7 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
     if (s >= nstar) return;
     StarPrep sp;
     int ndim = 0;
-    double S = 0., sumlnv = 0.;
+    double S = 0., sumlnv = 0., D2 = 0.;
     const double kmag = 2.5 / log(10.);
     for (int j = 0; j < NBMAX; ++j) {
         double d = 0., iv = 0., g = 0., iw = 0.;
@@ -215,6 +215,7 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
                 }
                 iw = 1. / W;
                 S += 1. / W;
+                D2 += f * f * iv;
             }
         }
         sp.d[j] = d;
@@ -223,6 +224,7 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
         sp.iW[j] = iw;
     }
     sp.S = S;
+    sp.D2 = D2;
     sp.ndim = ndim;
     sp.lnl_const = -0.5 * (ndim * log(2. * M_PI) + sumlnv);
     const double df = (double)(ndim - 3);
