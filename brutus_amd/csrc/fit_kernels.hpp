@@ -388,13 +388,21 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             if constexpr (RVF) {
                 GramR G;
                 gram_init_rf<NB>(c, R, sp, G);
-                for (int k = 0; k < K; ++k) {
-                    double dav, lw;
-                    gram_sweep_rf(G, sp.S, p, av, dav, lw);
-                    if (k < KS && live && lw == lw) {
+                // With Rv pinned the objective is exactly quadratic in (offset, Av)
+                // and a sweep is its Newton step with the offset eliminated: the
+                // first sweep lands on the (clamped) minimiser, every later one
+                // moves by rounding noise (<< mtol) and leaves logwt unchanged.
+                // So one sweep is computed; sweeps 2..K only enter the statistics
+                // (L_k = L_1, no step above tolerance), which makes K1 <= 2 as in
+                // the reference.
+                double dav, lw;
+                gram_sweep_rf(G, sp.S, p, av, dav, lw);
+                if (live && lw == lw) {
+                    if (lw > col[0]) col[0] = lw;
+                    if (fabs(dav) >= p.mtol && lw > col[TILE]) col[TILE] = lw;
+                    for (int k = 1; k < K && k < KS; ++k) {
                         double *c0 = col + (size_t)(2 * k) * TILE;
                         if (lw > c0[0]) c0[0] = lw;
-                        if (fabs(dav) >= p.mtol && lw > c0[TILE]) c0[TILE] = lw;
                     }
                 }
                 mle_scan<NB, true>(c, R, F0, sp, av, rv, s_tbl, m);
@@ -665,6 +673,8 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 if constexpr (RVF) {
                     GramR G;
                     gram_init_rf<NB>(c, R, sp, G);
+                    // (a single sweep would do, see k_fscan; the loop form keeps this
+                    // kernel's register allocation below the spill line)
                     for (int k = 0; k < K; ++k) {
                         double a_, c_;
                         gram_sweep_rf(G, sp.S, p, av, a_, c_);
@@ -822,10 +832,8 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
                 coef_R<NB>(c, rv, R);
                 GramR G;
                 gram_init_rf<NB>(c, R, sp, G);
-                for (int k = 0; k < K; ++k) {
-                    double a_, c_;
-                    gram_sweep_rf(G, sp.S, p, av, a_, c_);
-                }
+                double a_, c_;
+                if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
                 mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
             } else {
                 Gram G;
