@@ -229,6 +229,46 @@ def test_full_size_properties():
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("config", [2, 3])
+def test_full_size_fit_records_vs_c_oracle(config):
+    """BASELINE configs[1] / configs[2] at their full size (750k x 12, the bench's
+    grid and star generator): the compact records of the fast path against the
+    C restatement of `loglike` + the first cut of `lnpost`, six stars each."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.pdf import scale_parallax_lnprior
+    from oracle import c_oracle
+    models, _, _ = synth.make_mist_like_grid(750000, 12)
+    with_par = config == 3
+    st = synth.make_stars(models, 6, seed=1 if config == 2 else 2, with_parallax=with_par)
+    kw = dict(rvlim=(3.32, 3.32)) if config == 2 else dict()
+    par = st["parallax"] if with_par else np.full(6, np.nan)
+    perr = st["parallax_err"] if with_par else np.full(6, np.nan)
+    grid = fitting.DeviceGrid(models)
+    eng = fitting._Engine(grid, max_batch=6)
+    params = fitting._make_params((0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)),
+                                  (3.32, 0.18), 3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    recs = eng.fit_batch(st["flux"], st["err"], st["mask"], par, perr, params)
+    for i, rec in enumerate(recs):
+        tr = {}
+        lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+            st["flux"][i], st["err"][i], st["mask"][i], models, parallax=par[i],
+            parallax_err=perr[i], trace=tr, **kw)
+        with np.errstate(all="ignore"):
+            lnprob = lnl + scale_parallax_lnprior(
+                sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), par[i], perr[i])
+        lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+        sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
+        assert rec["K1"] == tr["K1"] and rec["K2"] == tr["K2"], (config, i)
+        assert np.array_equal(sel, rec["sel"]), (config, i)
+        assert relerr(lnl[sel], rec["lnlike"]) < RTOL
+        assert relerr(chi2[sel], rec["chi2"]) < RTOL
+        assert relerr(sc[sel], rec["scale"]) < RTOL
+        assert np.max(np.abs(av[sel] - rec["av"])) < 1e-8
+        assert relerr(rv[sel], rec["rv"]) < RTOL
+        d = np.sqrt(np.abs(np.einsum('nii->ni', icov[sel])))
+        assert np.max(np.abs(rec["icov"] - icov[sel]) / (d[:, :, None] * d[:, None, :])) < RTOL
+
+
 def test_fit_records_vs_oracle_all_cases():
     """The fast fit path (fused scan + compact flux phase) against the oracle's
     loglike + first cut, on stars that need K1 = 1, 2 and > 2 sweeps and
