@@ -115,6 +115,44 @@ def test_device_lnpost_shared_stream_vs_oracle():
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
 
 
+def test_full_size_fit_vs_oracle():
+    """The whole per-object result at the bench's size and defaults (750k x 12,
+    Nmc_prior=50, Ndraws=250, ~10^5 models per object through the Monte Carlo
+    integral): fused scan + device `lnpost` against the oracle -- C `loglike`
+    followed by the numpy `lnpost` / resampling -- driven by the same
+    PhiloxRandomState."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    from oracle import c_oracle
+    models, labels, lmask = synth.make_mist_like_grid(750000, 12)
+    st = synth.make_stars(models, 2, seed=2)
+    lnprior = O.static_lnprior(labels, lmask)
+    BF = fitting.BruteForce(models, labels, lmask)
+    BF.batch_size = 2
+    rs = PhiloxRandomState(77)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], rstate=rs,
+                       Nmc_prior=50, Ndraws=250))      # fit()'s defaults (_fit's differ)
+    ro = PhiloxRandomState(77)
+    py_loglike = O.loglike
+    O.loglike = lambda *a, return_vals=True, **k: c_oracle.loglike(*a, **k)
+    try:
+        for i in range(2):
+            ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                             labels, st["coords"][i], st["parallax"][i],
+                             st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=50,
+                             Ndraws=250)
+            assert np.array_equal(dev[i][0], ref[0]), "resampled indices, object %d" % i
+            for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
+                assert relerr(a, b) < 1e-6, (i, n, relerr(a, b))
+    finally:
+        O.loglike = py_loglike
+    assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
 def test_device_lnpost_per_object_and_host_agree():
     """seed0 + 'philox': per-object streams; the device path, the host path with
     the same rstate objects and the oracle all agree, for any batching."""
