@@ -5,7 +5,7 @@ with the ORACLE run on the same `rstate` -- indices bit-exact."""
 import numpy as np
 import pytest
 
-from helpers import relerr
+from helpers import galprior, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -229,3 +229,79 @@ def test_device_lnpost_vs_reference_golden():
         for n, got in zip(NAMES[1:], out[1:]):
             assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
     assert (rs.n_normal, rs.n_uniform) == (int(z["n_normal"]), int(z["n_uniform"]))
+
+
+def test_lnprior_ext_vs_oracle():
+    """External per-object Gaussian label constraints (fitting.py:1993-2009): the
+    full-grid device outputs + host cut, against the oracle pieces assembled the
+    way the reference's star loop does."""
+    from scipy.special import logsumexp
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nmodel=4000, nstar=4, seed=51)
+    ext = {"feh": np.array([[-0.3, 0.2], [np.nan, 0.2], [0.1, 0.0], [-1.0, 0.5]])}
+    with pytest.raises(ValueError, match="do not match"):
+        list(BF._fit(st["flux"], st["err"], st["mask"], lnprior=lnprior, lngalprior=galprior,
+                     data_coords=st["coords"], lnprior_ext={"nope": ext["feh"]},
+                     rstate=np.random.RandomState(1)))
+    rs = np.random.RandomState(5)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=15, lnprior=lnprior,
+                       lngalprior=galprior, data_coords=st["coords"], Ndraws=30,
+                       lnprior_ext=ext, rstate=rs))
+    ro = np.random.RandomState(5)
+    for i in range(4):
+        par, perr = st["parallax"][i], st["parallax_err"][i]
+        res = list(O.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
+                             av_gauss=(0., 1e6), parallax=par, parallax_err=perr,
+                             return_vals=True))
+        mean, std = ext["feh"][i]
+        if np.isfinite(mean) and std > 0:
+            res[0] = res[0] - 0.5 * ((labels["feh"] - mean) ** 2 / std ** 2
+                                     + np.log(2. * np.pi * std ** 2))
+        sel, cov, lnp, dists, reds, dreds, logwts = O.lnpost(
+            tuple(res), parallax=par, parallax_err=perr, coord=st["coords"][i],
+            Nmc_prior=15, lnprior=lnprior, wt_thresh=1e-3, lngalprior=galprior,
+            lndustprior=None, dlabels=labels, avlim=(0., 20.), rvlim=(1., 8.), rstate=ro,
+            apply_av_prior=False, mem_lim=8000.)
+        wt = np.exp(lnp - logsumexp(lnp))
+        wt /= wt.sum()
+        idxs = ro.choice(len(sel), size=30, p=wt)
+        assert np.array_equal(dev[i][0], sel[idxs]), i
+        assert relerr(lnp[idxs], dev[i][6]) < 1e-8
+        assert abs(dev[i][7] - logsumexp(lnp)) < 1e-8 * abs(logsumexp(lnp))
+        # second resampling stage consumes the stream too
+        wts = np.exp(logwts[idxs] - logsumexp(logwts[idxs], axis=1)[:, None])
+        for j in range(30):
+            ro.choice(15, p=wts[j] / wts[j].sum())
+
+
+def test_fit_options_device_equals_host(tmp_path):
+    """`save_dar_draws=False` + `running_io=False` through the public `fit()`: the
+    device `lnpost` mode writes the file the host stage writes for the same
+    PhiloxRandomState, and the sample datasets are absent."""
+    import os
+    from brutus_amd import h5io
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    BF, models, labels, st, lnprior = _setup(nmodel=5000, nstar=7, seed=61)
+    BF.batch_size = 3
+    files = []
+    for mode in (True, False):
+        BF.device_lnpost = mode
+        path = os.path.join(str(tmp_path), "dev" if mode else "host")
+        BF.fit(st["flux"], st["err"], st["mask"], np.arange(7), path,
+               parallax=st["parallax"], parallax_err=st["parallax_err"],
+               data_coords=st["coords"], lngalprior=gal_lnprior, Nmc_prior=12, Ndraws=25,
+               save_dar_draws=False, running_io=False, rstate=PhiloxRandomState(9),
+               verbose=False)
+        files.append(path + ".h5")
+    BF.device_lnpost = True
+    names = set(h5io.list_datasets(files[0]))
+    assert names == set(h5io.list_datasets(files[1]))
+    assert not any(n.startswith("samps_") for n in names)
+    assert np.array_equal(h5io.read_dataset(files[0], "model_idx"),
+                          h5io.read_dataset(files[1], "model_idx"))
+    for n in ("ml_scale", "ml_av", "ml_rv", "ml_cov_sar", "obj_log_post", "obj_log_evid",
+              "obj_chi2min", "obj_Nbands"):
+        a, b = h5io.read_dataset(files[0], n), h5io.read_dataset(files[1], n)
+        assert np.allclose(a, b, rtol=2e-6, atol=0), n
