@@ -305,3 +305,28 @@ def test_fit_options_device_equals_host(tmp_path):
               "obj_chi2min", "obj_Nbands"):
         a, b = h5io.read_dataset(files[0], n), h5io.read_dataset(files[1], n)
         assert np.allclose(a, b, rtol=2e-6, atol=0), n
+
+
+def test_user_dust_prior_hook_vs_oracle():
+    """A user `lndustprior(dists, coord, avs, dustfile=)` hook with `av_gauss=None`
+    (fitting.py:1010, 1085, 1396-1398): host stage on device records, and
+    `logl_dim_prior=False` + custom `avlim`, against the oracle."""
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nmodel=4000, nstar=5, seed=71)
+    BF.batch_size = 2
+
+    def dust(dists, coord, avs, dustfile=None):
+        return -0.5 * ((avs - 0.4 * np.log1p(dists)) / 0.6) ** 2
+
+    kw = dict(Nmc_prior=12, Ndraws=25, avlim=(0., 6.))
+    rs = np.random.RandomState(3)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], lnprior=lnprior, lngalprior=galprior,
+                       lndustprior=dust, data_coords=st["coords"], logl_dim_prior=False,
+                       rstate=rs, **kw))
+    ro = np.random.RandomState(3)
+    for i in range(5):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior, labels,
+                         st["coords"][i], st["parallax"][i], st["parallax_err"][i], ro,
+                         galprior, lndustprior=dust, dim_prior=False, **kw)
+        _compare(dev[i], ref, i)
