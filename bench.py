@@ -130,7 +130,7 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     # lnpost + resampling on the device (built-in priors, counter-based rstate)
     from brutus_amd.rng import PhiloxRandomState
     bf.host_workers = 0
-    n3 = 1024
+    n3 = 4096          # enough objects to amortise file creation and the first batch
     big = synth.make_stars(models, n3, seed=4242, with_parallax=with_par)
     bf.batch_size = 128
     for rep in range(2):          # first pass warms the workspaces
