@@ -822,8 +822,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
-            if constexpr (RVF) compute_F0_tbl<NB>(c, s_tbl, F0);
-            else compute_F0_fast<NB>(c, F0);
+            compute_F0_tbl<NB>(c, s_tbl, F0);
             double av = p.av_mean, rv = p.rv_mean;
             const int K = k1[s];
             Mle m;
@@ -842,7 +841,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
                     double a_, b_, c_;
                     gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
                 }
-                mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             }
             rec[0] = final_lnl<RVF>(sp, p, m.chi2, false);
             rec[1] = m.chi2;
