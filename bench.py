@@ -426,6 +426,20 @@ def main():
                     "avg_launch_ms": avg[dom],
                     "all_kernels_ms": avg,
                     "algorithmic_bytes_per_launch": B * bytes_per_star}
+        # measured on this box beside the 8 TB/s spec figure: a plain streaming
+        # kernel (1 GiB read with 4 B/lane, 2 GiB written with 8 B/lane)
+        n_cal = 256 << 20
+        src = torch.empty(n_cal, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty(n_cal, dtype=torch.float64, device=dev)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        _lib.check(L.brutus_calibrate_traffic(src.data_ptr(), dst.data_ptr(), n_cal, None))
+        e0.record()
+        for _ in range(3):
+            _lib.check(L.brutus_calibrate_traffic(src.data_ptr(), dst.data_ptr(), n_cal, None))
+        e1.record()
+        torch.cuda.synchronize()
+        roofline["measured_stream_gbs"] = 3 * 12.0 * n_cal / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        del src, dst
 
     if world > 1:
         dist.barrier()
