@@ -89,6 +89,8 @@ SIGNATURES = {
     "brutus_debug_rng": (C.c_int, [_u64, _u64, _i64, _vp, _vp, _vp]),
     "brutus_debug_galprior": (C.c_int, [C.POINTER(PostParams), _i32, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
+    "brutus_debug_copy": (C.c_int, [_vp, _sz, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "brutus_debug_sizeof_star32": (C.c_int, []),
     "brutus_cluster_workspace_bytes": (_sz, [_i32]),
     "brutus_cluster_lnl": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _i32, _vp, _sz, _vp, _vp]),

@@ -37,7 +37,11 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <stdlib.h>
+
+#include <mutex>
 #include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/brutus_amd.h"
@@ -46,6 +50,7 @@
 #include "fastmath.hpp"
 #include "grid_kernels.hpp"
 #include "fit_kernels.hpp"
+#include "fit2_kernels.hpp"
 #include "cluster_kernels.hpp"
 #include "post_kernels.hpp"
 
@@ -82,6 +87,16 @@ struct Workspace {
     int64_t *surv_off;  // (S + 1,)
     int32_t *wbase_surv, *wbase_sel;   // (S + 1,)
     unsigned long long *mask;          // (S, nmodel_pad / 64) membership words
+    // second-generation path (fit2_kernels.hpp)
+    Star32 *s32;                       // (S,)
+    float *lnlp32, *lnpr32;            // (S, nmodel) float32 statistics
+    float *part32, *st32;              // (nblk2, S, NV32), (S, NV32)
+    int32_t *status, *ids_all;         // (S,)
+    double *nomA, *nomB, *candS;       // (S,)
+    unsigned long long *smask;         // survivor bit-mask, layout of `mask`
+    float *aud;                        // (S,) run-time audit of eps
+    StarPrep *stars_tmp;               // (1,) scratch for the deep K1 probe
+    size_t part_doubles;
     size_t bytes;
 };
 
@@ -112,7 +127,9 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         for (int q = 0; q < 6; ++q) w.pl.icov[q] = (double *)take(plane);
     }
     w.stars = (StarPrep *)take(sizeof(StarPrep) * nstar);
-    w.part = (double *)take(sizeof(double) * (size_t)ntile * nstar * 2 * KCAP);
+    w.part_doubles = (size_t)ntile * (size_t)(nstar * 2 * KCAP > 1024 ? nstar * 2 * KCAP : 1024);
+    w.part = (double *)take(sizeof(double) * w.part_doubles);
+    w.stars_tmp = (StarPrep *)take(sizeof(StarPrep));
     w.vmax_lnlp = (double *)take(sizeof(double) * nstar);
     w.k1 = (int32_t *)take(sizeof(int32_t) * nstar);
     w.k2 = (int32_t *)take(sizeof(int32_t) * nstar);
@@ -134,6 +151,20 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         w.wbase_sel = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
         w.mask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
                                             (size_t)(pad_models(nmodel) / 64));
+        const size_t nblk2 = (size_t)(ntile + F2_T - 1) / F2_T;
+        w.s32 = (Star32 *)take(sizeof(Star32) * nstar);
+        w.lnlp32 = (float *)take(sizeof(float) * (size_t)nstar * (size_t)nmodel);
+        w.lnpr32 = (float *)take(sizeof(float) * (size_t)nstar * (size_t)nmodel);
+        w.part32 = (float *)take(sizeof(float) * nblk2 * nstar * NV32);
+        w.st32 = (float *)take(sizeof(float) * nstar * NV32);
+        w.status = (int32_t *)take(sizeof(int32_t) * nstar);
+        w.ids_all = (int32_t *)take(sizeof(int32_t) * nstar);
+        w.nomA = (double *)take(sizeof(double) * nstar);
+        w.nomB = (double *)take(sizeof(double) * nstar);
+        w.candS = (double *)take(sizeof(double) * nstar);
+        w.smask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
+                                             (size_t)(pad_models(nmodel) / 64));
+        w.aud = (float *)take(sizeof(float) * nstar * 4);
     }
     w.bytes = off;
     return w;
@@ -204,6 +235,11 @@ struct Timer {
     }
 };
 
+struct Workspace;
+template <int NB>
+int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &p, int max_iter,
+                  Workspace &w, int32_t *k1_out, hipStream_t st);
+
 template <int NB>
 int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &p,
                  int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
@@ -227,9 +263,18 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
         HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (h_unconv == 0) break;
-        if (kmax >= KCAP || kmax >= max_iter)
+        if (kmax >= max_iter)
             return fail(BRUTUS_ENOCONV, "magnitude phase not converged after %d sweeps for %d star(s)",
                         kmax, h_unconv);
+        if (kmax >= KCAP) {     // the few stars that need more: one by one, no cap but max_iter
+            std::vector<int32_t> hk(nstar);
+            HIP_TRY(hipMemcpyAsync(hk.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int s = 0; s < nstar; ++s)
+                if (hk[s] == 0)
+                    if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &hk[s], st)) return rc;
+            break;
+        }
         kmax = kmax * 2 > KCAP ? KCAP : kmax * 2;
     }
 
@@ -315,13 +360,15 @@ int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector
 template <int NB, bool RVF>
 int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParams &p, Workspace &w,
                     int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
-                    hipStream_t st, Timer &tm) {
+                    hipStream_t st, Timer &tm, int path = 1) {
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     tm.begin("k_select");
-    hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                       w.pl.lnprob, w.thr_sel, (const double *)nullptr, w.counts,
-                       (double *)nullptr, w.mask);
+    if (path == 1)
+        hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
+                           w.pl.lnprob, w.thr_sel, (const double *)nullptr, w.counts,
+                           (double *)nullptr, w.mask);
+    // path 2: k_select2 has already left the membership words and the chunk counts
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts,
                        w.offsets, d_sel_off, w.wbase_sel);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
@@ -330,7 +377,8 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     tm.begin("k_emit");
     hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                        nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
-                       w.wbase_sel, w.pl, capacity, d_sel_vals);
+                       w.wbase_sel, w.pl, capacity, d_sel_vals,
+                       path == 2 ? (const float *)w.lnlp32 : (const float *)nullptr);
     tm.end();
     HIP_TRY(hipGetLastError());
     return 0;
@@ -365,8 +413,11 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
         HIP_TRY(hipStreamSynchronize(st));
         std::vector<int32_t> listC;
         for (int s : listB) {
-            if (k1[s] == 0 || k1[s] > max_iter)
-                return fail(BRUTUS_ENOCONV, "magnitude phase of star %d not converged after 8 sweeps", s);
+            if (k1[s] == 0)     // more than eight sweeps: probe deeper, no cap but max_iter
+                if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &k1[s], st)) return rc;
+            if (k1[s] > max_iter)
+                return fail(BRUTUS_ENOCONV, "magnitude phase of star %d needs %d sweeps (max_iter %d)", s,
+                            k1[s], max_iter);
             if (k1[s] != 8) {
                 kfix[s] = k1[s];
                 listC.push_back(s);
@@ -395,7 +446,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
         hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                            nmodel_pad, nstar, w.stars, p, w.k1, w.k2, first, w.surv_idx, w.surv_off,
-                           w.wbase_surv, w.pl, w.part);
+                           w.wbase_surv, w.pl, w.part, (float *)nullptr, (const double *)nullptr);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
@@ -420,17 +471,216 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     return 0;
 }
 
+
+// ---- second-generation fast path (fit2_kernels.hpp) -----------------------------
+std::mutex g_path_mu;
+std::unordered_map<const void *, int> g_ws_path;     // workspace -> path of its last fit (1 / 2)
+
+int env_int(const char *name, int dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atoi(v) : dflt;
+}
+double env_double(const char *name, double dflt) {
+    const char *v = getenv(name);
+    return v && *v ? atof(v) : dflt;
+}
+
+// Exact number of magnitude sweeps of ONE star by probing kmax = 16, 32, ... sweeps
+// with the residual-carrying kernels (no cap but max_iter; fitting.py:173-264).
+template <int NB>
+int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &p, int max_iter,
+                  Workspace &w, int32_t *k1_out, hipStream_t st) {
+    const int64_t nmodel_pad = pad_models(nmodel);
+    const int ntile = (int)(nmodel_pad / TILE);
+    HIP_TRY(hipMemcpyAsync(w.stars_tmp, w.stars + star, sizeof(StarPrep), hipMemcpyDeviceToDevice, st));
+    const int cap = (int)(w.part_doubles / ((size_t)ntile * 2));
+    for (int kmax = 16;; kmax *= 2) {
+        if (kmax > max_iter) kmax = max_iter;
+        if (kmax > cap) kmax = cap;
+        hipLaunchKernelGGL(k_mag_stats<NB>, dim3(ntile, 1), dim3(TILE), 0, st, grid, nmodel,
+                           nmodel_pad, 1, w.stars_tmp, p, kmax, w.part);
+        hipLaunchKernelGGL(k_k1_deep_decide, dim3(1), dim3(256), 0, st, ntile, kmax, w.part,
+                           p.ln_init, w.k1 + star);
+        HIP_TRY(hipMemcpyAsync(k1_out, w.k1 + star, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (*k1_out > 0) return 0;
+        if (kmax >= max_iter || kmax >= cap)
+            return fail(BRUTUS_ENOCONV, "magnitude phase of star %d not converged after %d sweeps",
+                        star, kmax);
+    }
+}
+
+template <int NB, bool RVF>
+int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
+                 const std::vector<int32_t> &ids, const std::vector<int32_t> &kfix,
+                 const DevParams &p, Workspace &w, int accept, hipStream_t st, Timer &tm) {
+    constexpr int G = 4;
+    const int64_t nmodel_pad = pad_models(nmodel);
+    const int ntile = (int)(nmodel_pad / TILE);
+    const int nblkx = (ntile + F2_T - 1) / F2_T;
+    const int nrun = (int)ids.size();
+    HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
+    P32 q;
+    q.avmin = (float)p.avmin;
+    q.avmax = (float)p.avmax;
+    q.rvmin = (float)p.rvmin;
+    q.rvmax = (float)p.rvmax;
+    q.av_mean = (float)p.av_mean;
+    q.av_ivar = (float)p.av_ivar;
+    q.rv_mean = (float)p.rv_mean;
+    q.rv_ivar = (float)p.rv_ivar;
+    q.mtol_hi = (float)(p.mtol * 1.002 + 1e-4);
+    q.mtol_lo = (float)(p.mtol * 0.998 - 1e-4);
+    q.dim_prior = p.dim_prior;
+    q.nfilt = nfilt;
+    tm.begin("k_pre32");
+    hipLaunchKernelGGL((k_pre32<NB, RVF, G>), dim3(nblkx, (nrun + G - 1) / G), dim3(TILE), 0, st, grid,
+                       nmodel, nmodel_pad, nstar, nrun, w.ids, w.s32, q, w.kfix, ntile, w.lnlp32,
+                       w.lnpr32, w.part32);
+    tm.end();
+    hipLaunchKernelGGL(k_pre_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, w.ids, w.part32,
+                       w.s32, (float)p.ln_init, RVF ? 1 : 0, w.kfix, accept, w.st32, w.k1, w.status,
+                       w.nomA);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <int NB, bool RVF>
+int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevParams &p,
+              int max_iter, Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
+              int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2, hipStream_t st, Timer &tm) {
+    constexpr int G = 4;
+    const int64_t nmodel_pad = pad_models(nmodel);
+    const int ntile = (int)(nmodel_pad / TILE);
+    const int nblkx = (ntile + F2_T - 1) / F2_T;
+    const dim3 blk(TILE);
+    std::vector<int32_t> ids(nstar), kfix(nstar, 2), k1(nstar, 0), status(nstar, 0);
+    for (int s = 0; s < nstar; ++s) ids[s] = s;
+    HIP_TRY(hipMemcpyAsync(w.ids_all, ids.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
+    const int audit_on = env_int("BRUTUS_AUDIT", 0);
+    float *aud = audit_on ? w.aud : nullptr;
+    if (aud) HIP_TRY(hipMemsetAsync(w.aud, 0, sizeof(float) * nstar * 4, st));
+
+    // ---- float32 pass over the whole grid; K1 where float32 can decide it ----------
+    hipLaunchKernelGGL(k_prep32, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.stars,
+                       (float)env_double("BRUTUS_EPS_SCALE", 1.0), p.dim_prior, w.s32);
+    if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm)) return rc;
+    HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(status.data(), w.status, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    std::vector<int32_t> probe, redo;
+    for (int s = 0; s < nstar; ++s) {
+        if (status[s] == 1) redo.push_back(s);
+        if (status[s] == 2) probe.push_back(s);
+    }
+    if (!probe.empty()) {   // float32 could not decide: exact probe (float64, up to 8 sweeps, then deeper)
+        for (int s : probe) kfix[s] = 8;
+        if (int rc = launch_fscan<NB, 8, 1, RVF>(grid, nmodel, nstar, probe, kfix, p, w, 0, st, tm)) return rc;
+        HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int s : probe) {
+            if (k1[s] == 0)
+                if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &k1[s], st)) return rc;
+            if (k1[s] > max_iter)
+                return fail(BRUTUS_ENOCONV, "magnitude phase of star %d needs %d sweeps (max_iter %d)", s,
+                            k1[s], max_iter);
+            kfix[s] = k1[s];
+            if (!RVF && k1[s] != 2) redo.push_back(s);
+        }
+    }
+    for (int s : redo) kfix[s] = k1[s];
+    if (!redo.empty())      // float32 statistics at the state after K1 sweeps
+        if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, redo, kfix, p, w, 1, st, tm)) return rc;
+
+    // ---- exact cull threshold ---------------------------------------------------------
+    tm.begin("k_top");
+    hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
+                       nmodel_pad, nstar, nstar, w.ids_all, w.stars, p, w.k1, ntile, 0, w.lnlp32,
+                       w.nomA, (const float *)nullptr, w.part32, w.part, aud);
+    tm.end();
+    hipLaunchKernelGGL(k_top_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids_all, 0, w.part,
+                       w.s32, p.ln_init, (const double *)nullptr, w.thr_cull, w.candS);
+
+    // ---- candidates (lnl_p~ >= thr_cull - eps) as ordered lists --------------------------
+    tm.begin("k_surv_compact");
+    hipLaunchKernelGGL(k_cmp_count32, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.lnlp32, w.candS,
+                       w.counts, w.smask);
+    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
+                       w.surv_off, w.wbase_surv);
+    hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.smask,
+                       w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
+    tm.end();
+
+    // ---- exact cull test + flux phase on the candidates -----------------------------------
+    hipLaunchKernelGGL(k_set_i32, dim3((nstar + 255) / 256), dim3(256), 0, st, w.k2, nstar, 2);
+    int32_t h_unconv = 0;
+    int iter = 2;
+    for (int first = 1;; first = 0) {
+        HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
+        tm.begin(first ? "k_fflux" : "k_fflux_cont");
+        hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), blk, 0, st, grid, nmodel,
+                           nmodel_pad, nstar, w.stars, p, w.k1, w.k2, first, w.surv_idx, w.surv_off,
+                           w.wbase_surv, w.pl, w.part, w.lnlp32, w.thr_cull);
+        tm.end();
+        hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
+                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
+        HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (h_unconv == 0) break;
+        if (iter >= max_iter)
+            return fail(BRUTUS_ENOCONV, "flux phase not converged after %d iterations for %d star(s)",
+                        iter, h_unconv);
+        ++iter;
+    }
+
+    // ---- exact first-cut threshold, selection mask, ordered lists, records ---------------
+    hipLaunchKernelGGL(k_nomB, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxsurv, w.s32, w.nomB);
+    tm.begin("k_top");
+    hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
+                       nmodel_pad, nstar, nstar, w.ids_all, w.stars, p, w.k1, ntile, 1, w.lnpr32,
+                       w.nomB, w.lnlp32, w.part32, w.part, aud ? aud + nstar : nullptr);
+    tm.end();
+    hipLaunchKernelGGL(k_top_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids_all, 1, w.part,
+                       w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
+    tm.begin("k_select2");
+    const size_t maxt = (size_t)(ntile / NCHUNK + 2);
+    const size_t shm = sizeof(unsigned long long) * 4 * maxt + sizeof(int32_t) * TILE * maxt;
+    hipLaunchKernelGGL((k_select2<NB, RVF>), dim3(NCHUNK, nstar), blk, shm, st, grid, nmodel, nmodel_pad,
+                       ntile, w.stars, w.s32, p, w.k1, w.lnlp32, w.lnpr32, w.thr_sel, w.pl, w.counts,
+                       w.mask, aud ? aud + 2 * nstar : nullptr);
+    tm.end();
+    if (int rc = run_select_emit<NB, RVF>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
+                                          d_sel_off, st, tm, 2))
+        return rc;
+    if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+    if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// which path brutus_fit_batch takes: 2 (default) unless BRUTUS_FIT_PATH=1
+int fit_path(int64_t nmodel) {
+    (void)nmodel;
+    return env_int("BRUTUS_FIT_PATH", 2) == 1 ? 1 : 2;
+}
+
 // Rv pinned by its limits at the value every fit starts from: the (offset, Av)
 // specialisation computes the same thing
 inline bool rv_pinned(const DevParams &p) { return p.rvmin == p.rvmax && p.rv_mean == p.rvmin; }
 
-int dispatch_fast(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
-                  int max_iter, Workspace &w, int64_t capacity, int32_t *d_sel_idx,
-                  double *d_sel_vals, int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2,
-                  hipStream_t st, Timer &tm) {
+int dispatch_fast(int nb, int path, int nfilt, const float *grid, int64_t nmodel, int nstar,
+                  const DevParams &p, int max_iter, Workspace &w, int64_t capacity,
+                  int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off, int32_t *h_k1,
+                  int32_t *h_k2, hipStream_t st, Timer &tm) {
     const bool rvf = rv_pinned(p);
 #define BRUTUS_CASE(N)                                                                             \
     case N:                                                                                        \
+        if (path == 2)                                                                             \
+            return rvf ? run_fast2<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,  \
+                                            d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm)  \
+                       : run_fast2<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity, \
+                                             d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);\
         return rvf ? run_fast<N, true>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,   \
                                        d_sel_vals, d_sel_off, h_k1, h_k2, st, tm)                  \
                    : run_fast<N, false>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,  \
@@ -446,16 +696,16 @@ int dispatch_fast(int nb, const float *grid, int64_t nmodel, int nstar, const De
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
 
-int dispatch_select_emit(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
-                         Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
-                         int64_t *d_sel_off, hipStream_t st, Timer &tm) {
+int dispatch_select_emit(int nb, int path, const float *grid, int64_t nmodel, int nstar,
+                         const DevParams &p, Workspace &w, int64_t capacity, int32_t *d_sel_idx,
+                         double *d_sel_vals, int64_t *d_sel_off, hipStream_t st, Timer &tm) {
     const bool rvf = rv_pinned(p);
 #define BRUTUS_CASE(N)                                                                             \
     case N:                                                                                        \
         return rvf ? run_select_emit<N, true>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,      \
-                                              d_sel_vals, d_sel_off, st, tm)                       \
+                                              d_sel_vals, d_sel_off, st, tm, path)                 \
                    : run_select_emit<N, false>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,     \
-                                               d_sel_vals, d_sel_off, st, tm);
+                                               d_sel_vals, d_sel_off, st, tm, path);
     switch (nb) {
         BRUTUS_CASE(8)
         BRUTUS_CASE(12)
@@ -578,7 +828,13 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt, int ns
     if (w.bytes > workspace_bytes) return fail(BRUTUS_ENOMEM, "workspace too small");
     hipStream_t st = (hipStream_t)stream;
     Timer tm(st);
-    int rc = dispatch_select_emit(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, w, capacity,
+    int path = 1;
+    {
+        std::lock_guard<std::mutex> lk(g_path_mu);
+        auto it = g_ws_path.find(d_workspace);
+        if (it != g_ws_path.end()) path = it->second;
+    }
+    int rc = dispatch_select_emit(padded_nb(nfilt), path, d_grid_soa, nmodel, nstar, p, w, capacity,
                                   d_sel_idx, d_sel_vals, d_sel_off, st, tm);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
@@ -607,8 +863,13 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
                              has_parallax, w, d_ndim, st))
         return rc;
     const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
-    int rc = dispatch_fast(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, max_iter, w, capacity,
-                           d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);
+    const int path = fit_path(nmodel);
+    {
+        std::lock_guard<std::mutex> lk(g_path_mu);
+        g_ws_path[d_workspace] = path;
+    }
+    int rc = dispatch_fast(padded_nb(nfilt), path, nfilt, d_grid_soa, nmodel, nstar, p, max_iter, w,
+                           capacity, d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);
@@ -929,6 +1190,36 @@ int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n, void
     HIP_TRY(hipGetLastError());
     return 0;
 }
+
+
+int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel, int nfilt, int nstar,
+                      int which, void *d_dst, size_t nbytes, void *stream) {
+    if (int rc = check_common(nmodel, nfilt, nstar)) return rc;
+    if (!d_workspace || !d_dst) return fail(BRUTUS_EINVAL, "NULL pointer");
+    Workspace w = carve((char *)d_workspace, nmodel, nstar, true);
+    if (w.bytes > workspace_bytes) return fail(BRUTUS_ENOMEM, "workspace too small");
+    const size_t plane = (size_t)nstar * (size_t)nmodel;
+    const void *src = nullptr;
+    size_t have = 0;
+    switch (which) {
+        case 0: src = w.pl.lnlp; have = 8 * plane; break;       // path 1: float64 cull statistic
+        case 1: src = w.pl.lnprob; have = 8 * plane; break;     // path 1: float64 first-cut statistic
+        case 2: src = w.lnlp32; have = 4 * plane; break;        // path 2: float32 statistics
+        case 3: src = w.lnpr32; have = 4 * plane; break;
+        case 4: src = w.aud; have = 4 * (size_t)nstar * 4; break;
+        case 5: src = w.s32; have = sizeof(Star32) * (size_t)nstar; break;
+        case 6: src = w.thr_cull; have = 8 * (size_t)nstar; break;
+        case 7: src = w.thr_sel; have = 8 * (size_t)nstar; break;
+        case 8: src = w.st32; have = 4 * (size_t)nstar * NV32; break;
+        case 9: src = w.status; have = 4 * (size_t)nstar; break;
+        default: return fail(BRUTUS_EINVAL, "unknown array %d", which);
+    }
+    if (nbytes > have) return fail(BRUTUS_EINVAL, "array %d holds %zu bytes, %zu requested", which, have, nbytes);
+    HIP_TRY(hipMemcpyAsync(d_dst, src, nbytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return 0;
+}
+
+int brutus_debug_sizeof_star32(void) { return (int)sizeof(Star32); }
 
 void brutus_enable_timing(int on) { g_timing = on != 0; }
 

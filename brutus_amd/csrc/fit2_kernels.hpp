@@ -1,0 +1,770 @@
+// fit2_kernels.hpp -- second-generation hot path behind brutus_fit_batch
+// Part of the single translation unit brutus_kernels.hip (included after
+// fit_kernels.hpp); everything lives in that unit's anonymous namespace.
+//
+// Why.  The reference's per-star control flow hangs on maxima over the whole grid
+// (fitting.py:246-264 K1, :758-759 cull, :798-799 K2, :988-991 first cut), but
+// only the models within a few units of those maxima take part in any decision or
+// reach the output; for everything else it is enough to PROVE that it is below
+// the thresholds.  So:
+//
+//   k_pre32    every (star, model) in float32 (centred magnitudes, fluxes scaled to
+//              O(1)): approximate cull statistic lnl_p~ and first-cut statistic
+//              lnprob~ (4 + 4 B per pair), float32 maxima per 2048-model block, and the
+//              sweep statistics that decide K1 when they are clear of the tolerances.
+//              About 1/3 of the issue slots of the float64 scan it replaces.
+//   k_top      float64 re-evaluation of the models within 2 eps of the float32 maximum
+//              (only the blocks whose float32 maximum is that high are touched)
+//              ->  EXACT max lnl_p, i.e. the exact cull threshold.
+//   k_cmp_count32 + k_offsets + k_cmp_scatter
+//              ordered list of the models with lnl_p~ >= threshold - eps.
+//   k_fflux    (fit_kernels.hpp, second-generation mode) exact cull test in float64, flux
+//              iterations for the survivors, survivor marks (+inf / -inf) into the
+//              lnl_p~ plane.
+//   k_top (B)  exact maximum of lnprob over the non-survivors that could exceed the
+//              survivors' maximum  ->  EXACT first-cut threshold.
+//   k_select2  selection bit-mask: float32 decides when |lnprob~ - thr| > eps, the
+//              models inside the band are queued in LDS and re-evaluated in float64;
+//              survivors by their final value.
+//   k_offsets + k_cmp_scatter + k_emit   ordered records, each written once.
+//
+// float32 never produces an output value or a decision: a lane whose float32 value
+// is NaN or inside the error band is re-evaluated in float64.  `eps` is a per-star
+// bound on |float32 - float64| (Star32::eps, checked at run time with BRUTUS_AUDIT=1
+// and in tests/test_gpu_fit2.py).
+#pragma once
+
+namespace {
+
+constexpr int F2_T = 8;        // tiles per workgroup (2048 models)
+constexpr int NV32 = 10;       // float32 partial maxima per (block, star)
+
+struct Star32 {
+    float gc[NBMAX];    // magnitude - weighted mean magnitude
+    float w[NBMAX];     // 1 / mags_var
+    float dd[NBMAX];    // flux / D,  D = 10^(-0.4 gbar)
+    float iv[NBMAX];    // D^2 / flux variance
+    float S, DD2, gbar;
+    float par, par_ivar, sp_mean, sp_var;
+    float c0, c1;
+    float eps, epsw;    // bounds on |f32 - f64| of lnl_p / lnprob and of logwt
+    float chi2_lo;      // below this chi2 float32 is not trusted (re-evaluated in float64)
+    int has_par, sp_on, ok;
+};
+
+struct P32 {
+    float avmin, avmax, rvmin, rvmax, av_mean, av_ivar, rv_mean, rv_ivar;
+    float mtol_hi, mtol_lo;     // mtol +- slack for the step test
+    int dim_prior, nfilt;
+};
+
+// ---------------------------------------------------------------------------
+// per-star float32 companion of StarPrep
+// ---------------------------------------------------------------------------
+__global__ void k_prep32(int nstar, const StarPrep *__restrict__ stars, float eps_scale,
+                         int dim_prior, Star32 *__restrict__ out) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= nstar) return;
+    const StarPrep &sp = stars[s];
+    Star32 o;
+    double sw = 0., swg = 0.;
+    for (int j = 0; j < NBMAX; ++j) {
+        // bands with a non-positive flux carry mags_var = 1e50: no weight
+        const double w = sp.iW[j] > 1e-40 ? sp.iW[j] : 0.;
+        sw += w;
+        swg += w * sp.g[j];
+    }
+    const double gbar = sw > 0. ? swg / sw : 0.;
+    const double D = exp10(-0.4 * gbar);
+    double DD2 = 0., wy = 0., snmax = 0.;
+    bool ok = sw > 0. && isfinite(gbar) && isfinite(D) && D > 1e-30 && D < 1e30;
+    for (int j = 0; j < NBMAX; ++j) {
+        const double w = sp.iW[j] > 1e-40 ? sp.iW[j] : 0.;
+        const double dd = sp.d[j] / D, iv = sp.iV[j] * D * D;
+        o.gc[j] = (float)(w > 0. ? sp.g[j] - gbar : 0.);
+        o.w[j] = (float)w;
+        o.dd[j] = (float)dd;
+        o.iv[j] = (float)iv;
+        DD2 += dd * dd * iv;
+        wy += w;
+        const double sn = fabs(dd) * sqrt(iv);
+        snmax = sn > snmax ? sn : snmax;
+        if (!(fabs(dd) < 1e15) || !(iv < 1e30) || !(w < 1e30)) ok = false;
+    }
+    o.S = (float)sp.S;
+    o.DD2 = (float)DD2;
+    o.gbar = (float)gbar;
+    o.par = (float)sp.par;
+    o.par_ivar = (float)sp.par_ivar;
+    o.sp_mean = (float)sp.sp_mean;
+    o.sp_var = (float)sp.sp_var;
+    o.c0 = (float)sp.c0;
+    o.c1 = (float)sp.c1;
+    o.has_par = sp.has_par;
+    o.sp_on = sp.sp_on;
+    // |f32 - f64|: the single-pass chi2 cancels against DD2 = sum (S/N)^2, the
+    // magnitude-space chi2 against sum w y^2 (y up to a few mag for the models that
+    // matter); both scale with 2^-23 times those sums.  The parallax terms add
+    // 2^-23 times the parallax S/N.  eps_scale (default 1) multiplies the lot.
+    const double u = 1.1920929e-07;
+    const double psn = sp.has_par ? fabs(sp.par) * sqrt(sp.par_ivar) + 4. : 0.;
+    o.eps = (float)(eps_scale * (0.02 + 16. * u * (DD2 + 64. * snmax) + 64. * u * psn * psn));
+    o.epsw = (float)(eps_scale * (0.02 + 64. * u * wy));
+    // ln(chi2) of the dimensionality prior amplifies the chi2 error by c1 / chi2
+    o.chi2_lo = fmaxf(4.f * o.eps, dim_prior ? 0.5f * fabsf(o.c1) + 0.5f : 0.f);
+    o.ok = ok ? 1 : 0;
+    out[s] = o;
+}
+
+// ---------------------------------------------------------------------------
+// k_pre32: the whole grid in float32
+// ---------------------------------------------------------------------------
+// part[(bx * nstar + s) * NV32 + v]:
+//   v = 0, 1, 2 : sweep 1: L = max logwt, max{logwt : step >= mtol + slack},
+//                 max{logwt : step >= mtol - slack}
+//   v = 3, 4, 5 : the same for sweep 2 (general kernels only)
+//   v = 6, 7    : max lnl_p~, max lnprob~ (state after kfix[s] sweeps)
+//   v = 8       : > 0 if a live lane produced a non-finite logwt
+//   v = 9       : > 0 if a live lane's lnl_p~ or lnprob~ is NaN (= "ask float64")
+// logwt is the reference's sweep statistic -chi2/2 with the distance-modulus offset
+// LEFT IN the residuals (fitting.py:240-243).  With centred
+// magnitudes y_c = y - Delta (Delta = gbar - mbar) and o = sum w (y_c - Av R) / S,
+//   chi2 = [chi2_c - S o^2] + S (Delta + o)^2 :
+// the bracket is the offset-free chi2, and Delta + o is small exactly for the models
+// that can be inside the ln(init_thresh) window, so float32 resolves it there.
+template <int NB, bool RVF, int G>
+__global__ void __launch_bounds__(TILE)
+k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+        const int32_t *__restrict__ star_ids, const Star32 *__restrict__ stars, P32 p,
+        const int32_t *__restrict__ kfix, int ntile, float *__restrict__ lnlp32,
+        float *__restrict__ lnpr32, float *__restrict__ part) {
+    __shared__ float slot[4][G * NV32];
+    const float C10 = -1.32877123795494494f;     // -0.4 log2(10)
+    const float NINF = -INFINITY;
+    const int g0 = blockIdx.y * G;
+    const int ng = min(G, nrun - g0);
+    float mx[G][NV32];
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < NV32; ++v) mx[g][v] = NINF;
+    const int t0 = blockIdx.x * F2_T;
+    const int t1 = min(ntile, t0 + F2_T);
+    const float inv_nf = 1.f / (float)p.nfilt;
+    for (int t = t0; t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        const bool live = i < nmodel;
+        float mc[NB], R[NB], dr[RVF ? 1 : NB];
+        float mbar = 0.f;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) {
+            const float *q = grid + (int64_t)(3 * j) * nmodel_pad + i;
+            mc[j] = q[0];
+            R[j] = q[nmodel_pad];
+            const float d = q[2 * nmodel_pad];
+            if constexpr (RVF) R[j] = fmaf(p.rv_mean, d, R[j]);
+            else dr[j] = d;
+            if (j < p.nfilt) mbar += mc[j];
+        }
+        mbar *= inv_nf;
+#pragma unroll
+        for (int j = 0; j < NB; ++j) mc[j] -= mbar;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ng) break;
+            const int s = star_ids[g0 + g];
+            const Star32 &sp = stars[s];
+            const int K = kfix[s];
+            float av = p.av_mean, rv = p.rv_mean;
+            if constexpr (RVF) {
+                float uR = 0.f, RR = 0.f, yR = 0.f, uy = 0.f, yy = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float w = sp.w[j];
+                    const float y = sp.gc[j] - mc[j];
+                    const float Rw = R[j] * w, yw = y * w;
+                    uR += Rw;
+                    RR = fmaf(R[j], Rw, RR);
+                    yR = fmaf(R[j], yw, yR);
+                    uy += yw;
+                    yy = fmaf(y, yw, yy);
+                }
+                const float rs = uy - av * uR;
+                const float ra = (yR - av * RR) + (p.av_mean - av) * p.av_ivar;
+                const float a_den = RR + p.av_ivar;
+                float dav = (sp.S * ra - uR * rs) * __builtin_amdgcn_rcpf(sp.S * a_den - uR * uR);
+                dav = fmaxf(dav, p.avmin - av);
+                dav = fminf(dav, p.avmax - av);
+                av += dav;
+                const float oc = (uy - av * uR) * __builtin_amdgcn_rcpf(sp.S);
+                const float tt0 = (sp.gbar - mbar) + oc;
+                const float lw = -0.5f * ((yy - av * (2.f * yR - av * RR)) + sp.S * (tt0 * tt0 - oc * oc));
+                if (live) {
+                    if (lw == lw) {
+                        mx[g][0] = fmaxf(mx[g][0], lw);
+                        const float st = fabsf(dav);
+                        if (st >= p.mtol_hi) mx[g][1] = fmaxf(mx[g][1], lw);
+                        if (st >= p.mtol_lo) mx[g][2] = fmaxf(mx[g][2], lw);
+                    } else {
+                        mx[g][8] = 1.f;
+                    }
+                }
+            } else {
+                float ua = 0.f, ub = 0.f, uy = 0.f, aa = 0.f, ab = 0.f, bb = 0.f, ay = 0.f, by = 0.f,
+                      yy = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float w = sp.w[j];
+                    const float a = R[j], b = dr[j];
+                    const float y = sp.gc[j] - mc[j];
+                    const float aw = a * w, bw = b * w, yw = y * w;
+                    ua += aw;
+                    ub += bw;
+                    uy += yw;
+                    aa = fmaf(a, aw, aa);
+                    ab = fmaf(a, bw, ab);
+                    bb = fmaf(b, bw, bb);
+                    ay = fmaf(a, yw, ay);
+                    by = fmaf(b, yw, by);
+                    yy = fmaf(y, yw, yy);
+                }
+                auto sweep = [&](float &dav_o, float &drv_o) -> float {
+                    const float uR = ua + rv * ub;
+                    const float RR = aa + rv * (2.f * ab + rv * bb);
+                    const float yR = ay + rv * by;
+                    float rs = uy - av * uR;
+                    const float ra = (yR - av * RR) + (p.av_mean - av) * p.av_ivar;
+                    const float a_den = RR + p.av_ivar;
+                    float dav = (sp.S * ra - uR * rs) * __builtin_amdgcn_rcpf(sp.S * a_den - uR * uR);
+                    dav = fmaxf(dav, p.avmin - av);
+                    dav = fminf(dav, p.avmax - av);
+                    av += dav;
+                    const float r_den = bb * av * av + p.rv_ivar;
+                    const float sr = ub * av;
+                    rs = uy - av * uR;
+                    const float bres = by - av * (ab + rv * bb);
+                    const float rr = av * bres + (p.rv_mean - rv) * p.rv_ivar;
+                    float drv = (sp.S * rr - sr * rs) * __builtin_amdgcn_rcpf(sp.S * r_den - sr * sr);
+                    drv = fmaxf(drv, p.rvmin - rv);
+                    drv = fminf(drv, p.rvmax - rv);
+                    rv += drv;
+                    const float RR2 = aa + rv * (2.f * ab + rv * bb);
+                    const float yR2 = ay + rv * by;
+                    dav_o = dav;
+                    drv_o = drv;
+                    const float uR2 = ua + rv * ub;
+                    const float oc = (uy - av * uR2) * __builtin_amdgcn_rcpf(sp.S);
+                    const float tt0 = (sp.gbar - mbar) + oc;
+                    return -0.5f * ((yy - av * (2.f * yR2 - av * RR2)) + sp.S * (tt0 * tt0 - oc * oc));
+                };
+                float d1, d2;
+                if (K >= 1) {
+                    const float lw = sweep(d1, d2);
+                    if (live) {
+                        if (lw == lw) {
+                            const float st = fmaxf(fabsf(d1), fabsf(d2));
+                            mx[g][0] = fmaxf(mx[g][0], lw);
+                            if (st >= p.mtol_hi) mx[g][1] = fmaxf(mx[g][1], lw);
+                            if (st >= p.mtol_lo) mx[g][2] = fmaxf(mx[g][2], lw);
+                        } else {
+                            mx[g][8] = 1.f;
+                        }
+                    }
+                }
+                if (K >= 2) {
+                    const float lw = sweep(d1, d2);
+                    if (live) {
+                        if (lw == lw) {
+                            const float st = fmaxf(fabsf(d1), fabsf(d2));
+                            mx[g][3] = fmaxf(mx[g][3], lw);
+                            if (st >= p.mtol_hi) mx[g][4] = fmaxf(mx[g][4], lw);
+                            if (st >= p.mtol_lo) mx[g][5] = fmaxf(mx[g][5], lw);
+                        } else {
+                            mx[g][8] = 1.f;
+                        }
+                    }
+                }
+                for (int k = 2; k < K; ++k) sweep(d1, d2);
+            }
+            // MLE in scaled units: F = A f, A = 10^(-0.4 mbar), d = D dd
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float Rj = R[j];
+                if constexpr (!RVF) Rj = fmaf(rv, dr[j], R[j]);
+                const float e = __builtin_amdgcn_exp2f(C10 * fmaf(av, Rj, mc[j]));
+                const float fw = e * sp.iv[j];
+                num = fmaf(sp.dd[j], fw, num);
+                den = fmaf(e, fw, den);
+            }
+            const float q = __builtin_amdgcn_exp2f(C10 * (sp.gbar - mbar));       // D / A
+            float tt = num * __builtin_amdgcn_rcpf(den);
+            float sc = tt * q;
+            if (sc <= 1e-20f) {
+                sc = 1e-20f;
+                tt = sc * __builtin_amdgcn_rcpf(q);
+            }
+            const float chi2 = fmaf(tt, fmaf(tt, den, -2.f * num), sp.DD2);
+            const float lnl = -0.5f * chi2;
+            float lnlp = lnl;
+            if (sp.has_par) {
+                const float dp = __builtin_amdgcn_sqrtf(sc) - sp.par;
+                lnlp = lnl - 0.5f * (dp * dp * sp.par_ivar);
+            }
+            float lnpr = lnl;
+            if (p.dim_prior) lnpr = sp.c0 + sp.c1 * __logf(chi2) - 0.5f * chi2;
+            if (sp.sp_on) {
+                const float vt = sp.sp_var + q * q * __builtin_amdgcn_rcpf(den);
+                const float ds = sc - sp.sp_mean;
+                lnpr += -0.5f * (ds * ds * __builtin_amdgcn_rcpf(vt) + __logf(6.2831853071795865f * vt));
+            }
+            // a chi2 the cancellation cannot resolve, or a star float32 cannot
+            // represent: NaN = "re-evaluate in float64"
+            if (!(chi2 > 4.f * sp.eps) || !sp.ok) lnlp = NAN;
+            if (!(chi2 > sp.chi2_lo) || !sp.ok) lnpr = NAN;
+            if (live) {
+                const int64_t o = (int64_t)s * nmodel + i;
+                lnlp32[o] = lnlp;
+                lnpr32[o] = lnpr;
+                if (lnlp != lnlp || lnpr != lnpr) mx[g][9] = 1.f;
+                if (lnlp > mx[g][6]) mx[g][6] = lnlp;
+                if (lnpr > mx[g][7]) mx[g][7] = lnpr;
+            }
+        }
+    }
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#pragma unroll
+    for (int g = 0; g < G; ++g)
+#pragma unroll
+        for (int v = 0; v < NV32; ++v) {
+            float x = mx[g][v];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+            if (lane == 0) slot[wv][g * NV32 + v] = x;
+        }
+    __syncthreads();
+    if (threadIdx.x < G * NV32) {
+        const int g = threadIdx.x / NV32, v = threadIdx.x % NV32;
+        if (g < ng) {
+            const int s = star_ids[g0 + g];
+            const float x = fmaxf(fmaxf(slot[0][threadIdx.x], slot[1][threadIdx.x]),
+                                  fmaxf(slot[2][threadIdx.x], slot[3][threadIdx.x]));
+            part[((int64_t)blockIdx.x * nstar + s) * NV32 + v] = x;
+        }
+    }
+}
+
+// Per-star reduction of the float32 partials and the K1 decision they allow.
+//   status[s] = 0: K1 = k1[s] decided (== kfix used)      1: K1 = 1 decided, planes were
+//   computed after 2 sweeps -> redo k_pre32 with kfix = 1  2: undecided -> exact probe
+__global__ void k_pre_decide(int nblkx, int nstar, const int32_t *__restrict__ star_ids,
+                             const float *__restrict__ part, const Star32 *__restrict__ stars,
+                             float ln_init, int rvf, const int32_t *__restrict__ kfix,
+                             int accept, float *__restrict__ st32, int32_t *__restrict__ k1,
+                             int32_t *__restrict__ status, double *__restrict__ nomA) {
+    __shared__ float sm[NV32][4];
+    const int s = star_ids[blockIdx.x];
+    float v[NV32];
+    for (int q = 0; q < NV32; ++q) v[q] = -INFINITY;
+    for (int b = threadIdx.x; b < nblkx; b += blockDim.x) {
+        const float *pp = part + ((int64_t)b * nstar + s) * NV32;
+        for (int q = 0; q < NV32; ++q) v[q] = fmaxf(v[q], pp[q]);
+    }
+    for (int q = 0; q < NV32; ++q) {
+        float x = v[q];
+        for (int off = 32; off > 0; off >>= 1) x = fmaxf(x, __shfl_xor(x, off, 64));
+        if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    for (int q = 0; q < NV32; ++q)
+        v[q] = fmaxf(fmaxf(sm[q][0], sm[q][1]), fmaxf(sm[q][2], sm[q][3]));
+    for (int q = 0; q < NV32; ++q) st32[(int64_t)s * NV32 + q] = v[q];
+    const Star32 &sp = stars[s];
+    const float ew = 2.f * sp.epsw;
+    int st = 2, K1 = 0;
+    const int K = kfix[s];
+    if (sp.ok && !(v[8] > 0.f) && v[0] > -INFINITY) {
+        const bool cont1 = v[1] > v[0] + ln_init + ew;      // surely not converged after sweep 1
+        const bool may1 = v[2] > v[0] + ln_init - ew;       // possibly not converged
+        if (!may1) {
+            K1 = 1;
+            st = (rvf || K == 1) ? 0 : 1;
+        } else if (cont1) {
+            if (rvf) {            // pinned Rv: sweep 2 never moves (see k_fscan)
+                K1 = 2;
+                st = 0;
+            } else if (K >= 2) {
+                const bool cont2 = v[4] > v[3] + ln_init + ew;
+                const bool may2 = v[5] > v[3] + ln_init - ew;
+                if (!may2) {
+                    K1 = 2;
+                    st = (K == 2) ? 0 : 2;
+                } else if (cont2) {
+                    st = 2;       // K1 >= 3: exact probe
+                }
+            }
+        }
+    }
+    if (!accept) {      // accept: K1 already known exactly (exact probe / redo), stats only
+        k1[s] = K1;
+        status[s] = st;
+    }
+    // nominees for the exact maximum of lnl_p: within 2 eps of the float32 maximum
+    nomA[s] = (double)v[6] - 2. * (double)sp.eps;
+}
+
+// ---------------------------------------------------------------------------
+// float64 building blocks on a register-resident tile
+// ---------------------------------------------------------------------------
+template <int NB, bool RVF>
+struct Tile64 {
+    Coef<NB> c;
+    double F0[NB];
+    double R[RVF ? NB : 1];
+};
+
+template <int NB, bool RVF>
+__device__ __forceinline__ void tile_load(const float *__restrict__ grid, int64_t nmodel_pad,
+                                          int64_t i, double rv_mean, Tile64<NB, RVF> &t) {
+    load_coef<NB>(grid, nmodel_pad, i, t.c);
+    load_F0<NB>(grid, nmodel_pad, i, t.F0);
+    if constexpr (RVF) coef_R<NB>(t.c, rv_mean, t.R);
+}
+
+// K sweeps of the magnitude phase from (av_mean, rv_mean) (fitting.py:176-243)
+template <int NB, bool RVF>
+__device__ __forceinline__ void mag_phase(const Tile64<NB, RVF> &t, const StarPrep &sp,
+                                          const DevParams &p, int K, double &av, double &rv) {
+    av = p.av_mean;
+    rv = p.rv_mean;
+    if constexpr (RVF) {
+        GramR Gm;
+        gram_init_rf<NB>(t.c, t.R, sp, Gm);
+        for (int k = 0; k < K; ++k) {
+            double a_, c_;
+            gram_sweep_rf(Gm, sp.S, p, av, a_, c_);
+        }
+    } else {
+        Gram Gm;
+        gram_init<NB>(t.c, sp, Gm);
+        for (int k = 0; k < K; ++k) {
+            double a_, b_, c_;
+            gram_sweep(Gm, sp.S, p, av, rv, a_, b_, c_);
+        }
+    }
+}
+
+template <int NB, bool RVF, bool FULL>
+__device__ __forceinline__ void mle_at(const Tile64<NB, RVF> &t, const StarPrep &sp,
+                                       const DevParams &p, double av, double rv,
+                                       const double *__restrict__ tbl, Mle &m) {
+    if constexpr (RVF) mle_fast_rf<NB, true, FULL>(t.c, t.R, t.F0, sp, p, av, tbl, m);
+    else mle_fast<NB, true>(t.c, t.F0, sp, p, av, rv, tbl, m);
+}
+
+__device__ __forceinline__ void audit(float *__restrict__ aud, int s, float f32v, double f64v,
+                                      double thr) {
+    // largest |f32 - f64| among lanes within 12 of the threshold (run-time check of eps)
+    if (aud && f64v > thr - 12. && f32v == f32v) {
+        const float d = fabsf((float)(f64v - (double)f32v));
+        atomicMax(reinterpret_cast<int *>(aud + s), __float_as_int(d));
+    }
+}
+
+// mask word of (star s, tile t, wave w)
+__device__ __forceinline__ int64_t mword(int s, int ntile, int t, int w) {
+    return (int64_t)s * (4 * ntile) + (int64_t)t * 4 + w;
+}
+
+// ---------------------------------------------------------------------------
+// k_top: exact maxima over nominees
+// ---------------------------------------------------------------------------
+// mode 0: nominees = !(lnlp32 < nom[s])                          -> max lnl_p
+// mode 1: nominees = non-survivors with !(lnpr32 < nom[s])       -> max lnprob (mag-phase value)
+//         (survivors carry +inf in the lnl_p~ plane, see k_fflux)
+// A (block, star) whose float32 block maximum (part32 column 6 + mode) is below nom[s]
+// and that holds no NaN lane is skipped outright.
+// part[(bx * nstar + s)] = block maximum (-inf if no nominee)
+template <int NB, bool RVF, int G>
+__global__ void __launch_bounds__(TILE, 2)
+k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+      const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
+      const int32_t *__restrict__ k1, int ntile, int mode, const float *__restrict__ plane32,
+      const double *__restrict__ nom, const float *__restrict__ surv32,
+      const float *__restrict__ part32, double *__restrict__ part, float *__restrict__ aud) {
+    __shared__ double slot[4][G];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    const int g0 = blockIdx.y * G;
+    const int ng = min(G, nrun - g0);
+    const int t0 = blockIdx.x * F2_T;
+    const int t1 = min(ntile, t0 + F2_T);
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (lane < G) slot[wv][lane] = -INFINITY;      // wave-private row: no barrier needed
+    bool hot[G];
+    bool anyhot = false;
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        hot[g] = false;
+        if (g < ng) {
+            const int s = star_ids[g0 + g];
+            const float *pp = part32 + ((int64_t)blockIdx.x * nstar + s) * NV32;
+            hot[g] = !((double)pp[6 + mode] < nom[s]) || pp[9] > 0.f;
+            anyhot = anyhot || hot[g];
+        }
+    }
+    for (int t = t0; anyhot && t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        const bool live = i < nmodel;
+        unsigned long long need[G];
+        bool any = false;
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            need[g] = 0ull;
+            if (g < ng && hot[g]) {
+                const int s = star_ids[g0 + g];
+                bool nm = false;
+                if (live) {
+                    nm = !(plane32[(int64_t)s * nmodel + i] < nom[s]);
+                    if (mode == 1 && nm) nm = surv32[(int64_t)s * nmodel + i] != INFINITY;
+                }
+                need[g] = __ballot(nm);
+                any = any || need[g] != 0ull;
+            }
+        }
+        if (!any) continue;
+        Tile64<NB, RVF> tl;
+        tile_load<NB, RVF>(grid, nmodel_pad, i, p.rv_mean, tl);
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g >= ng || need[g] == 0ull) continue;
+            const int s = star_ids[g0 + g];
+            const StarPrep &sp = stars[s];
+            double av, rv;
+            mag_phase<NB, RVF>(tl, sp, p, k1[s], av, rv);
+            Mle m;
+            mle_at<NB, RVF, false>(tl, sp, p, av, rv, s_tbl, m);
+            double val;
+            if (mode == 0) val = cull_stat(sp, m);
+            else val = first_cut_lnprob(sp, final_lnl<false>(sp, p, m.chi2, false), m.scale, m.i00);
+            const bool mine = (need[g] >> lane) & 1ull;
+            if (mine) audit(aud, s, plane32[(int64_t)s * nmodel + i], val, nom[s]);
+            const double x = wave_max((mine && val == val) ? val : -INFINITY);
+            if (lane == 0 && x > slot[wv][g]) slot[wv][g] = x;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < ng) {
+        const int g = threadIdx.x;
+        double x = slot[0][g];
+        x = slot[1][g] > x ? slot[1][g] : x;
+        x = slot[2][g] > x ? slot[2][g] : x;
+        x = slot[3][g] > x ? slot[3][g] : x;
+        part[(int64_t)blockIdx.x * nstar + star_ids[g0 + g]] = x;
+    }
+}
+
+// thresholds from k_top's partials.
+//   mode 0: thr_cull[s] = max + ln_init;  candS[s] = thr_cull - eps
+//   mode 1: thr_sel[s] = max(maxsurv[s], max) + ln_wt
+__global__ void k_top_decide(int nblkx, int nstar, const int32_t *__restrict__ star_ids, int mode,
+                             const double *__restrict__ part, const Star32 *__restrict__ s32,
+                             double ln_thr, const double *__restrict__ maxsurv,
+                             double *__restrict__ thr, double *__restrict__ cand) {
+    __shared__ double sm[4];
+    const int s = star_ids[blockIdx.x];
+    double v = -INFINITY;
+    for (int b = threadIdx.x; b < nblkx; b += blockDim.x) {
+        const double x = part[(int64_t)b * nstar + s];
+        v = x > v ? x : v;
+    }
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    v = sm[0];
+    for (int w = 1; w < 4; ++w) v = sm[w] > v ? sm[w] : v;
+    if (mode == 0) {
+        thr[s] = v + ln_thr;
+        cand[s] = v + ln_thr - (double)s32[s].eps;
+    } else {
+        const double m = maxsurv[s] > v ? maxsurv[s] : v;
+        thr[s] = m + ln_thr;
+    }
+}
+
+// nomB[s] = maxsurv[s] - eps: the non-survivors that could exceed the survivors' maximum
+__global__ void k_nomB(int nstar, const double *__restrict__ maxsurv, const Star32 *__restrict__ s32,
+                       double *__restrict__ nomB) {
+    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < nstar) nomB[s] = maxsurv[s] - (double)s32[s].eps;
+}
+
+// Ordered compaction of a float32 plane: {i : !(plane[s][i] < thr[s])} (NaN counts as a
+// hit).  Same outputs as k_cmp_count.
+__global__ void __launch_bounds__(TILE)
+k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
+              const double *__restrict__ thr, int64_t *__restrict__ counts,
+              unsigned long long *__restrict__ mask) {
+    __shared__ int wsum[4];
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
+    const double th = thr[s];
+    int n = 0;
+    for (int t = t0; t < t1; ++t) {
+        const int64_t i = (int64_t)t * TILE + threadIdx.x;
+        bool hit = false;
+        if (i < nmodel) hit = !((double)plane[(int64_t)s * nmodel + i] < th);
+        n += hit ? 1 : 0;
+        const unsigned long long b = __ballot(hit);
+        if ((threadIdx.x & 63) == 0)
+            mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// ---------------------------------------------------------------------------
+// k_select2: the first cut of lnpost as a bit-mask (fitting.py:976-991)
+// ---------------------------------------------------------------------------
+// grid = (NCHUNK, nstar), one star per workgroup.  Survivors (+inf in the lnl_p~ plane)
+// are tested on their final float64 lnprob; the rest on lnprob~ with the margin eps;
+// models inside the band are queued in LDS and re-evaluated in float64 with dense
+// lanes.  Outputs as k_cmp_count: membership words + per-chunk counts.
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(TILE, 2)
+k_select2(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ntile,
+          const StarPrep *__restrict__ stars, const Star32 *__restrict__ s32, DevParams p,
+          const int32_t *__restrict__ k1, const float *__restrict__ lnlp32,
+          const float *__restrict__ lnpr32, const double *__restrict__ thr_sel, Planes pl,
+          int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
+          float *__restrict__ aud) {
+    // dynamic LDS: membership words of the chunk, then the band queue (one slot per model
+    // of the chunk, so it can never overflow and the scan loop needs no barrier)
+    extern __shared__ unsigned long long words[];
+    __shared__ int qn;
+    __shared__ int wsum[4];
+    __shared__ double s_tbl[64];
+    stage_exp_table(s_tbl);
+    if (threadIdx.x == 0) qn = 0;
+    __syncthreads();
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
+    const int maxt = ntile / NCHUNK + 2;
+    int32_t *queue = reinterpret_cast<int32_t *>(words + 4 * maxt);
+    const StarPrep &sp = stars[s];
+    const double th = thr_sel[s];
+    const double e = (double)s32[s].eps;
+    const int K = k1[s];
+    constexpr int U = 4;      // tiles in flight per lane (the loop is latency-bound otherwise)
+    for (int tb = t0; tb < t1; tb += U) {
+        float a[U], v32[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t i = (int64_t)(tb + u) * TILE + threadIdx.x;
+            const bool in = tb + u < t1 && i < nmodel;
+            a[u] = in ? lnlp32[(int64_t)s * nmodel + i] : -INFINITY;
+            v32[u] = in ? lnpr32[(int64_t)s * nmodel + i] : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int t = tb + u;
+            if (t >= t1) break;
+            const int64_t i = (int64_t)t * TILE + threadIdx.x;
+            bool yes = false, bd = false;
+            if (i < nmodel) {
+                if (a[u] == INFINITY) {
+                    yes = pl.lnprob[(int64_t)s * nmodel + i] > th;
+                } else {
+                    const double v = (double)v32[u];
+                    yes = v >= th + e;
+                    bd = !yes && !(v < th - e);
+                }
+            }
+            const unsigned long long b = __ballot(yes);
+            if ((threadIdx.x & 63) == 0) words[(t - t0) * 4 + (threadIdx.x >> 6)] = b;
+            if (bd) queue[atomicAdd(&qn, 1)] = (int32_t)i;
+        }
+    }
+    __syncthreads();
+    const int n = qn;
+    for (int q = threadIdx.x; q < n; q += TILE) {
+        const int64_t i = queue[q];
+        Tile64<NB, RVF> tl;
+        gather_coef<NB>(grid, nmodel_pad, i, tl.c);
+        compute_F0_tbl<NB>(tl.c, s_tbl, tl.F0);
+        if constexpr (RVF) coef_R<NB>(tl.c, p.rv_mean, tl.R);
+        double av, rv;
+        mag_phase<NB, RVF>(tl, sp, p, K, av, rv);
+        Mle m;
+        mle_at<NB, RVF, false>(tl, sp, p, av, rv, s_tbl, m);
+        const double lnprob =
+            first_cut_lnprob(sp, final_lnl<false>(sp, p, m.chi2, false), m.scale, m.i00);
+        audit(aud, s, lnpr32[(int64_t)s * nmodel + i], lnprob, th);
+        if (lnprob > th) {
+            const int k = (int)(i / TILE - t0) * 4 + (int)((i % TILE) >> 6);
+            atomicOr(&words[k], 1ull << (i & 63));
+        }
+    }
+    __syncthreads();
+    int cnt = 0;
+    for (int k = threadIdx.x; k < (t1 - t0) * 4; k += TILE) {
+        const unsigned long long b = words[k];
+        mask[(int64_t)s * (4 * ntile) + (int64_t)t0 * 4 + k] = b;
+        cnt += __popcll(b);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
+    __syncthreads();
+    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+}
+
+// Deep K1 probe for ONE star (k_mag_stats partials with nstar = 1): the first sweep
+// k at which max{logwt : step >= tol} <= max logwt + ln(init_thresh)
+// (fitting.py:246-264); 0 if none of the kmax sweeps converged.
+__global__ void k_k1_deep_decide(int ntile, int kmax, const double *__restrict__ part,
+                                 double ln_init, int32_t *__restrict__ out_k1) {
+    __shared__ double sm[2][4];
+    __shared__ int done;
+    if (threadIdx.x == 0) done = 0;
+    __syncthreads();
+    for (int k = 0; k < kmax; ++k) {
+        double L = -INFINITY, T = -INFINITY;
+        for (int t = threadIdx.x; t < ntile; t += blockDim.x) {
+            const double *pp = part + (int64_t)t * (2 * kmax) + 2 * k;
+            L = pp[0] > L ? pp[0] : L;
+            T = pp[1] > T ? pp[1] : T;
+        }
+        L = wave_max(L);
+        T = wave_max(T);
+        if ((threadIdx.x & 63) == 0) {
+            sm[0][threadIdx.x >> 6] = L;
+            sm[1][threadIdx.x >> 6] = T;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                L = sm[0][w] > L ? sm[0][w] : L;
+                T = sm[1][w] > T ? sm[1][w] : T;
+            }
+            L = L > -BIG ? L : -BIG;
+            if (!(T > L + ln_init)) {
+                *out_k1 = k + 1;
+                done = 1;
+            }
+        }
+        __syncthreads();
+        if (done) return;
+    }
+    if (threadIdx.x == 0) *out_k1 = 0;
+}
+
+}  // namespace

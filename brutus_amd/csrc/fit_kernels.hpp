@@ -341,6 +341,16 @@ __device__ __forceinline__ double first_cut_lnprob(const StarPrep &sp, double ln
     return lnprob;
 }
 
+// cull statistic lnl_p (fitting.py:745-756)
+__device__ __forceinline__ double cull_stat(const StarPrep &sp, const Mle &m) {
+    double lnlp = -0.5 * m.chi2;
+    if (sp.has_par) {
+        const double dp = sqrt(m.scale) - sp.par;
+        lnlp -= 0.5 * (dp * dp * sp.par_ivar);
+    }
+    return lnlp;
+}
+
 // FS_G = stars per workgroup of the fused scan (LDS: FS_G * NV * 2 KiB)
 
 // Fused full-grid scan.  grid = (ceil(ntile / tiles_per_block), ceil(nrun / FS_G)).
@@ -635,13 +645,18 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
 // the state planes.  Writes the state/result planes at the survivors' positions
 // and, per work item, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
 // M = max final lnprob.
+// Second-generation mode (surv32 != nullptr, fit2_kernels.hpp): the list holds the
+// CANDIDATES (lnl_p~ >= threshold - eps); the first launch applies the exact cull test
+// lnl_p > thr_cull[s] (fitting.py:758-759) and marks the outcome in the float32 plane
+// (+inf survivor, -inf not); only survivors iterate, store and enter the statistics.
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
         const int32_t *__restrict__ k2state, int first, const int32_t *__restrict__ surv_idx,
         const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
-        double *__restrict__ part) {
+        double *__restrict__ part, float *__restrict__ surv32,
+        const double *__restrict__ thr_cull) {
     __shared__ double slot[12];
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
@@ -655,9 +670,14 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
         const bool live = q < surv_off[s + 1];
         double L = -INFINITY, T = -INFINITY, M = -INFINITY;
+        bool go = live;
+        int64_t i = 0, o = 0;
         if (live) {
-            const int64_t i = surv_idx[q];
-            const int64_t o = (int64_t)s * pl.nmodel + i;
+            i = surv_idx[q];
+            o = (int64_t)s * pl.nmodel + i;
+            if (surv32 && !first) go = surv32[o] == INFINITY;
+        }
+        if (go) {
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
@@ -698,8 +718,12 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            if (surv32 && first) {
+                go = cull_stat(sp, m) > thr_cull[s];
+                surv32[o] = go ? INFINITY : -INFINITY;
+            }
             double lnl_new = lnl_old, dl = 0.;
-            for (int it = 0; it < niter; ++it) {
+            for (int it = 0; go && it < niter; ++it) {
                 double dav = (m.a_num + (p.av_mean - av) * p.av_ivar) / (m.a_ss + p.av_ivar) * step;
                 if (dav < p.avmin - av) dav = p.avmin - av;
                 if (dav > p.avmax - av) dav = p.avmax - av;
@@ -720,18 +744,20 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 if (lnl_new < lnl_old) step /= 1.2;
                 lnl_old = lnl_new;
             }
-            store_mle(pl, o, m);
-            pl.av[o] = av;
-            pl.rv[o] = rv;
-            pl.step[o] = step;
-            const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
-            const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
-            pl.lnl[o] = lnl;
-            pl.lnprob[o] = lnprob;
-            M = lnprob;
-            if (lnl_new == lnl_new) {
-                L = lnl_new;
-                if (dl > p.ltol) T = lnl_new;
+            if (go) {
+                store_mle(pl, o, m);
+                pl.av[o] = av;
+                pl.rv[o] = rv;
+                pl.step[o] = step;
+                const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
+                const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
+                pl.lnl[o] = lnl;
+                pl.lnprob[o] = lnprob;
+                M = lnprob;
+                if (lnl_new == lnl_new) {
+                    L = lnl_new;
+                    if (dl > p.ltol) T = lnl_new;
+                }
             }
         }
         double *out = part + (int64_t)item * 3;
@@ -797,7 +823,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
        const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
        const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
-       int64_t capacity, double *__restrict__ sel_vals) {
+       int64_t capacity, double *__restrict__ sel_vals, const float *__restrict__ surv32) {
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
@@ -810,7 +836,9 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
         const int64_t i = sel_idx[q];
         const int64_t o = (int64_t)s * pl.nmodel + i;
         double rec[BRUTUS_NVALS];
-        if (pl.lnlp[o] > thr_cull[s]) {
+        // survivor of the cull: float64 plane (path 1) / mark left by k_fflux (path 2)
+        const bool surv = surv32 ? surv32[o] == INFINITY : pl.lnlp[o] > thr_cull[s];
+        if (surv) {
             rec[0] = pl.lnl[o];
             rec[1] = pl.chi2[o];
             rec[2] = pl.scale[o];

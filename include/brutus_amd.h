@@ -221,6 +221,17 @@ int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
 int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n,
                       void *stream);
 
+/* Test hook: copy one internal array of the workspace of the last brutus_fit_batch
+ * (same nmodel / nfilt / nstar) into a caller-owned device buffer.  which =
+ * 0, 1: float64 planes (nstar, nmodel) of the cull / first-cut statistic (path 1);
+ * 2, 3: the float32 statistics of path 2; 4: run-time audit max|f32 - f64| (3, nstar)
+ * (BRUTUS_AUDIT=1); 5: per-star float32 block; 6, 7: exact cull / first-cut
+ * thresholds (nstar,) f64; 8: float32 maxima (nstar, 10); 9: K1 status (nstar,) i32. */
+int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
+                      int nfilt, int nstar, int which, void *d_dst, size_t nbytes,
+                      void *stream);
+int brutus_debug_sizeof_star32(void);
+
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */
 int brutus_last_timing(int *n_entries, const char **names, float *ms,

@@ -1,0 +1,146 @@
+"""GPU development aid: path 2 (float32 pre-classification + float64 on candidates)
+against path 1 (float64 everywhere) of brutus_fit_batch on the bench workload.
+
+    python tools/v2_check.py [--stars 32] [--config 2|3] [--nmodel 750000]
+
+Prints: record-set equality, max value differences, K1/K2 equality, the measured
+|float32 - float64| of the two statistics against the per-star eps, candidate
+fractions and per-kernel times of both paths.
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def timing(L):
+    n = C.c_int(0)
+    names = (C.c_char_p * 24)()
+    ms = (C.c_float * 24)()
+    L.brutus_last_timing(C.byref(n), names, ms, 24)
+    return {names[j].decode(): round(float(ms[j]), 3) for j in range(n.value)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--stars", type=int, default=32)
+    ap.add_argument("--config", type=int, default=2)
+    ap.add_argument("--nmodel", type=int, default=750000)
+    ap.add_argument("--nfilt", type=int, default=12)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--random-grid", action="store_true")
+    args = ap.parse_args()
+    import torch
+    from brutus_amd import _lib, fitting, synth
+    L = _lib.lib()
+    dev = torch.device("cuda:0")
+    if args.random_grid:
+        models, _, _ = synth.make_grid(args.nmodel, args.nfilt)
+    else:
+        models, _, _ = synth.make_mist_like_grid(args.nmodel, args.nfilt)
+    grid = fitting.DeviceGrid(models, device=dev)
+    with_par = args.config == 3
+    seed = args.seed if args.seed is not None else {2: 1, 3: 2}[args.config]
+    st = synth.make_stars(models, args.stars, seed=seed, with_parallax=with_par)
+    rvlim = (3.32, 3.32) if args.config == 2 else (1., 8.)
+    params = fitting._make_params((0., 20.), (0., 1e6), rvlim, (3.32, 0.18),
+                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    S, M = args.stars, args.nmodel
+    eng = fitting._Engine(grid, max_batch=S, mem_budget=200e9)
+    up = eng._upload(st["flux"], st["err"], st["mask"],
+                     st["parallax"] if with_par else None,
+                     st["parallax_err"] if with_par else None)
+    cap = S * 600000
+    bufs = [(torch.empty(cap, dtype=torch.int32, device=dev),
+             torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev)) for _ in range(2)]
+    ws = eng._workspace(S)
+
+    def copy(which, dtype, shape):
+        out = torch.empty(shape, dtype=dtype, device=dev)
+        _lib.check(L.brutus_debug_copy(ws.data_ptr(), ws.numel(), M, args.nfilt, S, which,
+                                       out.data_ptr(), out.numel() * out.element_size(), None))
+        torch.cuda.synchronize()
+        return out
+
+    res = {}
+    L.brutus_enable_timing(1)
+    for path in (1, 2):
+        os.environ["BRUTUS_FIT_PATH"] = str(path)
+        os.environ["BRUTUS_AUDIT"] = "1"
+        for rep in range(2):
+            out = eng.fit_batch_device(*up, params, sel_buffers=bufs[path - 1])
+            torch.cuda.synchronize()
+        res[path] = dict(out=out, t=timing(L))
+        print("path", path, "kernel ms:", res[path]["t"], "sum %.3f" % sum(res[path]["t"].values()))
+        if path == 1:
+            lnlp64 = copy(0, torch.float64, (S, M))
+            lnpr64 = copy(1, torch.float64, (S, M))
+    os.environ["BRUTUS_AUDIT"] = "0"
+    lnlp32 = copy(2, torch.float32, (S, M)).double()
+    lnpr32 = copy(3, torch.float32, (S, M)).double()
+    aud = copy(4, torch.float32, (4, S)).cpu().numpy()
+    n32 = L.brutus_debug_sizeof_star32() // 4
+    s32 = copy(5, torch.float32, (S, n32)).cpu().numpy()
+    thr_cull = copy(6, torch.float64, (S,)).cpu().numpy()
+    thr_sel = copy(7, torch.float64, (S,)).cpu().numpy()
+    st32 = copy(8, torch.float32, (S, 10)).cpu().numpy()
+    status = copy(9, torch.int32, (S,)).cpu().numpy()
+    eps = s32[:, 4 * 32 + 9]
+    epsw = s32[:, 4 * 32 + 10]
+    print("eps  min/median/max: %.3f %.3f %.3f   epsw: %.3f %.3f %.3f" % (
+        eps.min(), np.median(eps), eps.max(), epsw.min(), np.median(epsw), epsw.max()))
+    print("K1 status counts (0 ok, 1 redo, 2 probe):", np.bincount(status, minlength=3))
+
+    o1, o2 = res[1]["out"], res[2]["out"]
+    off1, off2 = o1[2].cpu().numpy(), o2[2].cpu().numpy()
+    print("K1 equal:", np.array_equal(o1[4], o2[4]), " K2 equal:", np.array_equal(o1[5], o2[5]),
+          " K1 hist", np.bincount(o1[4]), " K2 hist", np.bincount(o1[5]))
+    for sidx in np.where(o1[4] != o2[4])[0][:6]:
+        print("  star %d: K1 path1 %d path2 %d status %d  st32 %s  epsw %.3f" % (
+            sidx, o1[4][sidx], o2[4][sidx], status[sidx], np.array2string(st32[sidx], precision=3), epsw[sidx]))
+    print("offsets equal:", np.array_equal(off1, off2), " total", off1[-1], off2[-1],
+          " selected fraction %.3f" % (off1[-1] / float(S * M)))
+    n = int(min(off1[-1], off2[-1]))
+    if np.array_equal(off1, off2):
+        same_idx = bool(torch.equal(o1[0][:n], o2[0][:n]))
+        print("indices equal:", same_idx)
+        a, b = o1[1][:, :n], o2[1][:, :n]
+        d = (a - b).abs() / a.abs().clamp_min(1e-300)
+        names = "lnl chi2 scale av rv i00 i01 i02 i11 i12 i22".split()
+        print("max rel diff per value:", {k: float("%.2e" % float(d[j].max())) for j, k in enumerate(names)})
+        print("max abs diff av:", float((a[3] - b[3]).abs().max()))
+    else:
+        bad = np.where(np.diff(off1) != np.diff(off2))[0]
+        print("stars with different counts:", bad[:20], (np.diff(off1) - np.diff(off2))[bad[:20]])
+
+    # float32 vs float64 statistics
+    for name, f32, f64, thr in (("lnl_p", lnlp32, lnlp64, thr_cull), ("lnprob", lnpr32, lnpr64, thr_sel)):
+        t = torch.from_numpy(thr).to(dev)[:, None]
+        diff = (f32 - f64).abs()
+        near = (f64 > t - 12.) & torch.isfinite(f32)
+        dn = torch.where(near, diff, torch.zeros_like(diff)).max(dim=1).values.cpu().numpy()
+        above = (f64 > t) & torch.isfinite(f32)
+        da = torch.where(above, diff, torch.zeros_like(diff)).max(dim=1).values.cpu().numpy()
+        nan = torch.isnan(f32).double().mean().item()
+        ratio = dn / eps
+        print("%-7s max|f32-f64| within 12 of thr: median %.4f max %.4f   (above thr: max %.4f)   "
+              "max ratio to eps %.3f   NaN frac %.4f" % (name, np.median(dn), dn.max(), da.max(),
+                                                         ratio.max(), nan))
+        # proof obligation: every model above the threshold is a candidate
+        e = torch.from_numpy(eps.astype(np.float64)).to(dev)[:, None]
+        miss = ((f64 > t) & (f32 < t - e)).sum().item()
+        cand = (~(f32 < t - e)).double().mean().item()
+        band = ((~(f32 < t - e)) & (~(f32 >= t + e))).double().mean().item()
+        print("        missed candidates: %d   candidate fraction %.4f   band fraction %.4f   "
+              "true fraction %.4f" % (miss, cand, band, (f64 > t).double().mean().item()))
+    print("audit (run-time) max |f32-f64|: topA %.4f  topB %.4f  count %.4f  surv %.4f" % (
+        aud[0].max(), aud[1].max(), aud[2].max(), aud[3].max()))
+
+
+if __name__ == "__main__":
+    main()
