@@ -10,9 +10,13 @@ stars -- stars shard with no data-path collective (weak scaling).
 
 A "step" = one pass of the hot path (brutus_fit_batch: star vectors resident in
 HBM -> compact per-star survivor records in HBM) over one batch of `--batch`
-synthetic stars against the 750k-model x 12-band grid.  Workload = BASELINE.json
-configs[1] (Av-only: rvlim=(3.32, 3.32), no parallax); `--config 3` runs
-configs[2] (Av+Rv free, parallax prior).
+(default 512) DISTINCT synthetic stars against the 750k-model x 12-band grid, in
+sub-batches of `--sub-batch` stars.  Workload = BASELINE.json configs[1]
+(Av-only: rvlim=(3.32, 3.32), no parallax) -> `value`; configs[2] (Av+Rv free,
+parallax prior) is timed the same way in the same run -> `other_config`
+(`--config 3` swaps them).  `roofline.frac` = stars/s x 108 MB / 8 TB/s for the
+whole step; `roofline.kernels` lists every kernel with its own
+algorithmic bytes.
 """
 import argparse
 import json
@@ -34,9 +38,19 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--batch", type=int, default=128,
-                    help="stars per step per GPU (64 -> 128 -> 256: +4 %, +6 % stars/s; "
-                         "workspace ~87 MB per star at 750k models)")
+    ap.add_argument("--batch", type=int, default=512,
+                    help="DISTINCT stars per step per GPU: with the driver's 20 steps the "
+                         "timed region covers 10 240 different stars (BASELINE configs: "
+                         "'10k stars')")
+    ap.add_argument("--sub-batch", type=int, default=128,
+                    help="stars per brutus_fit_batch call (workspace ~95 MB per star at "
+                         "750k models); a step is batch / sub_batch calls")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: every rank fits its own steps x batch stars; strong: ONE "
+                         "catalogue of steps x batch stars split by parallel.shard_range "
+                         "(BASELINE configs[3]: --scaling strong --steps 250 --batch 4000)")
+    ap.add_argument("--single-config", action="store_true",
+                    help="skip the second configuration reported under other_config")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
                     help="2 / 3: the grid-likelihood path (BASELINE configs[1] / [2]); "
                          "5: cluster.isochrone_loglike (configs[4], supplementary line)")
@@ -281,6 +295,189 @@ def bench_cluster(args):
         dist.destroy_process_group()
 
 
+WORKLOADS = {
+    2: "configs[1]: 750k-model x 12-band grid, Av-only solve (rvlim=(3.32,3.32)), no parallax",
+    3: "configs[2]: 750k-model x 12-band grid, Av+Rv free, parallax prior",
+}
+
+# algorithmic bytes of one kernel launch: what the kernel has to
+# move at the very least for the work it is given.  g = grid bytes per star (108 MB at
+# 750k x 12), pairs = stars x models, nsel = selected records of the batch.
+KERNEL_ALG_BYTES = {
+    "k_pre32": lambda B, g, pairs, nsel: B * g,                  # the SURVEY 8(d) unit: one grid read per star
+    "k_fscan": lambda B, g, pairs, nsel: B * g,
+    "k_top": lambda B, g, pairs, nsel: 8. * pairs / 2048.,       # block partials only
+    "k_surv_compact": lambda B, g, pairs, nsel: 4. * pairs,      # the float32 statistic once
+    "k_sel_classify": lambda B, g, pairs, nsel: 8. * pairs,      # two float32 statistics
+    "k_select": lambda B, g, pairs, nsel: 4. * nsel,             # the index list
+    "k_emit": lambda B, g, pairs, nsel: 92. * nsel,              # the records (i32 + 11 f64)
+}
+
+
+def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
+    """Time `args.steps` steps of configs[config - 1] on this rank; returns a dict with
+    the whole-job rate and the per-kernel durations.  A step = `args.batch` DISTINCT
+    stars, pushed through brutus_fit_batch in sub-batches of `args.sub_batch`."""
+    from brutus_amd import _lib, fitting, synth
+    nmodel, nfilt = args.nmodel, args.nfilt
+    kw = dict(rvlim=(3.32, 3.32)) if config == 2 else dict()
+    with_par = config == 3
+    seed = {2: 1, 3: 2}[config]
+    B, SB = args.batch, args.sub_batch
+    nsub = (B + SB - 1) // SB
+    strong = args.scaling == "strong"
+    # weak: every rank fits its own `steps x batch` stars; strong: ONE catalogue of
+    # `steps x batch` stars, rank r takes the contiguous shard parallel.shard_range gives it
+    nstars_job = args.steps * B
+    if strong:
+        from brutus_amd import parallel
+        lo, hi = parallel.shard_range(nstars_job, rank, world)
+        stars = synth.make_stars(models, nstars_job, seed=seed, with_parallax=with_par)
+        stars = {k: v[lo:hi] for k, v in stars.items()}
+        mine = hi - lo
+    else:
+        stars = synth.make_stars(models, nstars_job, seed=seed + 1000 * rank,
+                                 with_parallax=with_par)
+        mine = nstars_job
+    params = fitting._make_params(
+        (0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
+        3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    NS = max(1, args.streams)
+    engines = [fitting._Engine(grid, max_batch=SB, mem_budget=64e9) for _ in range(NS)]
+    eng = engines[0]
+    # every sub-batch of the job resident in HBM before the clock starts (SURVEY 8d)
+    subs = []
+    for a in range(0, mine, SB):
+        sl = slice(a, min(mine, a + SB))
+        subs.append(eng._upload(stars["flux"][sl], stars["err"][sl], stars["mask"][sl],
+                                stars["parallax"][sl] if with_par else None,
+                                stars["parallax_err"][sl] if with_par else None))
+    cap = max(32 << 20, SB * 600000)
+    sel_bufs = [(torch.empty(cap, dtype=torch.int32, device=dev),
+                 torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
+                for _ in range(NS)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    nsel_seen = []
+
+    def one(i, j=0):
+        f, e, m, p, pe, hp = subs[i % len(subs)]
+        out = engines[j].fit_batch_device(f, e, m, p, pe, hp, params, sel_buffers=sel_bufs[j])
+        return out
+
+    def run(n_sub, first=0):
+        """n_sub consecutive sub-batches, dealt round-robin to NS host threads, each
+        with its own HIP stream and workspace."""
+        if NS == 1:
+            out = None
+            for i in range(first, first + n_sub):
+                out = one(i)
+            return out
+        import threading
+        outs = [None] * NS
+
+        def worker(j):
+            torch.cuda.set_device(dev)
+            with torch.cuda.stream(streams[j]):
+                for i in range(first + j, first + n_sub, NS):
+                    outs[j] = one(i, j)
+                streams[j].synchronize()
+
+        th = [threading.Thread(target=worker, args=(j,)) for j in range(NS)]
+        for t_ in th:
+            t_.start()
+        for t_ in th:
+            t_.join()
+        return next(o for o in outs if o is not None)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    run(max(args.warmup * nsub, NS if args.warmup else 0))
+    fence()
+    t0 = time.perf_counter()
+    out = run(len(subs))              # exactly `steps` steps (this rank's share of them)
+    fence()
+    dt = time.perf_counter() - t0
+    nsel_total = int(out[2][-1].item())
+    if nsel_total > cap:
+        raise SystemExit("record buffer overflow (%d > %d): timing would be invalid"
+                         % (nsel_total, cap))
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    total_stars = nstars_job if strong else world * nstars_job
+    res = {"value": total_stars / dt, "ms_per_step": dt / args.steps * 1e3,
+           "stars_timed_per_rank": mine, "selected_models_last_sub_batch": nsel_total}
+
+    # ---- per-kernel durations (HIP events on the launch stream), after the timed
+    # region and strictly sequential: with two streams the kernels of two sub-batches
+    # overlap and every individual duration is stretched
+    if rank == 0 and not args.no_kernel_timing:
+        import ctypes as C
+        ktimes = {}
+        L.brutus_enable_timing(1)
+        reps = max(2, min(4, len(subs)))
+        nsel_k = []
+        for i in range(reps):
+            o = one(i)
+            torch.cuda.synchronize()
+            nsel_k.append(int(o[2][-1].item()))
+            n = C.c_int(0)
+            names = (C.c_char_p * 24)()
+            ms = (C.c_float * 24)()
+            L.brutus_last_timing(C.byref(n), names, ms, 24)
+            for j in range(n.value):
+                ktimes.setdefault(names[j].decode(), []).append(float(ms[j]))
+        L.brutus_enable_timing(0)
+        res["kernels_ms"] = {k: float(np.mean(v)) for k, v in ktimes.items()}
+        res["kernel_sub_batch"] = int(subs[0][0].shape[0])
+        res["kernel_nsel"] = float(np.mean(nsel_k))
+    del engines, sel_bufs, subs
+    torch.cuda.empty_cache()
+    return res
+
+
+def roofline_of(res, args, config, world):
+    """SURVEY 8(d) / BASELINE.md section 4: achieved = stars/s x B_star (one float32
+    read of the grid per star = 108.0 MB at 750k x 12) against the 8 TB/s HBM peak,
+    for the WHOLE step.  The per-kernel entries carry each kernel's own algorithmic
+    bytes and, where a rocprofv3 PMC pass exists under profiles/, its measured traffic."""
+    g = float(args.nmodel) * args.nfilt * 12.
+    per_gpu = res["value"] / (world if args.scaling == "weak" else world)
+    ach = per_gpu * g / 1e9
+    rl = {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+          "frac": ach / HBM_PEAK_GBS, "traffic": None,
+          "algorithmic_bytes_per_star": g,
+          "definition": "stars/s (per GPU) x 108.0 MB (one f32 grid read per star) / 8 TB/s"}
+    if "kernels_ms" in res:
+        SB = res["kernel_sub_batch"]
+        pairs = float(SB) * args.nmodel
+        kern = {}
+        for name, ms in sorted(res["kernels_ms"].items(), key=lambda kv: -kv[1]):
+            alg = KERNEL_ALG_BYTES.get(name.replace("_cont", ""), None)
+            e = {"avg_launch_ms": ms}
+            if name.startswith("k_fflux"):
+                e["bound"] = "f64 VALU issue"
+            elif alg is not None:
+                ab = alg(SB, g, pairs, res["kernel_nsel"])
+                e.update(bound="hbm", algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
+            e["traffic"] = measured_traffic(name, SB, config)    # None for grouped timer entries
+            kern[name] = e
+        rl["kernels"] = kern
+        dom = max(res["kernels_ms"], key=res["kernels_ms"].get)
+        rl["dominant_kernel"] = dom
+        rl["sum_of_kernels_ms_per_sub_batch"] = float(sum(res["kernels_ms"].values()))
+        traffic = measured_traffic("__total__", SB, config)
+        if traffic:
+            # PMC bytes of every kernel of one sub-batch call, scaled to one step
+            rl["traffic"] = traffic * (float(args.batch) / SB)
+            rl["traffic_over_algorithmic"] = traffic / (SB * g)
+    return rl
+
+
 def main():
     args = parse()
     if args.config == 5:
@@ -298,9 +495,13 @@ def main():
     local_rank = _local_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    ranks_seen = 1
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         _init_pg(dist, rank, world, dev)
+        one = torch.ones(1, dtype=torch.int32, device=dev)
+        dist.all_reduce(one)                  # RCCL sum of ones = ranks that really joined
+        ranks_seen = int(one.item())
 
     L = _lib.lib()
     nmodel, nfilt = args.nmodel, args.nfilt
@@ -313,132 +514,32 @@ def main():
         from brutus_amd import parallel
         grid = parallel.broadcast_grid(grid if rank == 0 else None, nmodel,
                                        nfilt, dev, src=0)
-    # ---- stars: every rank draws its own shard -------------------------------
-    if args.config == 2:
-        kw = dict(rvlim=(3.32, 3.32))
-        with_par = False
-    else:
-        kw = dict()
-        with_par = True
-    seed = {2: 1, 3: 2}[args.config]
     if models is None:
         # ranks > 0 need the f32 coefficients only to synthesise their stars
         models, _, _ = synth.make_mist_like_grid(nmodel, nfilt)
-    B = args.batch
-    nb_pool = max(1, min(4, args.steps))       # distinct batches cycled through
-    stars = synth.make_stars(models, B * nb_pool, seed=seed + 1000 * rank,
-                             with_parallax=with_par)
-    params = fitting._make_params(
-        (0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
-        3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
-    NS = max(1, args.streams)
-    engines = [fitting._Engine(grid, max_batch=B, mem_budget=64e9) for _ in range(NS)]
-    eng = engines[0]
-    batches = []
-    for b in range(nb_pool):
-        sl = slice(b * B, (b + 1) * B)
-        batches.append(eng._upload(stars["flux"][sl], stars["err"][sl],
-                                   stars["mask"][sl],
-                                   stars["parallax"][sl] if with_par else None,
-                                   stars["parallax_err"][sl] if with_par else None))
-    # record buffer: the synthetic stars select up to ~500k models each
-    cap = max(32 << 20, B * 600000)
-    sel_bufs = [(torch.empty(cap, dtype=torch.int32, device=dev),
-                 torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
-                for _ in range(NS)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 
-    def step(i, j=0):
-        f, e, m, p, pe, hp = batches[i % nb_pool]
-        return engines[j].fit_batch_device(f, e, m, p, pe, hp, params,
-                                           sel_buffers=sel_bufs[j])
+    main_cfg = args.config
+    other_cfg = 3 if main_cfg == 2 else 2
+    res = run_config(main_cfg, args, L, grid, models, dev, world, rank, dist, torch)
+    res_other = None
+    if not args.single_config:
+        res_other = run_config(other_cfg, args, L, grid, models, dev, world, rank, dist, torch)
 
-    def run_steps(n):
-        """n steps; with --streams > 1 the steps are dealt round-robin to NS
-        host threads, each driving its own HIP stream and workspace."""
-        if NS == 1:
-            out = None
-            for i in range(n):
-                out = step(i)
-            return out
-        import threading
-        outs = [None] * NS
-
-        def worker(j):
-            torch.cuda.set_device(dev)
-            with torch.cuda.stream(streams[j]):
-                for i in range(j, n, NS):
-                    outs[j] = step(i, j)
-                streams[j].synchronize()
-
-        th = [threading.Thread(target=worker, args=(j,)) for j in range(NS)]
-        for t_ in th:
-            t_.start()
-        for t_ in th:
-            t_.join()
-        return next(o for o in outs if o is not None)
-
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    run_steps(max(args.warmup, NS if args.warmup else 0))
-    fence()
-    t0 = time.perf_counter()
-    out = run_steps(args.steps)
-    fence()
-    dt = time.perf_counter() - t0
-    nsel_total = int(out[2][-1].item())
-    if nsel_total > cap:
-        raise SystemExit("record buffer overflow (%d > %d): timing would be invalid"
-                         % (nsel_total, cap))
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-
-    # ---- per-kernel durations (HIP events on the launch stream), after the
-    # timed region so that the events do not perturb `value` --------------------
-    roofline = None
-    ktimes = {}
+    # measured on this box beside the 8 TB/s spec figure: the guide's reference stream
+    # (device copy, 16 B per lane; MI355X_MICROARCH.md quotes 6.29 TB/s for it)
+    stream_gbs = None
     if rank == 0 and not args.no_kernel_timing:
-        import ctypes as C
-        L.brutus_enable_timing(1)
-        reps = max(2, min(5, args.steps))
-        for i in range(reps):
-            step(i)
-            n = C.c_int(0)
-            names = (C.c_char_p * 16)()
-            ms = (C.c_float * 16)()
-            L.brutus_last_timing(C.byref(n), names, ms, 16)
-            for j in range(n.value):
-                ktimes.setdefault(names[j].decode(), []).append(float(ms[j]))
-        L.brutus_enable_timing(0)
-        avg = {k: float(np.mean(v)) for k, v in ktimes.items()}
-        dom = max(avg, key=avg.get)
-        bytes_per_star = nmodel * nfilt * 3 * 4      # SURVEY 8(d): one f32 grid read
-        achieved = B * bytes_per_star / (avg[dom] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved,
-                    "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS,
-                    "traffic": measured_traffic(dom, B, args.config),
-                    "avg_launch_ms": avg[dom],
-                    "all_kernels_ms": avg,
-                    "algorithmic_bytes_per_launch": B * bytes_per_star}
-        # measured on this box beside the 8 TB/s spec figure: a plain streaming
-        # kernel (1 GiB read with 4 B/lane, 2 GiB written with 8 B/lane)
-        n_cal = 256 << 20
-        src = torch.empty(n_cal, dtype=torch.float32, device=dev).normal_()
-        dst = torch.empty(n_cal, dtype=torch.float64, device=dev)
+        nbytes = 1 << 30
+        src = torch.empty(nbytes // 4, dtype=torch.float32, device=dev).normal_()
+        dst = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        _lib.check(L.brutus_calibrate_traffic(src.data_ptr(), dst.data_ptr(), n_cal, None))
+        _lib.check(L.brutus_calibrate_copy16(src.data_ptr(), dst.data_ptr(), nbytes, None))
         e0.record()
-        for _ in range(3):
-            _lib.check(L.brutus_calibrate_traffic(src.data_ptr(), dst.data_ptr(), n_cal, None))
+        for _ in range(5):
+            _lib.check(L.brutus_calibrate_copy16(src.data_ptr(), dst.data_ptr(), nbytes, None))
         e1.record()
         torch.cuda.synchronize()
-        roofline["measured_stream_gbs"] = 3 * 12.0 * n_cal / (e0.elapsed_time(e1) * 1e-3) / 1e9
+        stream_gbs = 5 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
     if world > 1:
@@ -448,34 +549,41 @@ def main():
             dist.destroy_process_group()
         return
 
-    stars_per_s = world * args.steps * B / dt
+    def cfg_block(cfg, r):
+        return {"workload": WORKLOADS[cfg], "nmodel": nmodel, "nfilt": nfilt,
+                "stars_per_step": args.batch, "sub_batch": args.sub_batch,
+                "distinct_stars_timed_per_rank": r["stars_timed_per_rank"],
+                "timed_region": "brutus_fit_batch: device-resident star vectors -> "
+                                "device-resident compact survivor records",
+                "selected_models_last_sub_batch": r["selected_models_last_sub_batch"],
+                "streams_per_gpu": max(1, args.streams),
+                "fit_path": int(os.environ.get("BRUTUS_FIT_PATH", "2")),
+                "parallelism": "stars sharded, %d rank(s), no data-path collective" % world}
+
     line = {
         "metric": "stars/sec at 750k-model x 12-band grid; achieved HBM GB/s vs peak",
-        "value": stars_per_s, "unit": "stars/s", "n_gpus": world,
+        "value": res["value"], "unit": "stars/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64",
-        "data": "synthetic",
-        "config": {"workload": ("configs[1]: 750k-model x 12-band grid, Av-only solve "
-                                "(rvlim=(3.32,3.32)), no parallax" if args.config == 2
-                                else "configs[2]: 750k-model x 12-band grid, Av+Rv free, "
-                                     "parallax prior"),
-                   "nmodel": nmodel, "nfilt": nfilt, "stars_per_step_per_gpu": B,
-                   "timed_region": "brutus_fit_batch: device-resident star vectors -> "
-                                   "device-resident compact survivor records",
-                   "selected_models_last_batch": nsel_total,
-                   "streams_per_gpu": NS,
-                   "parallelism": "stars sharded, %d rank(s)" % world},
-        "hbm_algorithmic_frac_whole_job":
-            stars_per_s / world * nmodel * nfilt * 12 / 1e9 / HBM_PEAK_GBS,
+        "ms_per_step": res["ms_per_step"], "higher_is_better": True,
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic", "config": cfg_block(main_cfg, res), "ranks_seen": ranks_seen,
     }
-    if roofline is not None:
-        line["roofline"] = roofline
+    rl = roofline_of(res, args, main_cfg, world)
+    if stream_gbs is not None:
+        rl["measured_stream_gbs"] = stream_gbs
+    line["roofline"] = rl
+    if res_other is not None:
+        line["other_config"] = {
+            "value": res_other["value"], "unit": "stars/s", "ms_per_step": res_other["ms_per_step"],
+            "config": cfg_block(other_cfg, res_other),
+            "roofline": roofline_of(res_other, args, other_cfg, world)}
     if world == 1 and args.e2e_stars > 0:
-        line["fit_end_to_end"] = end_to_end(models, grid, stars, args.e2e_stars,
-                                            kw, with_par)
+        kw = dict(rvlim=(3.32, 3.32)) if main_cfg == 2 else dict()
+        st_e2e = synth.make_stars(models, max(args.e2e_stars, 128), seed=main_cfg - 1,
+                                  with_parallax=main_cfg == 3)
+        line["fit_end_to_end"] = end_to_end(models, grid, st_e2e, args.e2e_stars, kw, main_cfg == 3)
     if world == 1 and args.cpu_seconds > 0:
-        line["cpu_baseline"] = cpu_baseline(args.config, nmodel, nfilt, args.cpu_seconds)
+        line["cpu_baseline"] = cpu_baseline(main_cfg, nmodel, nfilt, args.cpu_seconds)
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

@@ -80,6 +80,7 @@ SIGNATURES = {
                                      C.POINTER(C.c_float), C.c_int]),
     "brutus_enable_timing": (None, [C.c_int]),
     "brutus_calibrate_traffic": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "brutus_calibrate_copy16": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_math": (C.c_int, [_i32, _vp, _vp, _i64, _vp]),
     "brutus_post_workspace_bytes": (_sz, [_i32, _i64, _i32]),

@@ -86,6 +86,7 @@ struct Workspace {
     int32_t *surv_idx;  // (S * nmodel,) worst case
     int64_t *surv_off;  // (S + 1,)
     int32_t *wbase_surv, *wbase_sel;   // (S + 1,)
+    int32_t *bandn;                    // (S * NCHUNK,) band-queue fill of k_sel_classify
     unsigned long long *mask;          // (S, nmodel_pad / 64) membership words
     // second-generation path (fit2_kernels.hpp)
     Star32 *s32;                       // (S,)
@@ -149,6 +150,7 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         w.surv_off = (int64_t *)take(sizeof(int64_t) * (nstar + 1));
         w.wbase_surv = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
         w.wbase_sel = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
+        w.bandn = (int32_t *)take(sizeof(int32_t) * (size_t)NCHUNK * nstar);
         w.mask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
                                             (size_t)(pad_models(nmodel) / 64));
         const size_t nblk2 = (size_t)(ntile + F2_T - 1) / F2_T;
@@ -368,7 +370,7 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
         hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
                            w.pl.lnprob, w.thr_sel, (const double *)nullptr, w.counts,
                            (double *)nullptr, w.mask);
-    // path 2: k_select2 has already left the membership words and the chunk counts
+    // path 2: k_sel_classify / k_sel_band have left the membership words and the chunk counts
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts,
                        w.offsets, d_sel_off, w.wbase_sel);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
@@ -643,11 +645,13 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
     tm.end();
     hipLaunchKernelGGL(k_top_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids_all, 1, w.part,
                        w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
-    tm.begin("k_select2");
-    const size_t maxt = (size_t)(ntile / NCHUNK + 2);
-    const size_t shm = sizeof(unsigned long long) * 4 * maxt + sizeof(int32_t) * TILE * maxt;
-    hipLaunchKernelGGL((k_select2<NB, RVF>), dim3(NCHUNK, nstar), blk, shm, st, grid, nmodel, nmodel_pad,
-                       ntile, w.stars, w.s32, p, w.k1, w.lnlp32, w.lnpr32, w.thr_sel, w.pl, w.counts,
+    tm.begin("k_sel_classify");
+    hipLaunchKernelGGL(k_sel_classify, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.s32, w.lnlp32,
+                       w.lnpr32, w.pl.lnprob, w.thr_sel, w.counts, w.mask, w.surv_idx, w.bandn);
+    tm.end();
+    tm.begin("k_sel_band");      // (the candidate lists in surv_idx are no longer needed)
+    hipLaunchKernelGGL((k_sel_band<NB, RVF>), dim3(NCHUNK, nstar), blk, 0, st, grid, nmodel, nmodel_pad,
+                       ntile, w.stars, p, w.k1, w.lnpr32, w.thr_sel, w.surv_idx, w.bandn, w.counts,
                        w.mask, aud ? aud + 2 * nstar : nullptr);
     tm.end();
     if (int rc = run_select_emit<NB, RVF>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
@@ -1171,6 +1175,14 @@ int brutus_debug_galprior(const brutus_post_params *params, int n, const double 
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *stream) {
     if (!d_in || !d_out || n <= 0) return fail(BRUTUS_EINVAL, "bad calibration arguments");
     hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(TILE), 0, (hipStream_t)stream, d_in, d_out, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes, void *stream) {
+    if (!d_in || !d_out || nbytes < 16 || (nbytes & 15)) return fail(BRUTUS_EINVAL, "bad calibration arguments");
+    hipLaunchKernelGGL(k_calib_copy16, dim3(8192), dim3(TILE), 0, (hipStream_t)stream,
+                       (const float4 *)d_in, (float4 *)d_out, nbytes / 16);
     HIP_TRY(hipGetLastError());
     return 0;
 }

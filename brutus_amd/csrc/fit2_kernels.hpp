@@ -23,10 +23,12 @@
 //              lnl_p~ plane.
 //   k_top (B)  exact maximum of lnprob over the non-survivors that could exceed the
 //              survivors' maximum  ->  EXACT first-cut threshold.
-//   k_select2  selection bit-mask: float32 decides when |lnprob~ - thr| > eps, the
-//              models inside the band are queued in LDS and re-evaluated in float64;
-//              survivors by their final value.
-//   k_offsets + k_cmp_scatter + k_emit   ordered records, each written once.
+//   k_sel_classify + k_sel_band
+//              selection bit-mask: float32 decides when |lnprob~ - thr| > eps, the
+//              models inside the band are queued and re-evaluated in float64 with dense
+//              lanes; survivors by their final value.
+//   k_offsets + k_cmp_scatter + k_emit   ordered records, each written once: survivors
+//              from the result planes, the rest derived (K1 sweeps + full MLE).
 //
 // float32 never produces an output value or a decision: a lane whose float32 value
 // is NaN or inside the error band is re-evaluated in float64.  `eps` is a per-star
@@ -440,12 +442,12 @@ __device__ __forceinline__ void mag_phase(const Tile64<NB, RVF> &t, const StarPr
     av = p.av_mean;
     rv = p.rv_mean;
     if constexpr (RVF) {
+        // pinned Rv: the first sweep lands on the (clamped) minimiser, later ones move by
+        // rounding noise only (see k_fscan); one step, like k_fscan / k_emit
         GramR Gm;
         gram_init_rf<NB>(t.c, t.R, sp, Gm);
-        for (int k = 0; k < K; ++k) {
-            double a_, c_;
-            gram_sweep_rf(Gm, sp.S, p, av, a_, c_);
-        }
+        double a_, c_;
+        if (K > 0) gram_sweep_rf(Gm, sp.S, p, av, a_, c_);
     } else {
         Gram Gm;
         gram_init<NB>(t.c, sp, Gm);
@@ -632,38 +634,31 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 }
 
 // ---------------------------------------------------------------------------
-// k_select2: the first cut of lnpost as a bit-mask (fitting.py:976-991)
+// k_sel_classify + k_sel_band: the first cut of lnpost as a bit-mask (fitting.py:976-991)
 // ---------------------------------------------------------------------------
 // grid = (NCHUNK, nstar), one star per workgroup.  Survivors (+inf in the lnl_p~ plane)
-// are tested on their final float64 lnprob; the rest on lnprob~ with the margin eps;
-// models inside the band are queued in LDS and re-evaluated in float64 with dense
-// lanes.  Outputs as k_cmp_count: membership words + per-chunk counts.
-template <int NB, bool RVF>
-__global__ void __launch_bounds__(TILE, 2)
-k_select2(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ntile,
-          const StarPrep *__restrict__ stars, const Star32 *__restrict__ s32, DevParams p,
-          const int32_t *__restrict__ k1, const float *__restrict__ lnlp32,
-          const float *__restrict__ lnpr32, const double *__restrict__ thr_sel, Planes pl,
-          int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
-          float *__restrict__ aud) {
-    // dynamic LDS: membership words of the chunk, then the band queue (one slot per model
-    // of the chunk, so it can never overflow and the scan loop needs no barrier)
-    extern __shared__ unsigned long long words[];
+// are tested on their final float64 lnprob; the rest on lnprob~ with the margin eps.
+// Models inside the band |lnprob~ - thr| <= eps (or NaN) go to the block's region of
+// `bandq` (starts at s * nmodel + first model of the chunk: cannot overflow) and are
+// re-evaluated in float64, with dense lanes, by k_sel_band, which ORs the outcome into
+// the membership words.  Outputs as k_cmp_count: membership words + per-chunk counts.
+__global__ void __launch_bounds__(TILE)
+k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
+               const float *__restrict__ lnlp32, const float *__restrict__ lnpr32,
+               const double *__restrict__ lnprob_pl, const double *__restrict__ thr_sel,
+               int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
+               int32_t *__restrict__ bandq, int32_t *__restrict__ bandn) {
     __shared__ int qn;
     __shared__ int wsum[4];
-    __shared__ double s_tbl[64];
-    stage_exp_table(s_tbl);
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const int s = blockIdx.y, c = blockIdx.x;
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
-    const int maxt = ntile / NCHUNK + 2;
-    int32_t *queue = reinterpret_cast<int32_t *>(words + 4 * maxt);
-    const StarPrep &sp = stars[s];
     const double th = thr_sel[s];
     const double e = (double)s32[s].eps;
-    const int K = k1[s];
-    constexpr int U = 4;      // tiles in flight per lane (the loop is latency-bound otherwise)
+    int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
+    int n = 0;
+    constexpr int U = 4;      // tiles in flight per lane
     for (int tb = t0; tb < t1; tb += U) {
         float a[U], v32[U];
 #pragma unroll
@@ -681,20 +676,51 @@ k_select2(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, in
             bool yes = false, bd = false;
             if (i < nmodel) {
                 if (a[u] == INFINITY) {
-                    yes = pl.lnprob[(int64_t)s * nmodel + i] > th;
+                    yes = lnprob_pl[(int64_t)s * nmodel + i] > th;
                 } else {
                     const double v = (double)v32[u];
                     yes = v >= th + e;
                     bd = !yes && !(v < th - e);
                 }
             }
+            n += yes ? 1 : 0;
             const unsigned long long b = __ballot(yes);
-            if ((threadIdx.x & 63) == 0) words[(t - t0) * 4 + (threadIdx.x >> 6)] = b;
+            if ((threadIdx.x & 63) == 0)
+                mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
             if (bd) queue[atomicAdd(&qn, 1)] = (int32_t)i;
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
     __syncthreads();
-    const int n = qn;
+    if (threadIdx.x == 0) {
+        counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        bandn[s * NCHUNK + c] = qn;
+    }
+}
+
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(TILE, 2)
+k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ntile,
+           const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
+           const float *__restrict__ lnpr32, const double *__restrict__ thr_sel,
+           const int32_t *__restrict__ bandq, const int32_t *__restrict__ bandn,
+           int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
+           float *__restrict__ aud) {
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int n = bandn[s * NCHUNK + c];
+    if (n == 0) return;
+    __shared__ double s_tbl[64];
+    __shared__ int added;
+    stage_exp_table(s_tbl);
+    if (threadIdx.x == 0) added = 0;
+    __syncthreads();
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK);
+    const int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
+    const StarPrep &sp = stars[s];
+    const double th = thr_sel[s];
+    const int K = k1[s];
     for (int q = threadIdx.x; q < n; q += TILE) {
         const int64_t i = queue[q];
         Tile64<NB, RVF> tl;
@@ -709,23 +735,14 @@ k_select2(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, in
             first_cut_lnprob(sp, final_lnl<false>(sp, p, m.chi2, false), m.scale, m.i00);
         audit(aud, s, lnpr32[(int64_t)s * nmodel + i], lnprob, th);
         if (lnprob > th) {
-            const int k = (int)(i / TILE - t0) * 4 + (int)((i % TILE) >> 6);
-            atomicOr(&words[k], 1ull << (i & 63));
+            atomicOr(mask + (int64_t)s * (4 * ntile) + (i >> 6), 1ull << (i & 63));
+            atomicAdd(&added, 1);
         }
     }
     __syncthreads();
-    int cnt = 0;
-    for (int k = threadIdx.x; k < (t1 - t0) * 4; k += TILE) {
-        const unsigned long long b = words[k];
-        mask[(int64_t)s * (4 * ntile) + (int64_t)t0 * 4 + k] = b;
-        cnt += __popcll(b);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = cnt;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+    if (threadIdx.x == 0 && added) counts[(int64_t)s * NCHUNK + c] += added;   // this block owns the entry
 }
+
 
 // Deep K1 probe for ONE star (k_mag_stats partials with nstar = 1): the first sweep
 // k at which max{logwt : step >= tol} <= max logwt + ln(init_thresh)

@@ -505,6 +505,13 @@ __global__ void k_calib_stream(const float *__restrict__ in, double *__restrict_
         out[i] = (double)in[i];
 }
 
+// the guide's reference stream: 16 B per lane in, 16 B per lane out
+__global__ void k_calib_copy16(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+         i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
 __global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = fast_exp10(x[i]);

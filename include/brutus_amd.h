@@ -214,6 +214,10 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
  * on a known byte count (MI355X_MICROARCH.md, HBM section). */
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
                              void *stream);
+/* Plain device copy with 16 B per lane (nbytes a multiple of 16): the streaming
+ * ceiling MI355X_MICROARCH.md quotes (6.29 TB/s) is measured with this access. */
+int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes,
+                            void *stream);
 
 /* Test hooks: y[i] = the kernels' own 10^x / e^x / ln x for n inputs
  * (which = 0, 1, 2 in brutus_debug_math). */
