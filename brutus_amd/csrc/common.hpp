@@ -16,7 +16,7 @@ constexpr double BIG = 1e300;
 thread_local std::string g_err;
 bool g_timing = false;
 struct TimingEntry { std::string name; float ms; int count; };
-std::vector<TimingEntry> g_last_timing;
+thread_local std::vector<TimingEntry> g_last_timing;   // per calling thread (scan-ahead + lnpost threads time concurrently)
 
 int fail(int code, const char *fmt, ...) {
     char buf[512];

@@ -533,18 +533,18 @@ def _resolve_hooks(lngalprior, lndustprior, coord, apply_av_prior):
         from .galprior import gal_lnprior
         lngalprior = gal_lnprior
     if lndustprior is None and apply_av_prior:
-        raise NotImplementedError(
-            "the default 3-D dust-map prior needs the Bayestar map and healpy, "
-            "which are outside this package's scope; pass `lndustprior=` or an "
-            "`av_gauss` prior")
+        # reference fitting.py:961-962: the built-in 3-D dust prior; its line-of-sight
+        # table comes in through `dustfile` (pdf.LOSTable), not the Bayestar map
+        from .pdf import dust_lnprior
+        lndustprior = dust_lnprior
     return lngalprior, lndustprior
 
 
 def lnpost(results, parallax=None, parallax_err=None, coord=None,
            Nmc_prior=100, lnprior=None, wt_thresh=1e-3, cdf_thresh=2e-3,
            lngalprior=None, lndustprior=None, dustfile=None, dlabels=None,
-           avlim=(0., 20.), rvlim=(1., 8.), rstate=None,
-           apply_av_prior=True, mem_lim=8000., *args, **kwargs):
+           avlim=(0., 20.), rvlim=(1., 8.), mem_lim=8000., rstate=None,
+           apply_av_prior=True, *args, **kwargs):
     """Log-posteriors of the selected models from full-grid `loglike` results.
     Same signature and return values as reference `fitting.lnpost`
     (fitting.py:823-1107): `(sel, cov_sar, lnp, dist_mc, av_mc, rv_mc, lnp_mc)`.
@@ -603,12 +603,16 @@ def _pool_init(ctx):
 def _pool_task(args):
     rec, parallax, parallax_err, coord, seed = args
     c = _POOL_CTX
+    if c.get("rng_kind", "numpy") == "philox":      # same stream as the in-process stage
+        from .rng import PhiloxRandomState
+        rstate = PhiloxRandomState(seed)
+    else:
+        rstate = np.random.RandomState(seed)
     return BruteForce._finish_star(
         rec, parallax, parallax_err, coord, c["Nmc_prior"], c["lnprior"],
         c["wt_thresh"], c["cdf_thresh"], c["lngalprior"], c["lndustprior"],
         c["dustfile"], c["dlabels"], c["avlim"], c["rvlim"], c["mem_lim"],
-        np.random.RandomState(seed), c["apply_av_prior"], c["Ndraws"],
-        c["return_distreds"])
+        rstate, c["apply_av_prior"], c["Ndraws"], c["return_distreds"])
 
 
 class _HostPool(object):
@@ -731,9 +735,12 @@ class BruteForce(object):
             from .galprior import gal_lnprior
             lngalprior = gal_lnprior
         if lndustprior is None and dustfile is not None:
-            raise NotImplementedError(
-                "the Bayestar dust-map prior (`dustfile=`) is outside this "
-                "package's scope; pass your own `lndustprior` callable")
+            # reference fitting.py:1391-1395: the built-in 3-D dust prior.  Here the
+            # line-of-sight profiles come from a caller-supplied table
+            # (pdf.LOSTable) instead of the Bayestar map + healpy.
+            from .pdf import _los_provider, dust_lnprior
+            _los_provider(dustfile)           # raises for a Bayestar HDF5 path
+            lndustprior = dust_lnprior
         elif lndustprior is None and av_gauss is None:
             av_gauss = (0, 1e6)                       # fitting.py:1396-1398
         if data_coords is None:
@@ -945,11 +952,18 @@ class BruteForce(object):
                     mem_lim, return_distreds, rstate, seed0 if philox_per_object else None):
                 yield out
             return
+        pool = None
+        # worker processes rebuild the per-object stream from (kind, seed0 + i): only the
+        # two built-in kinds can be shipped; a user callable keeps the in-process stage
+        poolable = philox_per_object or rstate_per_object is None or getattr(
+            rstate_per_object, "_numpy_default", False)
         if seed0 is not None and rstate_per_object is None:
             rstate_per_object = lambda i: np.random.RandomState(seed0 + i)
-        pool = None
-        if seed0 is not None and self.host_workers and self.host_workers > 1:
+            rstate_per_object._numpy_default = True
+        if (seed0 is not None and self.host_workers and self.host_workers > 1
+                and poolable):
             pool = _HostPool(self.host_workers, dict(
+                rng_kind="philox" if philox_per_object else "numpy",
                 Nmc_prior=Nmc_prior, lnprior=lnprior, wt_thresh=wt_thresh,
                 cdf_thresh=cdf_thresh, lngalprior=lngalprior,
                 lndustprior=lndustprior, dustfile=dustfile, dlabels=dlabels,
@@ -1060,72 +1074,76 @@ class BruteForce(object):
                     streams[k % 2].synchronize()
                     return out
 
-        fut = pool.submit(scan, 0) if ahead else None
-        for kb, a in enumerate(starts):
-            b = min(Ndata, a + step)
-            S = b - a
-            with torch.cuda.device(dev):
-                if ahead:
-                    (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = fut.result()
-                    fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
-                else:
-                    (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = scan(kb)
-                pp = _lib.PostParams()
-                pp.nmc, pp.ndraws = int(Nmc_prior), int(Ndraws)
-                pp.return_distreds = 1 if return_distreds else 0
-                pp.has_feh = 1 if statics[1] is not None else 0
-                pp.has_loga = 1 if statics[2] is not None else 0
-                pp.wt_thresh = float(wt_thresh)
-                pp.avlim[:] = [float(avlim[0]), float(avlim[1])]
-                pp.rvlim[:] = [float(rvlim[0]), float(rvlim[1])]
-                pp.nsel_max = int(mem_lim / Nmc_prior / 4.0e-4)
-                if seed0 is not None:
-                    pp.per_object, pp.object0, pp.seed = 1, a, int(seed0) & (2 ** 64 - 1)
-                    pp.normal_base = pp.uniform_base = 0
-                else:
-                    pp.per_object, pp.object0, pp.seed = 0, 0, rstate.seed
-                    pp.normal_base, pp.uniform_base = rstate.n_normal, rstate.n_uniform
-                for k, val in gp.items():
-                    if isinstance(val, tuple):
-                        getattr(pp, k)[:] = list(val)
+        try:
+            fut = pool.submit(scan, 0) if ahead else None
+            for kb, a in enumerate(starts):
+                b = min(Ndata, a + step)
+                S = b - a
+                with torch.cuda.device(dev):
+                    if ahead:
+                        (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = fut.result()
+                        fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
                     else:
-                        setattr(pp, k, val)
-                out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
-                    sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
-                    parallax[a:b], parallax_err[a:b], pp)
-                ubase0 = pp.uniform_base
-                if seed0 is None:      # what the batch consumed from the shared stream
-                    rstate.n_normal = int(nbase[S])
-                    rstate.n_uniform = int(ubase0) + S * K
-                for s in range(S):
-                    i = a + s
-                    if flags[s]:
-                        # more than Nsel_max models survive the second cut: the
-                        # reference re-sorts them (fitting.py:1029-1036); rare,
-                        # done by the host stage on the same stream positions
-                        rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
-                              PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
-                                                n_uniform=int(ubase0) + s * K))
-                        rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
-                        yield self._finish_star(rec, parallax[i], parallax_err[i],
-                                                data_coords[i], Nmc_prior, lnprior,
-                                                wt_thresh, cdf_thresh, lngalprior, None,
-                                                None, dlabels, avlim, rvlim, mem_lim, rs,
-                                                False, Ndraws, return_distreds)
-                        continue
-                    if star_out[s, 3] < 1:
-                        raise ValueError("object %d: no model survives the prior "
-                                         "cuts (the reference fails in np.min on an "
-                                         "empty selection, fitting.py:2034)" % i)
-                    v = out_vals[s]
-                    nd = int(ndim[s]) + (1 if np.isfinite(parallax[i])
-                                         and np.isfinite(parallax_err[i]) else 0)
-                    res = (out_idx[s].astype(np.int64), v[:, 0], v[:, 1], v[:, 2],
-                           v[:, 3:12].reshape(-1, 3, 3), nd, v[:, 12],
-                           float(star_out[s, 0]), float(star_out[s, 1]))
-                    if return_distreds:
-                        res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
-                    yield res
+                        (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = scan(kb)
+                    pp = _lib.PostParams()
+                    pp.nmc, pp.ndraws = int(Nmc_prior), int(Ndraws)
+                    pp.return_distreds = 1 if return_distreds else 0
+                    pp.has_feh = 1 if statics[1] is not None else 0
+                    pp.has_loga = 1 if statics[2] is not None else 0
+                    pp.wt_thresh = float(wt_thresh)
+                    pp.avlim[:] = [float(avlim[0]), float(avlim[1])]
+                    pp.rvlim[:] = [float(rvlim[0]), float(rvlim[1])]
+                    pp.nsel_max = int(mem_lim / Nmc_prior / 4.0e-4)
+                    if seed0 is not None:
+                        pp.per_object, pp.object0, pp.seed = 1, a, int(seed0) & (2 ** 64 - 1)
+                        pp.normal_base = pp.uniform_base = 0
+                    else:
+                        pp.per_object, pp.object0, pp.seed = 0, 0, rstate.seed
+                        pp.normal_base, pp.uniform_base = rstate.n_normal, rstate.n_uniform
+                    for k, val in gp.items():
+                        if isinstance(val, tuple):
+                            getattr(pp, k)[:] = list(val)
+                        else:
+                            setattr(pp, k, val)
+                    out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
+                        sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
+                        parallax[a:b], parallax_err[a:b], pp)
+                    ubase0 = pp.uniform_base
+                    if seed0 is None:      # what the batch consumed from the shared stream
+                        rstate.n_normal = int(nbase[S])
+                        rstate.n_uniform = int(ubase0) + S * K
+                    for s in range(S):
+                        i = a + s
+                        if flags[s]:
+                            # more than Nsel_max models survive the second cut: the
+                            # reference re-sorts them (fitting.py:1029-1036); rare,
+                            # done by the host stage on the same stream positions
+                            rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
+                                  PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
+                                                    n_uniform=int(ubase0) + s * K))
+                            rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
+                            yield self._finish_star(rec, parallax[i], parallax_err[i],
+                                                    data_coords[i], Nmc_prior, lnprior,
+                                                    wt_thresh, cdf_thresh, lngalprior, None,
+                                                    None, dlabels, avlim, rvlim, mem_lim, rs,
+                                                    False, Ndraws, return_distreds)
+                            continue
+                        if star_out[s, 3] < 1:
+                            raise ValueError("object %d: no model survives the prior "
+                                             "cuts (the reference fails in np.min on an "
+                                             "empty selection, fitting.py:2034)" % i)
+                        v = out_vals[s]
+                        nd = int(ndim[s]) + (1 if np.isfinite(parallax[i])
+                                             and np.isfinite(parallax_err[i]) else 0)
+                        res = (out_idx[s].astype(np.int64), v[:, 0], v[:, 1], v[:, 2],
+                               v[:, 3:12].reshape(-1, 3, 3), nd, v[:, 12],
+                               float(star_out[s, 0]), float(star_out[s, 1]))
+                        if return_distreds:
+                            res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
+                        yield res
+        finally:
+            if pool is not None:      # also when the caller abandons the generator
+                pool.shutdown(wait=False)
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
                             lnprior_ext, offset, wt_thresh):

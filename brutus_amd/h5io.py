@@ -247,6 +247,54 @@ class _File(object):
         L.H5Sclose(sid)
         self._dsets[name] = (did, tid, close, tuple(shape), data.dtype)
 
+    def create_filled(self, name, shape, dtype, fill, block_rows=4096):
+        """Create a dataset holding `fill` everywhere without materialising it in RAM
+        (written in blocks of rows)."""
+        L = self.L
+        dt = np.dtype(dtype)
+        tid, close = _h5type(dt)
+        dims = (hsize_t * len(shape))(*shape)
+        sid = _check(L.H5Screate_simple(len(shape), dims, None), "H5Screate_simple")
+        did = _check(L.H5Dcreate2(self.fid, name.encode(), tid, sid, H5P_DEFAULT,
+                                  H5P_DEFAULT, H5P_DEFAULT), "H5Dcreate2 " + name)
+        L.H5Sclose(sid)
+        self._dsets[name] = (did, tid, close, tuple(shape), dt)
+        blk = np.full((min(block_rows, shape[0]),) + tuple(shape[1:]), fill, dtype=dt)
+        for a in range(0, shape[0], block_rows):
+            self.write_rows(name, a, blk[:min(block_rows, shape[0] - a)])
+
+    def bind_dataset(self, name, read_first_column=False):
+        """Bind an existing dataset for `write_rows` without reading it; optionally
+        return its first column (axis 1 index 0) only."""
+        L = self.L
+        did = _check(L.H5Dopen2(self.fid, name.encode(), H5P_DEFAULT),
+                     "H5Dopen2 " + name)
+        ftid = L.H5Dget_type(did)
+        dt = _nptype(ftid)
+        L.H5Tclose(ftid)
+        sid = L.H5Dget_space(did)
+        nd = L.H5Sget_simple_extent_ndims(sid)
+        dims = (hsize_t * max(nd, 1))()
+        L.H5Sget_simple_extent_dims(sid, dims, None)
+        shape = tuple(int(d) for d in dims[:nd])
+        tid, close = _h5type(dt)
+        self._dsets[name] = (did, tid, close, shape, dt)
+        col = None
+        if read_first_column:
+            st = (hsize_t * nd)(*([0] * nd))
+            cnt = (hsize_t * nd)(*([shape[0]] + [1] * (nd - 1)))
+            _check(L.H5Sselect_hyperslab(sid, H5S_SELECT_SET, st, None, cnt, None),
+                   "H5Sselect_hyperslab")
+            msp = L.H5Screate_simple(nd, cnt, None)
+            col = np.empty((shape[0],) + (1,) * (nd - 1), dtype=dt)
+            if col.size:
+                _check(L.H5Dread(did, tid, msp, sid, H5P_DEFAULT,
+                                 col.ctypes.data_as(C.c_void_p)), "H5Dread " + name)
+            L.H5Sclose(msp)
+            col = col.reshape(shape[0])
+        L.H5Sclose(sid)
+        return shape, col
+
     def open_dataset(self, name):
         """Bind an existing dataset for `write_rows`; returns its contents."""
         L = self.L
@@ -365,12 +413,35 @@ def read_dataset(path, name):
 class ResultsFile(object):
     """The fit() output file, reference layout (fitting.py:1632-1662).
 
-    Rows are staged in RAM and written to disk every `flush_every` objects
-    (and on close), so an interrupted run keeps everything up to the last
-    flush -- the purpose of the reference's `running_io=True` -- without one
-    tiny HDF5 write per dataset per object.  With `running_io=False`
-    everything is written once at the end (fitting.py:1784-1798).
+    `running_io=True` (default): the datasets are created on disk with the
+    reference's fill values (model_idx = -99 ...), finished rows are staged in RAM
+    and written every `flush_every` objects (and on close).  Memory is bounded by the
+    staging -- never by the catalogue -- and rows may arrive in any order (sharded
+    runs, resumed runs); an interrupted run keeps everything up to the last flush,
+    which is the purpose of the reference's `running_io`, without one tiny HDF5 write
+    per dataset per object.  `running_io=False`: everything is kept in RAM and
+    written once at the end, like the reference (fitting.py:1784-1798).
     """
+
+    SPEC = (("model_idx", (), "int32", -99), ("ml_scale", (), "float32", 1),
+            ("ml_av", (), "float32", 0), ("ml_rv", (), "float32", 0),
+            ("ml_cov_sar", (3, 3), "float32", 0), ("obj_log_post", (), "float32", 0))
+    SPEC1 = (("obj_log_evid", "float32", 0), ("obj_chi2min", "float32", 0),
+             ("obj_Nbands", "int16", 0))
+    DAR = ("samps_dist", "samps_red", "samps_dred", "samps_logp")
+
+    def _layout(self):
+        """name -> (row shape, dtype, fill, position in the yielded tuple)"""
+        nd = (self.Ndraws,)
+        lay = {"model_idx": (nd, "int32", -99, 0), "ml_scale": (nd, "float32", 1, 1),
+               "ml_av": (nd, "float32", 0, 2), "ml_rv": (nd, "float32", 0, 3),
+               "ml_cov_sar": (nd + (3, 3), "float32", 0, 4),
+               "obj_Nbands": ((), "int16", 0, 5), "obj_log_post": (nd, "float32", 0, 6),
+               "obj_log_evid": ((), "float32", 0, 7), "obj_chi2min": ((), "float32", 0, 8)}
+        if self.save_dar_draws:
+            for j, k in enumerate(self.DAR):
+                lay[k] = (nd, "float32", 1, 9 + j)
+        return lay
 
     def __init__(self, path, Ndata, Ndraws, data_labels, save_dar_draws,
                  running_io=True, flush_every=256):
@@ -378,31 +449,19 @@ class ResultsFile(object):
         self.Ndata, self.Ndraws = Ndata, Ndraws
         self.running_io = running_io
         self.flush_every = max(1, int(flush_every))
-        full = lambda shape, v, dt: np.full(shape, v, dtype=dt)
-        nd = (Ndata, Ndraws)
-        self.arrays = {
-            "model_idx": full(nd, -99, "int32"),
-            "ml_scale": full(nd, 1, "float32"),
-            "ml_av": full(nd, 0, "float32"),
-            "ml_rv": full(nd, 0, "float32"),
-            "ml_cov_sar": full(nd + (3, 3), 0, "float32"),
-            "obj_log_post": full(nd, 0, "float32"),
-            "obj_log_evid": full((Ndata,), 0, "float32"),
-            "obj_chi2min": full((Ndata,), 0, "float32"),
-            "obj_Nbands": full((Ndata,), 0, "int16"),
-        }
-        if save_dar_draws:
-            for k in ("samps_dist", "samps_red", "samps_dred", "samps_logp"):
-                self.arrays[k] = full(nd, 1, "float32")
         self.save_dar_draws = save_dar_draws
+        self.layout = self._layout()
+        self._pend = {}
+        self.arrays = None
         if data_labels is not None:
             self.file.create_dataset("labels", np.asarray(data_labels))
         if running_io:
-            for k, v in self.arrays.items():
-                self.file.create_dataset(k, v)
+            for k, (rs, dt, fill, _) in self.layout.items():
+                self.file.create_filled(k, (Ndata,) + rs, dt, fill)
             self.file.flush()
-        self._lo = 0   # first row not yet on disk
-        self._hi = 0   # one past the last row staged
+        else:
+            self.arrays = {k: np.full((Ndata,) + rs, fill, dtype=dt)
+                           for k, (rs, dt, fill, _) in self.layout.items()}
 
     @classmethod
     def resume(cls, path, Ndata, Ndraws, save_dar_draws, flush_every=256):
@@ -414,71 +473,62 @@ class ResultsFile(object):
         self.Ndata, self.Ndraws = Ndata, Ndraws
         self.running_io, self.flush_every = True, max(1, int(flush_every))
         self.save_dar_draws = save_dar_draws
-        names = ["model_idx", "ml_scale", "ml_av", "ml_rv", "ml_cov_sar",
-                 "obj_log_post", "obj_log_evid", "obj_chi2min", "obj_Nbands"]
-        if save_dar_draws:
-            names += ["samps_dist", "samps_red", "samps_dred", "samps_logp"]
-        self.arrays = {}
+        self.layout = self._layout()
+        self._pend = {}
+        self.arrays = None
         try:
-            for k in names:
-                self.arrays[k] = self.file.open_dataset(k)
-            if self.arrays["model_idx"].shape != (Ndata, Ndraws):
-                raise ValueError("existing results file has shape %r, expected %r"
-                                 % (self.arrays["model_idx"].shape, (Ndata, Ndraws)))
+            first = None
+            for k in self.layout:
+                shape, col = self.file.bind_dataset(k, read_first_column=(k == "model_idx"))
+                if k == "model_idx":
+                    first = col
+                    if shape != (Ndata, Ndraws):
+                        raise ValueError("existing results file has shape %r, expected %r"
+                                         % (shape, (Ndata, Ndraws)))
         except Exception:
             self.file.close()
             raise
-        self.todo = np.where(self.arrays["model_idx"][:, 0] == -99)[0]
-        self._lo = self._hi = 0
-        self._dirty = set()
+        self.todo = np.where(first == -99)[0]
         return self
 
     def write_row(self, i, results):
-        a = self.arrays
-        a["model_idx"][i] = results[0]
-        a["ml_scale"][i] = results[1]
-        a["ml_av"][i] = results[2]
-        a["ml_rv"][i] = results[3]
-        a["ml_cov_sar"][i] = results[4]
-        a["obj_Nbands"][i] = results[5]
-        a["obj_log_post"][i] = results[6]
-        a["obj_log_evid"][i] = results[7]
-        a["obj_chi2min"][i] = results[8]
-        if self.save_dar_draws:
-            a["samps_dist"][i] = results[9]
-            a["samps_red"][i] = results[10]
-            a["samps_dred"][i] = results[11]
-            with np.errstate(over="ignore"):     # -1e300 (out-of-bounds draw) -> -inf in f32, as h5py does
-                a["samps_logp"][i] = results[12]
-        if getattr(self, "_dirty", None) is not None:
-            # resumed file: rows arrive in arbitrary positions
-            self._dirty.add(i)
-            if len(self._dirty) >= self.flush_every:
-                self._flush_rows()
+        if self.arrays is not None:            # running_io=False: everything in RAM
+            with np.errstate(over="ignore"):
+                for k, (_, _, _, pos) in self.layout.items():
+                    self.arrays[k][i] = results[pos]
             return
-        self._hi = max(self._hi, i + 1)
-        if self.running_io and self._hi - self._lo >= self.flush_every:
+        row = {}
+        with np.errstate(over="ignore"):   # -1e300 (out-of-bounds draw) -> -inf in f32, as h5py does
+            for k, (rs, dt, _, pos) in self.layout.items():
+                v = np.empty(rs, dtype=dt)
+                v[...] = results[pos]
+                row[k] = v
+        self._pend[int(i)] = row
+        if len(self._pend) >= self.flush_every:
             self._flush_rows()
 
     def _flush_rows(self):
-        if getattr(self, "_dirty", None) is not None:
-            for i in sorted(self._dirty):
-                for k, v in self.arrays.items():
-                    self.file.write_rows(k, i, v[i:i + 1])
-            self._dirty.clear()
-            self.file.flush()
+        if not self._pend:
             return
-        if self._hi > self._lo:
-            for k, v in self.arrays.items():
-                self.file.write_rows(k, self._lo, v[self._lo:self._hi])
-            self.file.flush()
-            self._lo = self._hi
+        idx = sorted(self._pend)
+        # contiguous runs of row numbers -> one hyperslab write per dataset and run
+        runs, a = [], 0
+        for j in range(1, len(idx) + 1):
+            if j == len(idx) or idx[j] != idx[j - 1] + 1:
+                runs.append((a, j))
+                a = j
+        for a, b in runs:
+            for k in self.layout:
+                block = np.stack([self._pend[i][k] for i in idx[a:b]])
+                self.file.write_rows(k, idx[a], block)
+        self._pend.clear()
+        self.file.flush()
 
     def close(self):
         if self.file is None:
             return
         try:
-            if self.running_io:
+            if self.arrays is None:
                 self._flush_rows()
             else:
                 for k, v in self.arrays.items():

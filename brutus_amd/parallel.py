@@ -9,7 +9,8 @@ kernel layout (108 MB at 750k x 12) and of the static prior vector.
 """
 import numpy as np
 
-__all__ = ["shard_range", "broadcast_grid", "broadcast_array", "gather_rows"]
+__all__ = ["shard_range", "broadcast_grid", "broadcast_array", "gather_rows",
+           "fit_sharded"]
 
 
 def shard_range(n, rank, world):
@@ -74,12 +75,20 @@ def gather_rows(local_rows, dst=0):
 
 
 def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
-                seed0=0, rng="philox", **fit_kwargs):
+                seed0=0, rng="philox", chunk=256, **fit_kwargs):
     """`BruteForce.fit` over all ranks of the default process group.
 
     Every rank fits the contiguous shard `shard_range(Ndata, rank, world)` on
-    its own GPU (no collective on the data path); rank 0 gathers the per-object
-    rows in rank order and writes `{save_file}.h5` in the reference layout.
+    its own GPU (no collective on the data path).  The rows go to rank 0 in
+    bounded pieces: in round k every rank hands over its next `chunk` objects
+    (`gather_object` of at most `chunk` rows per rank), rank 0 writes them at
+    their catalogue positions -- row `lo_r + k * chunk + j`, the mapping of
+    reference fitting.py:1734-1748 -- through the buffered `ResultsFile`, and
+    nothing else is kept: no rank ever holds more than `chunk` finished rows,
+    rank 0 no more than `world * chunk` (+ the writer's `flush_every`), whatever
+    the catalogue size.  With `running_io=True` (default) the file on disk is
+    current up to the last flush, so a crash loses at most one round.
+
     Object `i` draws from its own stream keyed `seed0 + i`, so the file is
     identical for any number of ranks (the reference's single sequential
     stream, fitting.py:2039-2053, would make results depend on the sharding):
@@ -88,18 +97,24 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     `numpy.random.RandomState(seed0 + i)` and the host stage (optionally
     spread over `bf.host_workers` processes).
 
-    `fit_kwargs` are `BruteForce.fit` keyword arguments.  Returns the number of
-    objects this rank fitted.
+    `fit_kwargs` are `BruteForce.fit` keyword arguments (`lnprior_ext` arrays
+    are sliced to each rank's shard; `resume` is not supported here).  Returns
+    the number of objects this rank fitted.
     """
     import torch.distributed as dist
     from . import h5io
     rank, world = dist.get_rank(), dist.get_world_size()
     kw = dict(fit_kwargs)
+    if kw.pop("resume", False):
+        raise ValueError("fit_sharded: `resume` is not supported (rows are written by "
+                         "rank 0 in catalogue order; re-run the missing range instead)")
     Ndraws = kw.pop("Ndraws", 250)
     save_dar_draws = kw.pop("save_dar_draws", True)
     running_io = kw.pop("running_io", True)
+    lnprior_ext = kw.pop("lnprior_ext", None)
     kw.pop("verbose", None)
     kw.pop("rstate", None)
+    chunk = max(1, int(chunk))
     setup_keys = ("phot_offsets", "parallax", "parallax_err", "av_gauss",
                   "lnprior", "wt_thresh", "cdf_thresh", "apply_agewt",
                   "apply_grad", "lngalprior", "lndustprior", "dustfile",
@@ -118,9 +133,12 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                         "wt_thresh")}
     if "logl_dim_prior" not in fkw:
         fkw["logl_dim_prior"] = True
+    if lnprior_ext is not None:
+        # per-object constraints: this rank sees objects lo..hi as 0..hi-lo
+        fkw["lnprior_ext"] = {k: np.asarray(v)[lo:hi] for k, v in lnprior_ext.items()}
     par = kw.get("parallax")
     perr = kw.get("parallax_err")
-    rows = list(bf._fit(
+    gen = bf._fit(
         data[lo:hi], data_err[lo:hi], data_mask[lo:hi],
         parallax=None if par is None else np.asarray(par)[lo:hi],
         parallax_err=None if perr is None else np.asarray(perr)[lo:hi],
@@ -128,16 +146,35 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[lo:hi],
         Ndraws=Ndraws, return_distreds=save_dar_draws,
         seed0=seed0 + lo,
-        rstate_per_object="philox" if rng == "philox" else None, **fkw))
-    allrows = gather_rows(rows, dst=0)
+        rstate_per_object="philox" if rng == "philox" else None, **fkw)
+    bounds = [shard_range(Ndata, r, world) for r in range(world)]
+    nround = (max(b - a for a, b in bounds) + chunk - 1) // chunk
+    out = None
     if rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
                                data_labels, save_dar_draws,
                                running_io=running_io)
-        try:
-            for i, r in enumerate(allrows):
-                out.write_row(i, r)
-        finally:
+    try:
+        for k in range(nround):
+            mine = []
+            for _ in range(chunk):          # this rank's next piece (may be empty)
+                try:
+                    mine.append(next(gen))
+                except StopIteration:
+                    break
+            parts = [None] * world if rank == 0 else None
+            dist.gather_object(mine, parts, dst=0)
+            del mine
+            if rank == 0:
+                for r, part in enumerate(parts):
+                    base = bounds[r][0] + k * chunk
+                    for j, row in enumerate(part):
+                        out.write_row(base + j, row)
+                del parts
+    finally:
+        if hasattr(gen, "close"):
+            gen.close()                     # shuts the scan-ahead helper thread down
+        if out is not None:
             out.close()
     dist.barrier()
     return hi - lo

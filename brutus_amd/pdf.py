@@ -12,7 +12,8 @@ import os
 import numpy as np
 
 __all__ = ["imf_lnprior", "ps1_MrLF_lnprior", "parallax_lnprior",
-           "scale_parallax_lnprior", "parallax_to_scale"]
+           "scale_parallax_lnprior", "parallax_to_scale", "dust_lnprior",
+           "LOSTable"]
 
 
 def _kroupa_segment(m, alpha_low, alpha_high, mass_break):
@@ -50,8 +51,8 @@ def ps1_MrLF_lnprior(Mr):
     """PS1 r-band luminosity-function prior: linear interpolation (with linear
     extrapolation) of a two-column (M_r, ln LF) table (reference pdf.py:111-141).
 
-    The table is looked up at $BRUTUS_AMD_PSLF, else next to this file as
-    `PSMrLF_lnprior.dat` (the reference ships it as brutus/PSMrLF_lnprior.dat).
+    The table ships with the package (`PSMrLF_lnprior.dat`, the reference's data
+    file brutus/PSMrLF_lnprior.dat, unchanged); $BRUTUS_AMD_PSLF overrides it.
     """
     global _PS_TABLE
     if _PS_TABLE is None:
@@ -101,3 +102,86 @@ def scale_parallax_lnprior(scales, scale_errs, p_meas, p_err, snr_lim=4.):
     with np.errstate(all="ignore"):
         var = s_std ** 2 + np.asarray(scale_errs, dtype=np.float64) ** 2
         return -0.5 * ((scales - s_mean) ** 2 / var + np.log(2. * np.pi * var))
+
+
+# ---------------------------------------------------------------------------
+# 3-D dust prior without Bayestar / healpy
+# ---------------------------------------------------------------------------
+class LOSTable(object):
+    """Line-of-sight reddening profiles supplied by the caller: what the reference
+    obtains from `dust.Bayestar.query(coord)` (dust.py:184-299), i.e. for a
+    sightline the arrays `(av_dist [kpc], av_mean, av_err)`, without the Bayestar
+    HDF5 map or healpy.
+
+    `LOSTable(l, b, dist, av_mean, av_err)`: `l, b` (Nlos,) Galactic degrees of the
+    tabulated sightlines, `dist` (Ndist,) kpc, `av_mean`, `av_err` (Nlos, Ndist).
+    `query(coord)` returns the profile of the nearest tabulated sightline (great-
+    circle distance); profiles with NaNs mean "no coverage", like the reference.
+    `LOSTable.load(path)` reads the same five arrays from an `.npz` file.
+    """
+
+    def __init__(self, l, b, dist, av_mean, av_err):
+        self.l = np.atleast_1d(np.asarray(l, dtype=np.float64))
+        self.b = np.atleast_1d(np.asarray(b, dtype=np.float64))
+        self.dist = np.asarray(dist, dtype=np.float64)
+        self.av_mean = np.atleast_2d(np.asarray(av_mean, dtype=np.float64))
+        self.av_err = np.atleast_2d(np.asarray(av_err, dtype=np.float64))
+        if self.av_mean.shape != (self.l.size, self.dist.size) or \
+                self.av_err.shape != self.av_mean.shape or self.b.size != self.l.size:
+            raise ValueError("LOSTable: av_mean / av_err must be (Nlos, Ndist)")
+
+    @classmethod
+    def load(cls, path):
+        z = np.load(path)
+        return cls(z["l"], z["b"], z["dist"], z["av_mean"], z["av_err"])
+
+    def query(self, coord):
+        l0, b0 = np.deg2rad(coord[0]), np.deg2rad(coord[1])
+        l, b = np.deg2rad(self.l), np.deg2rad(self.b)
+        cosd = np.sin(b0) * np.sin(b) + np.cos(b0) * np.cos(b) * np.cos(l - l0)
+        k = int(np.argmax(cosd))
+        return self.dist, self.av_mean[k], self.av_err[k]
+
+
+def _los_provider(dustfile):
+    if dustfile is None:
+        raise ValueError("dust_lnprior needs a line-of-sight table: pass "
+                         "`dustfile=` a LOSTable, an object with `.query(coord)`, a "
+                         "callable `coord -> (dist, av_mean, av_err)` or the path of "
+                         "an .npz file with arrays l, b, dist, av_mean, av_err")
+    if hasattr(dustfile, "query"):
+        return dustfile.query
+    if callable(dustfile):
+        return dustfile
+    if isinstance(dustfile, str) and dustfile.endswith(".npz"):
+        return LOSTable.load(dustfile).query
+    raise NotImplementedError(
+        "dustfile=%r: reading the Bayestar HDF5 map needs healpy, which is outside "
+        "this package's scope; convert the sightlines you need to a LOSTable "
+        "(see brutus_amd.pdf.LOSTable)" % (dustfile,))
+
+
+def dust_lnprior(dists, coord, avs, dustfile=None, offset=0., scale=1., smooth=1.,
+                 scatter=0.2, return_components=False):
+    """ln prior of a 3-D dust model: Gaussian in Av around the line-of-sight
+    profile interpolated at `dists` (reference pdf.py:752-840, same arithmetic);
+    flat if the sightline has no coverage.  The profile comes from `dustfile`,
+    here a caller-supplied table instead of the Bayestar map (see `LOSTable`).
+    Same hook signature as the reference: `lndustprior(dists, coord, avs, dustfile=)`.
+    """
+    av_dist, av_mean, av_err = _los_provider(dustfile)(coord)
+    dists = np.asarray(dists, dtype=np.float64)
+    avs = np.asarray(avs, dtype=np.float64)
+    if np.all(np.isfinite(av_mean) & np.isfinite(av_err)):
+        av_mean = scale * np.interp(dists, av_dist, av_mean) + offset
+        av_err = smooth * scale * np.interp(dists, av_dist, av_err)
+        av_err = np.sqrt(av_err ** 2 + scatter ** 2)
+        with np.errstate(all="ignore"):
+            chi2 = (avs - av_mean) ** 2 / av_err ** 2
+            lnorm = np.log(2. * np.pi * av_err ** 2)
+        lnprior = -0.5 * (chi2 + lnorm)
+    else:
+        lnprior = np.zeros_like(avs)
+    if not return_components:
+        return lnprior
+    return lnprior, (av_mean, av_err)

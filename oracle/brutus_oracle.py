@@ -569,11 +569,26 @@ def lnpost(results, parallax=None, parallax_err=None, coord=None,
     return sel, cov_sar, lnp, dist_mc.T, a_mc.T, r_mc.T, lnp_mc.T
 
 
+def ps1_MrLF_lnprior(Mr, table=None):
+    """pdf.py:111-141: `interp1d(grid_Mr, grid_lnp, fill_value='extrapolate')` of the
+    reference's bundled two-column data table (read here as DATA from the copy the
+    package ships, brutus_amd/PSMrLF_lnprior.dat)."""
+    import os
+    from scipy.interpolate import interp1d
+    if table is None:
+        table = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))),
+                             "brutus_amd", "PSMrLF_lnprior.dat")
+    grid_Mr, grid_lnp = np.loadtxt(table).T
+    return interp1d(grid_Mr, grid_lnp, fill_value='extrapolate')(Mr)
+
+
 def static_lnprior(labels, labels_mask, apply_agewt=True, apply_grad=True):
-    """fitting.py:1334-1359 (`_setup`): IMF prior on `mini`, age weights and
-    grid-spacing terms.  (The PS1 LF fallback for `Mr`-only grids needs the
-    reference's bundled data table and is not restated here.)"""
-    lnprior = imf_lnprior(labels['mini'])
+    """fitting.py:1334-1359 (`_setup`): IMF prior on `mini` (PS1 luminosity function on
+    `Mr` when the grid has no `mini`, :1338-1346), age weights and grid-spacing terms."""
+    if 'mini' in labels.dtype.names:
+        lnprior = imf_lnprior(labels['mini'])
+    else:
+        lnprior = ps1_MrLF_lnprior(labels['Mr'])
     if apply_agewt and 'agewt' in labels.dtype.names:
         with np.errstate(all="ignore"):
             lnprior = lnprior + np.log(np.abs(labels['agewt']))
@@ -608,6 +623,19 @@ def fit_star(data, data_err, data_mask, models, lnprior, labels, coord,
                       ltol_subthresh=ltol_subthresh, init_thresh=init_thresh,
                       parallax=parallax, parallax_err=parallax_err,
                       return_vals=True)
+    return finish_star(results, lnprior, labels, coord, parallax, parallax_err, rstate,
+                       lngalprior, lndustprior=lndustprior, Nmc_prior=Nmc_prior,
+                       avlim=avlim, rvlim=rvlim, wt_thresh=wt_thresh, Ndraws=Ndraws,
+                       mem_lim=mem_lim, return_distreds=return_distreds,
+                       apply_av_prior=apply_av_prior)
+
+
+def finish_star(results, lnprior, labels, coord, parallax, parallax_err, rstate,
+                lngalprior, lndustprior=None, Nmc_prior=50, avlim=(0., 20.),
+                rvlim=(1., 8.), wt_thresh=1e-3, Ndraws=250, mem_lim=8000.,
+                return_distreds=True, apply_av_prior=False):
+    """`lnpost` + the resampling tail of the star loop (fitting.py:2010-2065) from
+    full-grid `loglike` results."""
     lnlike, Ndim, chi2, scales, avs, rvs, icovs = results
     sel, cov_sar, lnprob, dists, reds, dreds, logwts = lnpost(
         results, parallax=parallax, parallax_err=parallax_err, coord=coord,

@@ -330,3 +330,71 @@ def test_user_dust_prior_hook_vs_oracle():
                          st["coords"][i], st["parallax"][i], st["parallax_err"][i], ro,
                          galprior, lndustprior=dust, dim_prior=False, **kw)
         _compare(dev[i], ref, i)
+
+
+def test_device_psd_repair_on_crafted_records():
+    """The crafted non-positive-definite set of tests/golden/psd.npz (the reference runs
+    its repair loop, fitting.py:1039-1065, on 128 of the 160 matrices; the host stage is
+    pinned to it in tests/test_priors_golden.py) fed to the DEVICE post stage as first-cut
+    records: same repaired covariances, same resampled indices as the oracle driven by the
+    same PhiloxRandomState."""
+    import os
+    import torch
+    from helpers import GOLDEN
+    from brutus_amd import _lib, fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    z = np.load(os.path.join(GOLDEN, "psd.npz"))
+    n = len(z["scale"])
+    lab = np.zeros(n, dtype=[('feh', 'f8'), ('loga', 'f8')])
+    lab['feh'] = z["feh"]
+    lab['loga'] = 9.5
+    models, _, _ = synth.make_grid(n, 6, seed=1)          # only to own an engine
+    eng = fitting._Engine(fitting.DeviceGrid(models), max_batch=2)
+    dev = eng.grid.device
+    coord, par, perr = np.array([[50., 20.]]), np.array([1.2]), np.array([0.1])
+    Nmc, Ndraws = 25, 80
+    # records of one object: every model selected by the first cut, ascending order
+    vals = np.empty((_lib.NVALS, n))
+    vals[0], vals[1], vals[2], vals[3], vals[4] = z["lnl"], z["chi2"], z["scale"], z["av"], z["rv"]
+    ic = z["icov"]
+    for k, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+        vals[5 + k] = ic[:, a, b]
+    up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
+    sel_idx = up(np.arange(n), torch.int32)
+    sel_vals = up(vals, torch.float64)
+    sel_off = up(np.array([0, n]), torch.int64)
+    statics = (up(z["lnprior"], torch.float64), up(lab['feh'], torch.float64),
+               up(lab['loga'], torch.float64))
+    pp = _lib.PostParams()
+    pp.nmc, pp.ndraws, pp.return_distreds = Nmc, Ndraws, 1
+    pp.has_feh = pp.has_loga = 1
+    pp.wt_thresh = 1e-3
+    pp.avlim[:] = [0., 20.]
+    pp.rvlim[:] = [1., 8.]
+    pp.nsel_max = 400000
+    pp.per_object, pp.object0, pp.seed = 0, 0, 99
+    pp.normal_base = pp.uniform_base = 0
+    for k, val in gal_lnprior.device_params().items():
+        if isinstance(val, tuple):
+            getattr(pp, k)[:] = list(val)
+        else:
+            setattr(pp, k, val)
+    out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
+        sel_idx, sel_vals, sel_off, 1, statics, coord, par, perr, pp)
+    res = (z["lnl"].copy(), 8, z["chi2"].copy(), z["scale"].copy(), z["av"].copy(),
+           z["rv"].copy(), z["icov"].copy())
+    ref = O.finish_star(res, z["lnprior"].copy(), lab, coord[0], par[0], perr[0],
+                        PhiloxRandomState(99), gal_lnprior, Nmc_prior=Nmc, Ndraws=Ndraws)
+    assert flags[0] == 0
+    v = out_vals[0]
+    assert np.array_equal(out_idx[0].astype(np.int64), ref[0])
+    # at least a third of the drawn models went through the repair loop
+    assert np.mean(z["not_psd_before"][ref[0]]) > 0.3
+    assert relerr(ref[4], v[:, 3:12].reshape(-1, 3, 3)) < 1e-8       # repaired covariances
+    assert relerr(ref[6], v[:, 12]) < 1e-8                            # lnprob
+    assert abs(ref[7] - star_out[0, 0]) < 1e-8 * abs(ref[7])          # log evidence
+    for a, b in ((ref[9], v[:, 13]), (ref[10], v[:, 14]), (ref[11], v[:, 15]),
+                 (ref[12], v[:, 16])):
+        assert relerr(a, b) < 1e-8

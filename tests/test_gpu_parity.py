@@ -539,23 +539,56 @@ def test_fit_orion_catalogue_vs_reference_golden():
                         data_coords=z["coords"], Ndraws=100,
                         seed0=int(z["seed0"])))
     # The reference decides "is cov positive definite?" from the SIGN of
-    # np.linalg.eigvals (fitting.py:1042).  For a 4-band object whose scale
-    # variance is 1e-21 next to Av/Rv variances of 1e-4 the smallest eigenvalue
-    # is below eps*||cov||, its computed sign is rounding noise, and with it the
-    # whole regularisation loop (fitting.py:1045-1065).  Such objects are only
-    # held to the cov-independent outputs.
-    n_illcond = 0
+    # np.linalg.eigvals (fitting.py:1042).  For a 4-band object whose scale variance is
+    # 1e-21 next to Av/Rv variances of 1e-4 the smallest eigenvalue is below
+    # eps * ||cov||: its computed sign is rounding noise, and with it the whole
+    # regularisation loop (fitting.py:1045-1065).  CRITERION for leaving an object's
+    # cov-dependent outputs unchecked: for at least one model that survives the second
+    # cut, the reference's own decision (sign pattern of eigvals of inverse3(icov))
+    # flips when the precision matrix is perturbed by 1e-12 relative -- the agreement
+    # level of `icov` between any two correct implementations of `loglike`.
+    eng = BF._engine()
+    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18), 3e-2, 1e-2,
+                                  5e-3, True, wt_thresh=1e-3)
+    recs = eng.fit_batch(z["flux"], z["err"], z["mask"], z["parallax"], z["parallax_err"],
+                         params)
+
+    def decision_is_noise(i):
+        from brutus_amd.utils import _inverse3
+        r = recs[i]
+        with np.errstate(all="ignore"):
+            lnp = (r["lnlike"] + z["lnprior"][r["sel"]]
+                   + galprior(1. / np.sqrt(r["scale"]), z["coords"][i], labels=labels[r["sel"]]))
+        keep = lnp > np.log(1e-3) + np.max(lnp)
+        icov = r["icov"][keep]
+        rng = np.random.RandomState(i)
+
+        def bad(ic):
+            with np.errstate(all="ignore"):
+                return ~np.all(np.linalg.eigvals(_inverse3(ic)) > 0, axis=1)
+        base = bad(icov)
+        for _ in range(4):
+            e = rng.uniform(-1e-12, 1e-12, size=icov.shape)
+            e = 0.5 * (e + np.transpose(e, (0, 2, 1)))
+            if np.any(bad(icov * (1. + e)) != base):
+                return True
+        return False
+
+    exempt = []
     for i, out in enumerate(outs):
         assert np.array_equal(out[0], z["sidxs"][i]), "object %d indices" % i
-        ev = np.linalg.eigvalsh(z["cov"][i])
-        ill = np.any(np.abs(ev[:, 0]) < 1e-13 * np.abs(ev[:, -1]))
-        n_illcond += int(ill)
+        noise = None
         for n, got in zip(names[1:], out[1:]):
-            if ill and n in ("cov", "lnprob", "levid", "dists", "reds", "dreds",
-                             "logwts"):
+            err = relerr(z[n][i], got)
+            if err < 1e-5:
                 continue
-            assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
-    assert n_illcond <= 4        # of 20
+            assert n in ("cov", "lnprob", "levid", "dists", "reds", "dreds", "logwts"), (i, n, err)
+            if noise is None:
+                noise = decision_is_noise(i)
+            assert noise, (i, n, err)
+        if noise:
+            exempt.append(i)
+    print("objects whose PSD decision is rounding noise in the reference itself:", exempt)
 
 
 def test_cabi_error_codes():

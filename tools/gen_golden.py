@@ -383,10 +383,143 @@ def gen_fit_philox():
                         **{k: np.array(v) for k, v in res.items()})
 
 
+def gen_ps1():
+    """`ps1_MrLF_lnprior` (reference pdf.py:111-141) on a grid that leaves the table on
+    both sides (linear extrapolation), and `_setup`'s static prior for a Bayestar-style
+    grid whose labels carry `Mr` but no `mini` (reference fitting.py:1334-1346)."""
+    Mr = np.concatenate([np.linspace(-6., 24., 121), [-2., 16., 4.9999, 5.0001]])
+    out = P.ps1_MrLF_lnprior(Mr)
+    models, labels, lmask = synth.make_grid(1024, 6, seed=43)
+    ltype = np.dtype([('Mr', 'f8'), ('feh', 'f8'), ('agewt', 'f8')])
+    lab = np.zeros(len(labels), dtype=ltype)
+    lab['Mr'] = np.round(np.random.RandomState(3).uniform(-3., 17., len(labels)) / 0.25) * 0.25
+    lab['feh'] = labels['feh']
+    lab['agewt'] = labels['agewt']
+    mtype = np.dtype([(n, '?') for n in ltype.names])
+    lm = np.zeros(1, dtype=mtype)
+    lm['Mr'] = True
+    lm['feh'] = True
+    st = synth.make_stars(models, 4, seed=12)
+    BF = F.BruteForce(models.astype(np.float64), lab, lm)
+    res = BF._setup(st['flux'].copy(), st['err'].copy(), st['mask'].copy(), None,
+                    data_coords=st['coords'], lngalprior=galprior)
+    np.savez_compressed(os.path.join(OUT, "ps1.npz"), Mr=Mr, lnp=out, grid_seed=43,
+                        lab_Mr=lab['Mr'], lab_feh=lab['feh'], lab_agewt=lab['agewt'],
+                        setup_lnprior=res[5])
+    print("ps1 done")
+
+
+class _FakeLOS(object):
+    """Stand-in for dust.Bayestar (dust.py:184-299): `query(coord)` returns
+    `(av_dist, av_mean, av_err)` of a sightline."""
+
+    def __init__(self, dist, mean, err):
+        self.args = (dist, mean, err)
+
+    def query(self, coord):
+        return self.args
+
+
+def gen_dust():
+    """`dust_lnprior` (reference pdf.py:752-840) with the Bayestar object replaced by a
+    table (the module-level `bayestar` global is what the reference queries), for the
+    two call shapes of `lnpost` ((Nsel,) and (Nmc, Nsel)) and a sightline without
+    coverage."""
+    rng = np.random.RandomState(17)
+    dist = np.concatenate([[0.063], 10. ** np.linspace(-1., 1.8, 40)])
+    mean = np.cumsum(rng.uniform(0., 0.12, dist.size))
+    err = 0.05 + 0.1 * rng.uniform(size=dist.size)
+    d1 = 10. ** rng.uniform(-1.5, 2., 200)
+    a1 = rng.uniform(0., 4., 200)
+    d2 = 10. ** rng.uniform(-1.5, 2., (7, 50))
+    a2 = rng.uniform(0., 4., (7, 50))
+    P.bayestar = _FakeLOS(dist, mean, err)
+    o1 = P.dust_lnprior(d1, (120., 10.), a1)
+    o2 = P.dust_lnprior(d2, (120., 10.), a2)
+    o3 = P.dust_lnprior(d1, (120., 10.), a1, offset=0.1, scale=0.9, smooth=1.5, scatter=0.1)
+    bad = mean.copy()
+    bad[5] = np.nan
+    P.bayestar = _FakeLOS(dist, bad, err)
+    o4 = P.dust_lnprior(d1, (120., 10.), a1)
+    np.savez_compressed(os.path.join(OUT, "dust.npz"), dist=dist, mean=mean, err=err,
+                        d1=d1, a1=a1, d2=d2, a2=a2, o1=o1, o2=o2, o3=o3, o4=o4)
+    print("dust done")
+
+
+def gen_psd():
+    """`lnpost` on a crafted set of precision matrices whose inverse is NOT positive
+    definite, so that the repair loop of reference fitting.py:1039-1065 runs on purpose:
+    a non-positive variance in each position, pairs of them, all three, and matrices
+    with positive diagonal that are indefinite; several need more than one doubling of
+    the regulariser.  Well-conditioned matrices in between must come out untouched."""
+    rng = np.random.RandomState(77)
+    n = 160
+    A = rng.normal(size=(n, 3, 3))
+    icov = np.einsum('nij,nkj->nik', A, A) + 0.3 * np.eye(3)        # SPD
+    scale = 10. ** rng.uniform(-1.5, 0.5, n)
+    # per-model units: (s, Av, Rv) precisions of very different magnitude
+    u = np.stack([1. / scale, np.full(n, 8.), np.full(n, 5.)], axis=1)
+    icov = icov * u[:, :, None] * u[:, None, :]
+    kinds = np.zeros(n, dtype=int)
+
+    def flip(k, signs, boost=1.):
+        """make the covariance (= inverse) have eigen-directions of negative variance"""
+        w, V = np.linalg.eigh(icov[k])
+        w = w * np.asarray(signs) * boost
+        icov[k] = (V * w) @ V.T
+
+    spec = [(1, (-1, 1, 1)), (2, (1, -1, 1)), (3, (1, 1, -1)), (4, (-1, -1, 1)),
+            (5, (-1, 1, -1)), (6, (1, -1, -1)), (7, (-1, -1, -1))]
+    for j in range(0, 105):
+        kind, signs = spec[j % 7]
+        flip(j, signs, boost=10. ** rng.uniform(-2., 2.))
+        kinds[j] = kind
+    # positive diagonal of the covariance but indefinite: strong off-diagonals
+    for j in range(105, 125):
+        d = np.sqrt(np.diag(icov[j]))
+        c = np.diag(np.diag(icov[j]))
+        c[0, 1] = c[1, 0] = 1.4 * d[0] * d[1] * rng.choice([-1, 1])
+        c[1, 2] = c[2, 1] = 0.2 * d[1] * d[2]
+        icov[j] = c
+        kinds[j] = 8
+    # diag entries of the precision exactly zero / negative
+    icov[125, 0, 0] = 0.
+    icov[126, 1, 1] = -icov[126, 1, 1]
+    icov[127, 2, 2] = 0.
+    kinds[125:128] = 9
+    icov = 0.5 * (icov + np.transpose(icov, (0, 2, 1)))
+    av = rng.uniform(0.2, 3., n)
+    rv = rng.uniform(2., 5., n)
+    lnl = rng.uniform(-3., 0., n)          # all inside both cuts
+    chi2 = rng.uniform(3., 9., n)
+    lnprior = rng.uniform(-0.5, 0.5, n)
+    labels = np.zeros(n, dtype=[('feh', 'f8')])
+    labels['feh'] = rng.uniform(-1., 0.3, n)
+    res = (lnl.copy(), 8, chi2.copy(), scale.copy(), av.copy(), rv.copy(), icov.copy())
+    out = F.lnpost(res, parallax=None, parallax_err=None, coord=(50., 20.), Nmc_prior=30,
+                   lnprior=lnprior.copy(), lngalprior=galprior, lndustprior=None,
+                   dlabels=labels, rstate=np.random.RandomState(123), apply_av_prior=False)
+    sel, cov, lnp, dist_mc, a_mc, r_mc, lnp_mc = out
+    with np.errstate(all="ignore"):
+        bad0 = ~np.all(np.linalg.eigvals(U._inverse3(icov.copy())) > 0, axis=1)
+    np.savez_compressed(os.path.join(OUT, "psd.npz"), icov=icov, scale=scale, av=av, rv=rv,
+                        lnl=lnl, chi2=chi2, lnprior=lnprior, feh=labels['feh'], kinds=kinds,
+                        not_psd_before=bad0, sel=sel, cov=cov, lnp=lnp, dist_mc=dist_mc,
+                        a_mc=a_mc, r_mc=r_mc, lnp_mc=lnp_mc)
+    print("psd done: %d of %d matrices needed repair, %d kept by lnpost"
+          % (bad0.sum(), n, len(sel)))
+
+
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
                              "cluster"]
+    if "ps1" in which:
+        gen_ps1()
+    if "dust" in which:
+        gen_dust()
+    if "psd" in which:
+        gen_psd()
     if "cluster" in which:
         gen_cluster()
     if "orion" in which:
