@@ -353,7 +353,10 @@ def test_device_psd_repair_on_crafted_records():
     models, _, _ = synth.make_grid(n, 6, seed=1)          # only to own an engine
     eng = fitting._Engine(fitting.DeviceGrid(models), max_batch=2)
     dev = eng.grid.device
-    coord, par, perr = np.array([[50., 20.]]), np.array([1.2]), np.array([0.1])
+    # parallax S/N < 4: the reference's first cut then rests on lnlike alone (pdf.py:209),
+    # so all 160 crafted models are first-cut records on both sides; the Monte Carlo stage
+    # still applies the parallax likelihood
+    coord, par, perr = np.array([[50., 20.]]), np.array([1.2]), np.array([0.5])
     Nmc, Ndraws = 25, 80
     # records of one object: every model selected by the first cut, ascending order
     vals = np.empty((_lib.NVALS, n))
