@@ -87,6 +87,10 @@ SIGNATURES = {
     "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
+    "brutus_post_batch_numpy": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
+                                          _vp, _i32, _vp, _vp, _sz, _vp]),
+    "brutus_debug_mt_stream": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "brutus_debug_rng": (C.c_int, [_u64, _u64, _i64, _vp, _vp, _vp]),
     "brutus_debug_galprior": (C.c_int, [C.POINTER(PostParams), _i32, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),

@@ -52,6 +52,7 @@
 #include "fit_kernels.hpp"
 #include "fit2_kernels.hpp"
 #include "cluster_kernels.hpp"
+#include "mt_kernels.hpp"
 #include "post_kernels.hpp"
 
 namespace {
@@ -950,12 +951,17 @@ struct PostWs {
     // k_post_mc: work counter and staged normals
     unsigned int *mc_counter;
     double2 *mc_stage;
+    // numpy-stream mode (mt_kernels.hpp)
+    uint32_t *mt_states;      // (nstar, MT_STATE_WORDS)
+    int64_t *mt_nnorm, *mt_zoff;   // (nstar,)
+    int32_t *mt_seg;          // (nstar + 1,)
+    double *mt_uni;           // (nstar, 2 * ndraws)
     size_t bytes;
 };
 
 constexpr int MC_SLOTS = 1024;     // persistent workgroups (= staging slots) of k_post_mc
 
-PostWs carve_post(char *base, int nstar, int64_t cap, int nmc) {
+PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
     PostWs w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -990,9 +996,21 @@ PostWs carve_post(char *base, int nstar, int64_t cap, int nmc) {
     w.sort_tmp = take(w.sort_tmp_bytes);
     w.mc_counter = (unsigned int *)take(256);
     w.mc_stage = (double2 *)take(sizeof(double2) * (size_t)MC_SLOTS * mc_npair_max(nmc) * TILE);
+    w.mt_states = (uint32_t *)take(sizeof(uint32_t) * (size_t)nstar * MT_STATE_WORDS);
+    w.mt_nnorm = (int64_t *)take(8 * (size_t)nstar);
+    w.mt_zoff = (int64_t *)take(8 * (size_t)nstar);
+    w.mt_seg = (int32_t *)take(4 * ((size_t)nstar + 1));
+    w.mt_uni = (double *)take(8 * (size_t)nstar * 2 * (size_t)(ndraws > 0 ? ndraws : 1));
     w.bytes = off;
     return w;
 }
+
+struct MtArgs {            // numpy-stream mode of post_batch_impl
+    int nstream;           // 1: one stream serves all objects in order; nstar: one per object
+    uint32_t *h_states;    // (nstream, MT_STATE_WORDS) in / out
+    double *d_zbuf;        // normals of one group of objects
+    size_t zbuf_doubles;
+};
 
 // Keep the nsel_max best records of object s, best first (fitting.py:1029-1036).
 int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep, hipStream_t st) {
@@ -1056,16 +1074,20 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
 
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc) {
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1 || nmc < 1) return 0;
-    return carve_post(nullptr, nstar, capacity, nmc).bytes;
+    // sized for up to 4096 draws per object in the numpy-stream mode
+    return carve_post(nullptr, nstar, capacity, nmc, 4096).bytes;
 }
 
-int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+}  // extern "C"
+
+namespace {
+int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                       const double *d_sel_vals, const int64_t *d_sel_off, const double *d_lnprior,
                       const double *d_feh, const double *d_loga, const double *d_coords,
                       const double *d_parallax, const double *d_parallax_err,
                       const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
-                      int32_t *h_flags, uint64_t *h_nbase, void *stream) {
+                      int32_t *h_flags, uint64_t *h_nbase, void *stream, const MtArgs *mt) {
     static_assert(sizeof(PostParams) == sizeof(brutus_post_params) + POST_DERIVED * sizeof(double),
                   "post params layout");
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1)
@@ -1077,7 +1099,8 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         return fail(BRUTUS_EINVAL, "nmc, ndraws and wt_thresh must be positive");
     if ((params->has_feh && !d_feh) || (params->has_loga && !d_loga))
         return fail(BRUTUS_EINVAL, "label arrays missing");
-    PostWs w = carve_post((char *)d_workspace, nstar, capacity, params->nmc);
+    if (params->ndraws > 4096) return fail(BRUTUS_EINVAL, "at most 4096 draws per object");
+    PostWs w = carve_post((char *)d_workspace, nstar, capacity, params->nmc, 4096);
     if (w.bytes > workspace_bytes)
         return fail(BRUTUS_ENOMEM, "post workspace too small: need %zu bytes, got %zu", w.bytes,
                     workspace_bytes);
@@ -1117,29 +1140,113 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             }
         if (any) HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * (size_t)nstar, st));
     }
-    tm.begin("k_post_mc");
-    {
-        const int nitem = PCH * nstar;
-        HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
-        hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
-                           capacity, nitem, w.mc_counter, w.mc_stage, d_sel_idx,
+    const dim3 gdraw((pp.ndraws + 63) / 64, nstar);
+    if (!mt) {
+        tm.begin("k_post_mc");
+        {
+            const int nitem = PCH * nstar;
+            HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
+            hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
+                               capacity, 0, nitem, w.mc_counter, (const double *)nullptr,
+                               (const int64_t *)nullptr, w.mc_stage, d_sel_idx, d_sel_vals, d_sel_off,
+                               w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp,
+                               w.part_max, w.part_chi2);
+        }
+        tm.end();
+        tm.begin("k_post_cdf");
+        hipLaunchKernelGGL(k_post_evid_part, g2, blk, 0, st, 0, w.off2, w.nsel, w.flags, w.part_max,
+                           w.part_chi2, w.rp, w.part);
+        hipLaunchKernelGGL(k_post_wt_part, g2, blk, 0, st, 0, w.off2, w.nsel, w.flags, w.part_max,
+                           w.part_chi2, w.part, w.rp, w.part_w);
+        hipLaunchKernelGGL(k_post_cdf, g2, blk, 0, st, 0, w.off2, w.nsel, w.flags, w.part_max,
+                           w.part_chi2, w.part, w.part_w, w.rp, w.cdf, w.star_out);
+        tm.end();
+        tm.begin("k_post_draw");
+        hipLaunchKernelGGL(k_post_draw, gdraw, dim3(64), 0, st, pp, 0, (const double *)nullptr,
+                           (const int64_t *)nullptr, (const double *)nullptr, capacity, d_sel_idx,
                            d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh,
-                           d_loga, w.rp, w.part_max, w.part_chi2);
+                           d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
+        tm.end();
+    } else {
+        // numpy's own stream (mt_kernels.hpp): objects are served in groups whose normals fit
+        // the caller's buffer; a group's stream walk, Monte Carlo integral, cdf and draws run
+        // before the next group overwrites the buffer.
+        std::vector<int64_t> hn(nstar), nnorm(nstar), zoff(nstar);
+        HIP_TRY(hipMemcpyAsync(hn.data(), w.nsel, 8 * (size_t)nstar, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(w.mt_states, mt->h_states,
+                               sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
+                               hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        const int nuni = pp.ndraws * (pp.return_distreds ? 2 : 1);
+        for (int s = 0; s < nstar; ++s) nnorm[s] = 3 * (int64_t)pp.nmc * hn[s];
+        std::vector<int32_t> seg(nstar + 1);
+        for (int s0 = 0; s0 < nstar;) {
+            int s1 = s0;
+            int64_t used = 0;
+            while (s1 < nstar) {
+                const int64_t need = ((nnorm[s1] + 1) & ~(int64_t)1) + 2;      // even, padded
+                if (used + need > (int64_t)mt->zbuf_doubles) break;
+                zoff[s1] = used;
+                used += need;
+                ++s1;
+            }
+            if (s1 == s0)
+                return fail(BRUTUS_ENOMEM, "normal buffer too small: object %d needs %lld doubles, "
+                            "buffer holds %zu", s0, (long long)nnorm[s0] + 3, mt->zbuf_doubles);
+            const int ng = s1 - s0;
+            int nseg;
+            uint32_t *d_states;
+            if (mt->nstream == 1) {
+                nseg = 1;
+                seg[0] = s0;
+                seg[1] = s1;
+                d_states = w.mt_states;
+            } else {
+                nseg = ng;
+                for (int q = 0; q <= ng; ++q) seg[q] = s0 + q;
+                d_states = w.mt_states + (size_t)s0 * MT_STATE_WORDS;
+            }
+            HIP_TRY(hipMemcpyAsync(w.mt_nnorm, nnorm.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(w.mt_seg, seg.data(), 4 * (size_t)(nseg + 1), hipMemcpyHostToDevice, st));
+            tm.begin("k_mt_stream");
+            hipLaunchKernelGGL(k_mt_stream, dim3(nseg), blk, 0, st, nseg, w.mt_seg, d_states, w.mt_nnorm,
+                               w.mt_zoff, mt->d_zbuf, nuni, w.mt_uni);
+            tm.end();
+            tm.begin("k_post_mc");
+            {
+                const int nitem = PCH * ng;
+                HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
+                hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
+                                   capacity, PCH * s0, PCH * s1, w.mc_counter, (const double *)mt->d_zbuf,
+                                   (const int64_t *)w.mt_zoff, w.mc_stage, d_sel_idx, d_sel_vals,
+                                   d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga,
+                                   w.rp, w.part_max, w.part_chi2);
+            }
+            tm.end();
+            const dim3 gg(PCH, ng);
+            tm.begin("k_post_cdf");
+            hipLaunchKernelGGL(k_post_evid_part, gg, blk, 0, st, s0, w.off2, w.nsel, w.flags, w.part_max,
+                               w.part_chi2, w.rp, w.part);
+            hipLaunchKernelGGL(k_post_wt_part, gg, blk, 0, st, s0, w.off2, w.nsel, w.flags, w.part_max,
+                               w.part_chi2, w.part, w.rp, w.part_w);
+            hipLaunchKernelGGL(k_post_cdf, gg, blk, 0, st, s0, w.off2, w.nsel, w.flags, w.part_max,
+                               w.part_chi2, w.part, w.part_w, w.rp, w.cdf, w.star_out);
+            tm.end();
+            tm.begin("k_post_draw");
+            hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, ng), dim3(64), 0, st, pp, s0,
+                               (const double *)mt->d_zbuf, (const int64_t *)w.mt_zoff,
+                               (const double *)w.mt_uni, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+                               w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.cdf,
+                               w.star_out, d_out_idx, d_out_vals);
+            tm.end();
+            HIP_TRY(hipStreamSynchronize(st));     // the host arrays of this group are reused
+            s0 = s1;
+        }
+        HIP_TRY(hipMemcpyAsync(mt->h_states, w.mt_states,
+                               sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
+                               hipMemcpyDeviceToHost, st));
     }
-    tm.end();
-    tm.begin("k_post_cdf");
-    hipLaunchKernelGGL(k_post_evid_part, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max,
-                       w.part_chi2, w.rp, w.part);
-    hipLaunchKernelGGL(k_post_wt_part, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max,
-                       w.part_chi2, w.part, w.rp, w.part_w);
-    hipLaunchKernelGGL(k_post_cdf, g2, blk, 0, st, w.off2, w.nsel, w.flags, w.part_max, w.part_chi2,
-                       w.part, w.part_w, w.rp, w.cdf, w.star_out);
-    tm.end();
-    tm.begin("k_post_draw");
-    hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, nstar), dim3(64), 0, st, pp, nstar,
-                       capacity, d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
-                       w.geom, d_feh, d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
-    tm.end();
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_star_out, w.star_out, 8 * 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(h_flags, w.flags, 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
@@ -1147,6 +1254,83 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         HIP_TRY(hipMemcpyAsync(h_nbase, w.nbase, 8 * ((size_t)nstar + 1), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     tm.collect();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                      const double *d_sel_vals, const int64_t *d_sel_off, const double *d_lnprior,
+                      const double *d_feh, const double *d_loga, const double *d_coords,
+                      const double *d_parallax, const double *d_parallax_err,
+                      const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
+                      int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
+                      int32_t *h_flags, uint64_t *h_nbase, void *stream) {
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+                           d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
+                           d_out_idx, d_out_vals, h_star_out, h_flags, h_nbase, stream, nullptr);
+}
+
+int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                            const double *d_sel_vals, const int64_t *d_sel_off,
+                            const double *d_lnprior, const double *d_feh, const double *d_loga,
+                            const double *d_coords, const double *d_parallax,
+                            const double *d_parallax_err, const brutus_post_params *params,
+                            void *d_workspace, size_t workspace_bytes, int32_t *d_out_idx,
+                            double *d_out_vals, double *h_star_out, int32_t *h_flags,
+                            int nstream, uint32_t *h_states, double *d_zbuf, size_t zbuf_doubles,
+                            void *stream) {
+    if ((nstream != 1 && nstream != nstar) || !h_states || !d_zbuf || zbuf_doubles < 1024)
+        return fail(BRUTUS_EINVAL, "bad numpy-stream arguments");
+    MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles};
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+                           d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
+                           d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
+}
+
+int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states, const int64_t *h_nnorm,
+                           int nuni, double *d_z, double *d_u, void *stream) {
+    // test hook: walk the stream(s) for objects that need h_nnorm[o] normals and nuni
+    // uniforms each; normals of object o at d_z + sum of the (even-rounded + 2) counts before it
+    if (nobj < 1 || (nstream != 1 && nstream != nobj) || !h_states || !h_nnorm || !d_z || !d_u)
+        return fail(BRUTUS_EINVAL, "bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    std::vector<int64_t> zoff(nobj);
+    std::vector<int32_t> seg(nobj + 1);
+    int64_t used = 0;
+    for (int o = 0; o < nobj; ++o) {
+        zoff[o] = used;
+        used += ((h_nnorm[o] + 1) & ~(int64_t)1) + 2;
+    }
+    const int nseg = nstream == 1 ? 1 : nobj;
+    if (nstream == 1) {
+        seg[0] = 0;
+        seg[1] = nobj;
+    } else {
+        for (int q = 0; q <= nobj; ++q) seg[q] = q;
+    }
+    uint32_t *d_states;
+    int64_t *d_nn, *d_zo;
+    int32_t *d_seg;
+    HIP_TRY(hipMalloc(&d_states, sizeof(uint32_t) * (size_t)nstream * MT_STATE_WORDS));
+    HIP_TRY(hipMalloc(&d_nn, 8 * (size_t)nobj));
+    HIP_TRY(hipMalloc(&d_zo, 8 * (size_t)nobj));
+    HIP_TRY(hipMalloc(&d_seg, 4 * ((size_t)nobj + 1)));
+    HIP_TRY(hipMemcpyAsync(d_states, h_states, sizeof(uint32_t) * (size_t)nstream * MT_STATE_WORDS, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_nn, h_nnorm, 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_zo, zoff.data(), 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_seg, seg.data(), 4 * ((size_t)nseg + 1), hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(TILE), 0, st, nseg, d_seg, d_states, d_nn, d_zo, d_z,
+                       nuni, d_u);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(h_states, d_states, sizeof(uint32_t) * (size_t)nstream * MT_STATE_WORDS, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    (void)hipFree(d_states);
+    (void)hipFree(d_nn);
+    (void)hipFree(d_zo);
+    (void)hipFree(d_seg);
     return 0;
 }
 

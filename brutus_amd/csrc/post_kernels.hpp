@@ -423,12 +423,15 @@ struct NormalReader {
     uint64_t seed, p;
     double z0, z1;
     bool have;
-    __device__ __forceinline__ void init(uint64_t seed_) {
+    const double *zs;      // non-null: the object's normals are in memory (k_mt_stream)
+    __device__ __forceinline__ void init(uint64_t seed_, const double *zs_ = nullptr) {
         seed = seed_;
         have = false;
         p = 0;
+        zs = zs_;
     }
     __device__ __forceinline__ double at(uint64_t j) {
+        if (zs) return zs[j];
         const uint64_t q = j >> 1;
         if (!have || q != p) {
             rng_normal_pair(seed, q, z0, z1);
@@ -498,7 +501,8 @@ __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2;
 // integrates, reading three normals per sample.
 //
 __global__ void __launch_bounds__(TILE, 3)
-k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ counter,
+k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
+          const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
           double2 *__restrict__ zs, const int32_t *__restrict__ sel_idx,
           const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
           const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
@@ -513,7 +517,7 @@ k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ coun
     double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_item = atomicAdd(counter, 1u);
+        if (threadIdx.x == 0) s_item = (unsigned int)item_base + atomicAdd(counter, 1u);
         __syncthreads();
         const unsigned int item = s_item;
         if (item >= (unsigned int)nitem) break;
@@ -521,7 +525,10 @@ k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ coun
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
-        const uint64_t nb = nbase[s];
+        // array source (numpy stream reproduced by k_mt_stream): the object's normals are
+        // numbered from 0 in its own slice of zarr
+        const double2 *const zsrc = zarr ? reinterpret_cast<const double2 *>(zarr + zoff[s]) : nullptr;
+        const uint64_t nb = zarr ? 0ull : nbase[s];
         const uint64_t seed = star_seed(pp, s);
         double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
         if (!flags[s]) {
@@ -533,7 +540,14 @@ k_post_mc(PostParams pp, int64_t cap, int nitem, unsigned int *__restrict__ coun
                 // pair q - p_lo goes to row q - p_lo of the slot as one 16-byte store
                 const uint64_t j_lo = nb + (uint64_t)(3 * n * (int64_t)pp.nmc);
                 const uint64_t p_lo = j_lo >> 1;
-                {
+                if (zsrc) {
+                    // copy the record's run of the stream into the lane's staging column
+                    // (the last pair may reach one normal past the object's slice: the
+                    // buffer is padded, the value is never used)
+                    const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
+                    if (live)
+                        for (uint64_t p = p_lo; p <= p_hi; ++p) col[(int64_t)(p - p_lo) * TILE] = zsrc[p];
+                } else {
                     const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
                     uint64_t p = live ? p_lo : p_hi + 1;
                     uint32_t retry = 0;
@@ -627,11 +641,11 @@ __device__ __forceinline__ void post_star_max(const double *__restrict__ part_ma
 }
 
 __global__ void __launch_bounds__(TILE)
-k_post_evid_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+k_post_evid_part(int s0, const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
                  const int32_t *__restrict__ flags, const double *__restrict__ part_max,
                  const double *__restrict__ part_chi2, RecPost rp, double *__restrict__ part_e) {
     __shared__ double sh[TILE];
-    const int s = blockIdx.y, c = blockIdx.x;
+    const int s = s0 + blockIdx.y, c = blockIdx.x;
     if (flags[s]) return;
     int64_t a, b;
     rec_range_n(off2[s], nsel[s], c, a, b);
@@ -681,12 +695,12 @@ __device__ __forceinline__ double post_chunk_scan(const double *__restrict__ lnp
 }
 
 __global__ void __launch_bounds__(TILE)
-k_post_wt_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+k_post_wt_part(int s0, const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
                const int32_t *__restrict__ flags, const double *__restrict__ part_max,
                const double *__restrict__ part_chi2, const double *__restrict__ part_e, RecPost rp,
                double *__restrict__ part_w) {
     __shared__ double sh[TILE];
-    const int s = blockIdx.y, c = blockIdx.x;
+    const int s = s0 + blockIdx.y, c = blockIdx.x;
     if (flags[s]) return;
     int64_t a, b;
     rec_range_n(off2[s], nsel[s], c, a, b);
@@ -698,13 +712,13 @@ k_post_wt_part(const int64_t *__restrict__ off2, const int64_t *__restrict__ nse
 }
 
 __global__ void __launch_bounds__(TILE)
-k_post_cdf(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
+k_post_cdf(int s0, const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
            const int32_t *__restrict__ flags, const double *__restrict__ part_max,
            const double *__restrict__ part_chi2, const double *__restrict__ part_e,
            const double *__restrict__ part_w, RecPost rp, double *__restrict__ cdf,
            double *__restrict__ star_out) {
     __shared__ double sh[TILE];
-    const int s = blockIdx.y, c = blockIdx.x;
+    const int s = s0 + blockIdx.y, c = blockIdx.x;
     if (flags[s]) return;
     int64_t a, b;
     rec_range_n(off2[s], nsel[s], c, a, b);
@@ -725,7 +739,8 @@ k_post_cdf(const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
 // P6: resampling (fitting.py:2037-2057).  One lane per (object, draw).
 constexpr int POST_NOUT = 17;   // scale av rv cov[9] lnprob dist red dred logwt
 __global__ void __launch_bounds__(64)
-k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ sel_idx,
+k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
+            const double *__restrict__ uarr, int64_t cap, const int32_t *__restrict__ sel_idx,
             const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
             const int64_t *__restrict__ off2, const int64_t *__restrict__ nselv,
             const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
@@ -736,9 +751,10 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
-    const int s = blockIdx.y;
+    const int s = sbase + blockIdx.y;
     const int q = blockIdx.x * 64 + threadIdx.x;
     if (q >= pp.ndraws || flags[s]) return;
+    const int nuni = pp.ndraws * (pp.return_distreds ? 2 : 1);
     const int64_t a = off2[s], nsel = nselv[s];
     if (nsel <= 0) return;
     const StarGeom g = geom[s];
@@ -746,7 +762,7 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     const uint64_t seed = star_seed(pp, s);
     // choice(Nsel, p=wt): searchsorted(cdf / cdf[-1], u, side='right')
     const double total = star_out[4 * s + 2];
-    const double u = rng_uniform(seed, ub + (uint64_t)q);
+    const double u = uarr ? uarr[(int64_t)s * nuni + q] : rng_uniform(seed, ub + (uint64_t)q);
     int64_t lo = 0, hi = nsel;
     while (lo < hi) {
         const int64_t mid = (lo + hi) >> 1;
@@ -775,11 +791,12 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
     label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
 #pragma unroll
     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
-    const uint64_t nb = nbase[s];
+    const uint64_t nb = zarr ? 0ull : nbase[s];
+    const double *zo = zarr ? zarr + zoff[s] : nullptr;
     double m = -INFINITY;
     bool inb_;
     NormalReader rd[3];
-    rd[0].init(seed); rd[1].init(seed); rd[2].init(seed);
+    rd[0].init(seed, zo); rd[1].init(seed, zo); rd[2].init(seed, zo);
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
         const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);
@@ -791,7 +808,8 @@ k_post_draw(PostParams pp, int nstar, int64_t cap, const int32_t *__restrict__ s
         z += exp(mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_) - m);
     }
     // wt = softmax(logwts); imc = searchsorted(cumsum(wt) / sum, u2, side='right')
-    const double u2 = rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
+    const double u2 = uarr ? uarr[(int64_t)s * nuni + pp.ndraws + q]
+                           : rng_uniform(seed, ub + (uint64_t)pp.ndraws + (uint64_t)q);
     double run = 0., dist = 0., red = 0., dred = 0., lw = 0.;
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;

@@ -253,9 +253,11 @@ class _Engine(object):
         return sel_idx, sel_vals, sel_off, off, ndim.cpu().numpy(), k1, k2
 
     def post_batch_device(self, sel_idx, sel_vals, sel_off, nstar, statics,
-                          coords, parallax, parallax_err, pp):
+                          coords, parallax, parallax_err, pp, np_states=None):
         """`brutus_post_batch` on device-resident records.  `statics` =
-        (lnprior, feh, loga) device tensors (feh / loga may be None)."""
+        (lnprior, feh, loga) device tensors (feh / loga may be None).
+        `np_states` (uint32 (nstream, 628), advanced in place): draw from numpy's own
+        legacy stream(s) instead (`brutus_post_batch_numpy`)."""
         torch, L, g = self.torch, self.L, self.grid
         cap = sel_idx.numel()
         nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
@@ -270,6 +272,34 @@ class _Engine(object):
         flags = np.zeros(nstar, dtype=np.int32)
         nbase = np.zeros(nstar + 1, dtype=np.uint64)
         lnprior, feh, loga = statics
+        if np_states is not None:
+            assert np_states.dtype == np.uint32 and np_states.flags.c_contiguous
+            while True:
+                zb = getattr(self, "_zbuf", None)
+                if zb is None:
+                    import os
+                    gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", "6"))
+                    zb = self._zbuf = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
+                                                  device=g.device)
+                rc = L.brutus_post_batch_numpy(
+                    nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
+                    lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
+                    loga.data_ptr() if loga is not None else None, t_coords.data_ptr(),
+                    t_par.data_ptr(), t_perr.data_ptr(), pp, self._post_ws.data_ptr(),
+                    self._post_ws.numel(), out_idx.data_ptr(), out_vals.data_ptr(),
+                    star_out.ctypes.data, flags.ctypes.data, int(np_states.shape[0]),
+                    np_states.ctypes.data, zb.data_ptr(), zb.numel(), _stream_ptr(torch))
+                if rc == -2 and b"normal buffer too small" in L.brutus_last_error() \
+                        and zb.numel() * 8 < 96 * 2 ** 30:
+                    # one object alone exceeds the buffer (the states were not touched): grow
+                    n = zb.numel() * 2
+                    self._zbuf = zb = None
+                    torch.cuda.empty_cache()
+                    self._zbuf = torch.empty(n, dtype=torch.float64, device=g.device)
+                    continue
+                _lib.check(rc)
+                break
+            return (out_idx.cpu().numpy(), out_vals.cpu().numpy(), star_out, flags, nbase)
         _lib.check(L.brutus_post_batch(
             nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
             lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
@@ -665,6 +695,8 @@ class BruteForce(object):
         #: device `lnpost` mode: scan batch k+1 on a second stream while `lnpost`
         #: of batch k runs (costs a second workspace)
         self.scan_ahead = True
+        # `lnpost` on the device also for numpy's own random stream (RandomState / None)
+        self.device_numpy_rng = True
 
     # -- device state -------------------------------------------------------
     def _engine(self):
@@ -939,17 +971,32 @@ class BruteForce(object):
                              and rstate_per_object == "philox")
         if philox_per_object:
             rstate_per_object = lambda i: PhiloxRandomState(seed0 + i)
+        # random stream the device `lnpost` can reproduce: the counter-based Philox stream,
+        # or numpy's own legacy MT19937 stream -- one shared `RandomState` / the global
+        # `numpy.random` (the reference's semantics), or `RandomState(seed0 + i)` per object
+        from .rng import numpy_stream
+        np_mode = None
+        if rstate_per_object is None:
+            if seed0 is not None:
+                np_mode = "per_object"
+            elif numpy_stream(rstate) is not None:
+                np_mode = "shared"
         if (self.device_lnpost and lnprior_ext is None and not apply_av_prior
                 and lndustprior is None and wt_thresh is not None and wt_thresh > 0
                 and getattr(lngalprior, "device_params", None) is not None
+                and Ndraws <= 4096
                 and (philox_per_object
                      or (isinstance(rstate, PhiloxRandomState)
-                         and rstate_per_object is None))):
+                         and rstate_per_object is None)
+                     or (np_mode is not None and self.device_numpy_rng))):
+            philox = philox_per_object or isinstance(rstate, PhiloxRandomState)
             for out in self._fit_device_post(
                     eng, params, step, data, data_err, data_mask, parallax,
                     parallax_err, data_coords, lnprior, lngalprior, dlabels,
                     Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim, rvlim,
-                    mem_lim, return_distreds, rstate, seed0 if philox_per_object else None):
+                    mem_lim, return_distreds, rstate,
+                    seed0 if (philox_per_object or (not philox and np_mode == "per_object")) else None,
+                    np_mode=None if philox else np_mode):
                 yield out
             return
         pool = None
@@ -1024,12 +1071,12 @@ class BruteForce(object):
     def _fit_device_post(self, eng, params, step, data, data_err, data_mask,
                          parallax, parallax_err, data_coords, lnprior, lngalprior,
                          dlabels, Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim,
-                         rvlim, mem_lim, return_distreds, rstate, seed0):
+                         rvlim, mem_lim, return_distreds, rstate, seed0, np_mode=None):
         """`_fit` with `lnpost` and the resampling on the device
         (`brutus_post_batch`): built-in priors, Philox random stream.  Yields
         exactly what the host stage yields for the same `rstate` -- one shared
         sequential `PhiloxRandomState`, or (`seed0`) one stream per object."""
-        from .rng import PhiloxRandomState
+        from .rng import PhiloxRandomState, state_to_words, words_to_state
         torch = eng.torch
         dev = eng.grid.device
         names = dlabels.dtype.names if dlabels is not None else ()
@@ -1094,7 +1141,16 @@ class BruteForce(object):
                     pp.avlim[:] = [float(avlim[0]), float(avlim[1])]
                     pp.rvlim[:] = [float(rvlim[0]), float(rvlim[1])]
                     pp.nsel_max = int(mem_lim / Nmc_prior / 4.0e-4)
-                    if seed0 is not None:
+                    np_states = None
+                    if np_mode == "shared":
+                        np_states = state_to_words(rstate.get_state()).reshape(1, -1).copy()
+                    elif np_mode == "per_object":
+                        np_states = np.stack([state_to_words(
+                            np.random.RandomState(seed0 + i).get_state()) for i in range(a, b)])
+                    if np_mode is not None:
+                        pp.per_object, pp.object0, pp.seed = 0, 0, 0
+                        pp.normal_base = pp.uniform_base = 0
+                    elif seed0 is not None:
                         pp.per_object, pp.object0, pp.seed = 1, a, int(seed0) & (2 ** 64 - 1)
                         pp.normal_base = pp.uniform_base = 0
                     else:
@@ -1107,9 +1163,12 @@ class BruteForce(object):
                             setattr(pp, k, val)
                     out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
                         sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
-                        parallax[a:b], parallax_err[a:b], pp)
+                        parallax[a:b], parallax_err[a:b], pp, np_states=np_states)
                     ubase0 = pp.uniform_base
-                    if seed0 is None:      # what the batch consumed from the shared stream
+                    if np_mode == "shared":      # the caller's generator continues from here
+                        rstate.set_state(words_to_state(np_states[0]))
+                    elif np_mode is None and seed0 is None:
+                        # what the batch consumed from the shared stream
                         rstate.n_normal = int(nbase[S])
                         rstate.n_uniform = int(ubase0) + S * K
                     for s in range(S):

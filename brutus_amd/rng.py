@@ -137,3 +137,42 @@ class PhiloxRandomState(object):
         z = self.normal(size=(n, mean.size))
         out = mean + z @ L.T
         return out[0] if size is None else out.reshape(tuple(np.atleast_1d(size)) + (mean.size,))
+
+
+# ---------------------------------------------------------------------------
+# numpy's legacy generator <-> the 628-word state block of brutus_post_batch_numpy
+# ---------------------------------------------------------------------------
+MT_STATE_WORDS = 628
+
+
+def numpy_stream(rstate):
+    """The object whose `get_state` / `set_state` address the legacy MT19937 stream the
+    reference would draw from: a `numpy.random.RandomState`, or the `numpy.random`
+    module itself (`rstate=None`, reference fitting.py:937-944).  None for anything
+    else (other bit generators, user classes)."""
+    if rstate is np.random or isinstance(rstate, np.random.RandomState):
+        try:
+            if rstate.get_state()[0] == 'MT19937':
+                return rstate
+        except Exception:      # pragma: no cover
+            return None
+    return None
+
+
+def state_to_words(state):
+    """`RandomState.get_state()` -> uint32[628]: key[624], pos, has_gauss, cached_gaussian."""
+    name, key, pos, has_gauss, gauss = state[:5]
+    if name != 'MT19937':
+        raise ValueError("not a legacy MT19937 state")
+    w = np.empty(MT_STATE_WORDS, dtype=np.uint32)
+    w[:624] = key
+    w[624] = pos
+    w[625] = has_gauss
+    w[626:628] = np.frombuffer(np.float64(gauss).tobytes(), dtype=np.uint32)
+    return w
+
+
+def words_to_state(w):
+    w = np.ascontiguousarray(w, dtype=np.uint32)
+    gauss = float(np.frombuffer(w[626:628].tobytes(), dtype=np.float64)[0])
+    return ('MT19937', w[:624].copy(), int(w[624]), int(w[625]), gauss)

@@ -181,6 +181,37 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                       double *d_out_vals, double *h_star_out, int32_t *h_flags,
                       uint64_t *h_nbase, void *stream);
 
+/* The same with NUMPY'S OWN random stream (legacy `numpy.random.RandomState`: MT19937,
+ * polar Box-Muller with the cached second deviate, `choice` = searchsorted of
+ * random_sample), i.e. what the reference consumes when `rstate` is a RandomState or
+ * None (fitting.py:937-944, utils.py:892-905, fitting.py:2037-2053).  h_states holds
+ * `nstream` generator states in numpy's representation, 628 words each:
+ * key[624], pos, has_gauss, cached_gaussian (2 words, little endian double) --
+ * `RandomState.get_state()`; they are advanced in place, so `set_state` makes the
+ * caller's generator continue exactly where the reference's would.
+ *   nstream == 1     one stream serves the objects in order (the reference's semantics);
+ *                    a stream is sequential by nature: one workgroup walks it
+ *   nstream == nstar object s has its own stream (per-object seeds: sharded runs)
+ * d_zbuf (zbuf_doubles float64) receives the normals of a group of objects; an object
+ * needs 3 * nmc * Nsel + 3 doubles; BRUTUS_ENOMEM if a single object does not fit. */
+int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                            const double *d_sel_vals, const int64_t *d_sel_off,
+                            const double *d_lnprior, const double *d_feh,
+                            const double *d_loga, const double *d_coords,
+                            const double *d_parallax, const double *d_parallax_err,
+                            const brutus_post_params *params, void *d_workspace,
+                            size_t workspace_bytes, int32_t *d_out_idx,
+                            double *d_out_vals, double *h_star_out, int32_t *h_flags,
+                            int nstream, uint32_t *h_states, double *d_zbuf,
+                            size_t zbuf_doubles, void *stream);
+
+/* Test hook: walk numpy stream(s) for nobj objects needing h_nnorm[o] normals and nuni
+ * uniforms each (normals of object o at d_z + sum over earlier objects of
+ * (h_nnorm rounded up to even) + 2; uniforms at d_u + o * nuni). */
+int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states,
+                           const int64_t *h_nnorm, int nuni, double *d_z, double *d_u,
+                           void *stream);
+
 /* Test hooks for the two building blocks above. */
 int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
                      double *d_uniforms, void *stream);

@@ -1,0 +1,180 @@
+"""GPU: numpy's own random stream on the device (csrc/mt_kernels.hpp).
+
+The reference draws from a legacy `numpy.random.RandomState` (MT19937 + polar
+Box-Muller with a cached deviate + `choice` via random_sample).  These
+tests pin (1) the stream kernel against numpy itself, word for word, including the
+state it hands back, and (2) `BruteForce._fit` with a plain `RandomState` / the global
+`numpy.random` / per-object seeds running `lnpost` on the device: resampled indices
+bit-exact against the reference-generated goldens and against the oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import GOLDEN, galprior, relerr
+
+pytestmark = pytest.mark.gpu
+
+
+def _walk(states, nnorm, nuni):
+    """brutus_debug_mt_stream -> (list of normals per object, uniforms (nobj, nuni))"""
+    import torch
+    from brutus_amd import _lib
+    L = _lib.lib()
+    nobj = len(nnorm)
+    offs = np.concatenate([[0], np.cumsum(((np.asarray(nnorm) + 1) & ~1) + 2)])
+    z = torch.zeros(int(offs[-1]) + 8, dtype=torch.float64, device="cuda")
+    u = torch.zeros((nobj, max(nuni, 1)), dtype=torch.float64, device="cuda")
+    nn = np.ascontiguousarray(nnorm, dtype=np.int64)
+    _lib.check(L.brutus_debug_mt_stream(nobj, states.shape[0], states.ctypes.data, nn.ctypes.data,
+                                        nuni, z.data_ptr(), u.data_ptr(), None))
+    z = z.cpu().numpy()
+    return [z[offs[o]:offs[o] + nnorm[o]] for o in range(nobj)], u.cpu().numpy()[:, :nuni]
+
+
+def test_mt_stream_matches_numpy_word_for_word():
+    from brutus_amd.rng import state_to_words, words_to_state
+    rng = np.random.RandomState(77)
+    for trial in range(6):
+        rs = np.random.RandomState(1000 + trial)
+        # arbitrary position inside a block, odd word offsets, a cached deviate pending
+        rs.randint(0, 2 ** 31, size=int(rng.randint(0, 700)))
+        if trial % 2:
+            rs.normal(size=3)
+        nnorm = [0, 1, 2, 7, 150 * 37, 75 * 1001 + 1, 0, 3 * 50 * 4000][: 3 + trial]
+        nuni = [0, 1, 500, 40, 7, 500][trial]
+        ref = np.random.RandomState()
+        ref.set_state(rs.get_state())
+        want_z, want_u = [], []
+        for n in nnorm:
+            want_z.append(ref.normal(size=n))
+            want_u.append(ref.random_sample(nuni))
+        st = state_to_words(rs.get_state()).reshape(1, -1).copy()
+        got_z, got_u = _walk(st, nnorm, nuni)
+        for o, n in enumerate(nnorm):
+            assert np.array_equal(got_u[o], want_u[o]), (trial, o)
+            if n:
+                err = np.abs(got_z[o] - want_z[o]) / np.abs(want_z[o])
+                # same accept / reject decisions (a wrong one shifts every later deviate);
+                # values agree to the last bit or two (ln is not correctly rounded anywhere)
+                assert err.max() < 1e-15, (trial, o, err.max())
+        # the state handed back continues numpy's own stream
+        back = np.random.RandomState()
+        back.set_state(words_to_state(st[0]))
+        a, b = back.random_sample(9), ref.random_sample(9)
+        assert np.array_equal(a, b), trial
+        za, zb = back.normal(size=5), ref.normal(size=5)
+        assert relerr(zb, za) < 1e-15, trial
+
+
+def test_mt_stream_per_object_streams():
+    from brutus_amd.rng import state_to_words
+    nnorm = [150 * 200, 0, 151, 75 * 333]
+    st = np.stack([state_to_words(np.random.RandomState(500 + i).get_state()) for i in range(4)])
+    got_z, got_u = _walk(st, nnorm, 20)
+    for i, n in enumerate(nnorm):
+        ref = np.random.RandomState(500 + i)
+        z = ref.normal(size=n)
+        u = ref.random_sample(20)
+        assert np.array_equal(got_u[i], u)
+        if n:
+            assert relerr(z, got_z[i]) < 1e-15
+
+
+NAMES = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds dreds "
+         "logwts").split()
+
+
+def _bf(seed=31, nmodel=6000):
+    from brutus_amd import fitting, synth
+    from oracle import brutus_oracle as O
+    models, labels, lmask = synth.make_mist_like_grid(nmodel, 8, seed=seed)
+    st = synth.make_stars(models, 9, seed=seed + 1)
+    st["mask"][1, 2] = False
+    BF = fitting.BruteForce(models, labels, lmask)
+    return BF, models, labels, st, O.static_lnprior(labels, lmask)
+
+
+def _device_path_taken(BF, monkeypatch_calls):
+    return monkeypatch_calls["n"] > 0
+
+
+def test_fit_with_shared_randomstate_on_device_vs_oracle(monkeypatch):
+    """One sequential RandomState over all objects (the reference's semantics), batches of
+    4: device `lnpost` with numpy's stream == oracle with the same RandomState, and the
+    caller's generator ends in the same state."""
+    from brutus_amd import fitting
+    from brutus_amd.galprior import gal_lnprior
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _bf()
+    BF.batch_size = 4
+    calls = {"n": 0}
+    orig = fitting._Engine.post_batch_device
+
+    def spy(self, *a, **k):
+        if k.get("np_states") is not None:
+            calls["n"] += 1
+        return orig(self, *a, **k)
+    monkeypatch.setattr(fitting._Engine, "post_batch_device", spy)
+    rs = np.random.RandomState(2024)
+    rs.normal(size=1)               # a cached deviate is pending when the fit starts
+    ro = np.random.RandomState(2024)
+    ro.normal(size=1)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60,
+                       rstate=rs))
+    assert calls["n"] == 3           # 9 objects in batches of 4: all through the device stage
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60)
+        assert np.array_equal(dev[i][0], ref[0]), i
+        for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
+            assert relerr(a, b) < 1e-8, (i, n, relerr(a, b))
+    assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
+    assert relerr(ro.normal(size=3), rs.normal(size=3)) < 1e-15
+
+
+def test_fit_with_global_numpy_random_on_device():
+    """rstate=None: the reference draws from the global numpy.random (fitting.py:937-944;
+    the notebooks call np.random.seed first)."""
+    from brutus_amd.galprior import gal_lnprior
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _bf(seed=41)
+    np.random.seed(862)
+    dev = list(BF._fit(st["flux"][:3], st["err"][:3], st["mask"][:3], parallax=st["parallax"][:3],
+                       parallax_err=st["parallax_err"][:3], Nmc_prior=15, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"][:3], Ndraws=40))
+    after = np.random.random_sample(4)
+    ro = np.random.RandomState(862)
+    for i in range(3):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=15, Ndraws=40)
+        assert np.array_equal(dev[i][0], ref[0]), i
+        assert relerr(ref[6], dev[i][6]) < 1e-8
+    assert np.array_equal(after, ro.random_sample(4))
+
+
+def test_device_numpy_rng_equals_host_stage_full_size():
+    """750k x 12 (the bench's grid and stars): `_fit` with per-object numpy seeds, device
+    stage vs the host stage of the same package (numpy itself drawing), which the goldens
+    pin to the reference."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    models, labels, lmask = synth.make_mist_like_grid(750000, 12)
+    st = synth.make_stars(models, 3, seed=5)
+    BF = fitting.BruteForce(models, labels, lmask)
+    lnprior = BF._setup(st["flux"], st["err"], st["mask"], None, data_coords=st["coords"],
+                        lngalprior=gal_lnprior)[5]
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=50,
+              lnprior=lnprior, lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=250,
+              seed0=4242)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    BF.device_numpy_rng = False
+    host = list(BF._fit(st["flux"], st["err"], st["mask"], **kw))
+    for i in range(3):
+        assert np.array_equal(dev[i][0], host[i][0]), i
+        for n, a, b in zip(NAMES[1:], host[i][1:], dev[i][1:]):
+            assert relerr(a, b) < 1e-6, (i, n, relerr(a, b))
