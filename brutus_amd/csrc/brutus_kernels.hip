@@ -1210,7 +1210,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_seg, seg.data(), 4 * (size_t)(nseg + 1), hipMemcpyHostToDevice, st));
             tm.begin("k_mt_stream");
-            hipLaunchKernelGGL(k_mt_stream, dim3(nseg), blk, 0, st, nseg, w.mt_seg, d_states, w.mt_nnorm,
+            hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(MT_NT), 0, st, nseg, w.mt_seg, d_states, w.mt_nnorm,
                                w.mt_zoff, mt->d_zbuf, nuni, w.mt_uni);
             tm.end();
             tm.begin("k_post_mc");
@@ -1322,7 +1322,7 @@ int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states, const int6
     HIP_TRY(hipMemcpyAsync(d_nn, h_nnorm, 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_zo, zoff.data(), 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_seg, seg.data(), 4 * ((size_t)nseg + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(TILE), 0, st, nseg, d_seg, d_states, d_nn, d_zo, d_z,
+    hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(MT_NT), 0, st, nseg, d_seg, d_states, d_nn, d_zo, d_z,
                        nuni, d_u);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_states, d_states, sizeof(uint32_t) * (size_t)nstream * MT_STATE_WORDS, hipMemcpyDeviceToHost, st));
