@@ -670,6 +670,257 @@ int fit_path(int64_t nmodel) {
     return env_int("BRUTUS_FIT_PATH", 2) == 1 ? 1 : 2;
 }
 
+
+// ---- numpy stream on many workgroups (mt_kernels.hpp, second half) ----------------
+std::mutex g_mt_mu;
+std::vector<uint32_t> g_mt_polys;        // 2 x 624 words: strides MT_J and MT_L1 * MT_J
+
+struct MtPlanStream {
+    int o0, o1;            // objects (global indices)
+    int64_t T, K, base, bit_base;
+    int pos0;
+};
+
+// slots to generate for a stream whose objects need `a` accepted pairs in total
+int64_t mt_slots_for(int64_t pairs, int64_t nobj, int nuni) {
+    const double need = 1.2733 * (double)pairs * 1.01 + 50. * sqrt((double)pairs + 1.) + 4096.;
+    int64_t T = (int64_t)need + nobj * (int64_t)(nuni / 2 + 8);
+    return (T + MT_SB - 1) / MT_SB * MT_SB;
+}
+
+// device bytes the parallel walk of the given streams needs besides Z
+size_t mt_scratch_bytes(const std::vector<MtPlanStream> &ps, int nobj_total) {
+    size_t b = 4096;
+    int64_t K = 0, T = 0;
+    for (const auto &p : ps) {
+        K += p.K;
+        T += p.T;
+    }
+    const size_t ns = ps.size();
+    b += 2 * MT_N * 4 + 256;
+    b += (size_t)K * MT_N * 4 + 256;                 // windows
+    b += (size_t)K * sizeof(MtSub) + 256;
+    b += (size_t)(K + ns) * (8 + 8 + 4) * 2 + 1024;  // chain arrays (two levels)
+    b += (size_t)T / 8 + 256;                        // bitmap
+    b += (size_t)T / MT_SB * 4 + 256;                // cnt
+    b += ((size_t)T / MT_SB + ns + 1) * 8 + 256;     // pre
+    b += ns * 128 + 4096;                            // per-stream arrays
+    b += (size_t)nobj_total * sizeof(MtObj) + 256;
+    return b;
+}
+
+// Walk the streams of one group with many workgroups.  Returns 0, a negative error, or 1
+// if the generated slots did not suffice / the shape is not supported (caller then uses
+// the sequential k_mt_stream; nothing has been modified).
+int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states,
+                     const std::vector<int> &pos0, const std::vector<int64_t> &nnorm,
+                     const int32_t *d_seg, const int64_t *d_nnorm, const int64_t *d_zoff, double *d_Z,
+                     int nuni, double *d_U, char *scratch, size_t scratch_bytes, int nobj_total,
+                     hipStream_t st, Timer &tm) {
+    if (nuni & 1) return 1;                      // slot grid needs an even number of uniforms
+    std::vector<uint32_t> polys;
+    {
+        std::lock_guard<std::mutex> lk(g_mt_mu);
+        polys = g_mt_polys;
+    }
+    if (polys.size() != 2 * MT_N) return 1;
+    std::vector<MtPlanStream> ps(nstream);
+    int64_t Ktot = 0, Ttot = 0;
+    for (int g = 0; g < nstream; ++g) {
+        MtPlanStream &p = ps[g];
+        p.o0 = seg[g];
+        p.o1 = seg[g + 1];
+        p.pos0 = pos0[g];
+        int64_t pairs = 0;
+        for (int o = p.o0; o < p.o1; ++o) pairs += (nnorm[o] + 1) / 2;
+        p.T = mt_slots_for(pairs, p.o1 - p.o0, nuni);
+        p.K = (p.pos0 + 4 * p.T + MT_J - 1) / MT_J;
+        if (p.K < 1) p.K = 1;
+        p.base = Ktot;
+        p.bit_base = Ttot;
+        Ktot += p.K;
+        Ttot += p.T;
+    }
+    if (mt_scratch_bytes(ps, nobj_total) > scratch_bytes) return 1;
+    // ---- carve ---------------------------------------------------------------------
+    size_t off = 0;
+    auto take = [&](size_t n) {
+        char *q = scratch + off;
+        off += (n + 255) & ~(size_t)255;
+        return q;
+    };
+    uint32_t *d_polys = (uint32_t *)take(2 * MT_N * 4);
+    uint32_t *d_win = (uint32_t *)take((size_t)Ktot * MT_N * 4);
+    MtSub *d_subs = (MtSub *)take((size_t)Ktot * sizeof(MtSub));
+    unsigned long long *d_bits = (unsigned long long *)take((size_t)Ttot / 8);
+    const int64_t nsb = Ttot / MT_SB;
+    uint32_t *d_cnt = (uint32_t *)take((size_t)nsb * 4);
+    int64_t *d_pre = (int64_t *)take((size_t)(nsb + nstream + 1) * 8);
+    int64_t *d_base = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_bitbase = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_sblo = (int64_t *)take(8 * ((size_t)nstream + 1));
+    int64_t *d_tslots = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_endslot = (int64_t *)take(8 * (size_t)nstream);
+    int32_t *d_endhasg = (int32_t *)take(4 * (size_t)nstream);
+    int32_t *d_endnew = (int32_t *)take(4 * (size_t)nstream);
+    double *d_endgauss = (double *)take(8 * (size_t)nstream);
+    int64_t *d_widx = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_skip = (int64_t *)take(8 * (size_t)nstream);
+    int32_t *d_fail = (int32_t *)take(256);
+    MtObj *d_objs = (MtObj *)take((size_t)nobj_total * sizeof(MtObj));
+    // chains
+    std::vector<int64_t> c1s, c1d, c2s, c2d;
+    std::vector<int32_t> c1n, c2n;
+    std::vector<MtSub> subs(Ktot);
+    std::vector<int64_t> hbase(nstream), hbit(nstream), hsblo(nstream + 1), hT(nstream);
+    for (int g = 0; g < nstream; ++g) {
+        const MtPlanStream &p = ps[g];
+        hbase[g] = p.base;
+        hbit[g] = p.bit_base;
+        hsblo[g] = p.bit_base / MT_SB;
+        hT[g] = p.T;
+        if (p.K > 1) {
+            c1s.push_back(p.base);
+            c1d.push_back(p.base + MT_L1);
+            c1n.push_back((int32_t)((p.K - 1) / MT_L1));
+        }
+        for (int64_t m = 0; m < p.K; m += MT_L1) {
+            const int64_t cnt = std::min<int64_t>(MT_L1 - 1, p.K - m - 1);
+            if (cnt > 0) {
+                c2s.push_back(p.base + m);
+                c2d.push_back(p.base + m + 1);
+                c2n.push_back((int32_t)cnt);
+            }
+        }
+        for (int64_t k = 0; k < p.K; ++k) {
+            MtSub &sb = subs[p.base + k];
+            auto qk = [&](int64_t kk) -> int64_t {
+                if (kk <= 0) return 0;
+                int64_t q = (kk * MT_J - p.pos0 + 3) / 4;
+                q = (q + 63) / 64 * 64;
+                return q;
+            };
+            sb.q0 = std::min(qk(k), p.T);
+            sb.q1 = std::min(qk(k + 1), p.T);
+            if (k == p.K - 1) sb.q1 = p.T;
+            sb.bit0 = p.bit_base + sb.q0;
+            sb.stream = g;
+            sb.skip = (int32_t)(p.pos0 + 4 * sb.q0 - k * MT_J);
+        }
+    }
+    hsblo[nstream] = Ttot / MT_SB;
+    auto upv = [&](void *d, const void *h, size_t n) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st); };
+    const size_t n1 = c1s.size(), n2 = c2s.size();
+    int64_t *d_c1s = (int64_t *)take(8 * (n1 + 1)), *d_c1d = (int64_t *)take(8 * (n1 + 1));
+    int32_t *d_c1n = (int32_t *)take(4 * (n1 + 1));
+    int64_t *d_c2s = (int64_t *)take(8 * (n2 + 1)), *d_c2d = (int64_t *)take(8 * (n2 + 1));
+    int32_t *d_c2n = (int32_t *)take(4 * (n2 + 1));
+    if (off > scratch_bytes) return 1;
+    HIP_TRY(upv(d_polys, polys.data(), 2 * MT_N * 4));
+    HIP_TRY(upv(d_subs, subs.data(), sizeof(MtSub) * (size_t)Ktot));
+    HIP_TRY(upv(d_base, hbase.data(), 8 * (size_t)nstream));
+    HIP_TRY(upv(d_bitbase, hbit.data(), 8 * (size_t)nstream));
+    HIP_TRY(upv(d_sblo, hsblo.data(), 8 * ((size_t)nstream + 1)));
+    HIP_TRY(upv(d_tslots, hT.data(), 8 * (size_t)nstream));
+    if (n1) {
+        HIP_TRY(upv(d_c1s, c1s.data(), 8 * n1));
+        HIP_TRY(upv(d_c1d, c1d.data(), 8 * n1));
+        HIP_TRY(upv(d_c1n, c1n.data(), 4 * n1));
+    }
+    if (n2) {
+        HIP_TRY(upv(d_c2s, c2s.data(), 8 * n2));
+        HIP_TRY(upv(d_c2d, c2d.data(), 8 * n2));
+        HIP_TRY(upv(d_c2n, c2n.data(), 4 * n2));
+    }
+    HIP_TRY(hipMemsetAsync(d_fail, 0, 4, st));
+    // ---- sub-stream windows by jump-ahead ------------------------------------------------
+    tm.begin("k_mt_jump");
+    hipLaunchKernelGGL(k_mt_keys, dim3(nstream), dim3(256), 0, st, nstream, d_states, d_base, d_win);
+    const size_t jlds = (size_t)MT_JX * 4 + 19968 * 2;
+    static bool attr_set = false;
+    if (!attr_set) {
+        HIP_TRY(hipFuncSetAttribute((const void *)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jlds));
+        attr_set = true;
+    }
+    if (n1)
+        hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)n1), dim3(MT_NT), jlds, st, d_polys + MT_N, d_win,
+                           d_c1s, d_c1d, (int64_t)MT_L1, d_c1n);
+    if (n2)
+        hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)n2), dim3(MT_NT), jlds, st, d_polys, d_win, d_c2s,
+                           d_c2d, (int64_t)1, d_c2n);
+    tm.end();
+    // ---- pass 1, prefix, boundaries ----------------------------------------------------------
+    tm.begin("k_mt_bits");
+    hipLaunchKernelGGL(k_mt_bits, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs, d_win, d_bits);
+    tm.end();
+    tm.begin("k_mt_resolve");
+    hipLaunchKernelGGL(k_mt_sbcount, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, st, nsb, d_bits, d_cnt);
+    hipLaunchKernelGGL(k_mt_sbscan, dim3(nstream), dim3(1024), 0, st, d_sblo, d_cnt, d_pre);
+    hipLaunchKernelGGL(k_mt_resolve, dim3(nstream), dim3(64), 0, st, d_seg, d_nnorm, nuni, d_states,
+                       d_bitbase, d_sblo, d_tslots, d_bits, d_pre, d_zoff, d_Z, d_objs, d_endslot,
+                       d_endhasg, d_endnew, d_fail);
+    tm.end();
+    int32_t hfail = 0;
+    std::vector<int64_t> hend(nstream);
+    std::vector<int32_t> hhasg(nstream);
+    HIP_TRY(hipMemcpyAsync(&hfail, d_fail, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(hend.data(), d_endslot, 8 * (size_t)nstream, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    if (hfail) return 1;        // not enough slots generated (the resolve wrote only scratch and
+                                // possibly a cached deviate the sequential walk rewrites)
+    // ---- pass 2 -----------------------------------------------------------------------------
+    tm.begin("k_mt_emit");
+    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs, d_win, d_bits,
+                       d_bitbase, d_sblo, d_pre, d_seg, d_objs, d_nnorm, d_zoff, d_Z, nuni, d_U,
+                       d_endgauss);
+    tm.end();
+    // ---- states after the last consumed word ---------------------------------------------------
+    std::vector<int64_t> hw(nstream), hs(nstream);
+    for (int g = 0; g < nstream; ++g) {
+        const int64_t e = ps[g].pos0 + 4 * hend[g];
+        int64_t k = e / MT_J;
+        if (k >= ps[g].K) k = ps[g].K - 1;
+        hw[g] = ps[g].base + k;
+        hs[g] = e - k * MT_J;
+    }
+    HIP_TRY(upv(d_widx, hw.data(), 8 * (size_t)nstream));
+    HIP_TRY(upv(d_skip, hs.data(), 8 * (size_t)nstream));
+    hipLaunchKernelGGL(k_mt_advance, dim3(nstream), dim3(MT_PT), 0, st, nstream, d_win, d_widx, d_skip,
+                       d_endhasg, d_endgauss, d_endnew, d_states);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));        // host vectors go out of scope
+    return 0;
+}
+
+
+// Walk the streams of one group: many workgroups per stream when the jump polynomials are
+// loaded and the shape allows it, else one workgroup per stream (k_mt_stream).
+int mt_walk(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states, std::vector<int> &pos0,
+            const std::vector<int64_t> &nnorm, const int32_t *d_seg, const int64_t *d_nnorm,
+            const int64_t *d_zoff, double *d_Z, int nuni, double *d_U, char *scratch,
+            size_t scratch_bytes, int nobj_total, hipStream_t st, Timer &tm) {
+    int rc = 1;
+    if (env_int("BRUTUS_MT_PARALLEL", 1) && scratch)
+        rc = mt_walk_parallel(nstream, seg, d_states, pos0, nnorm, d_seg, d_nnorm, d_zoff, d_Z, nuni,
+                              d_U, scratch, scratch_bytes, nobj_total, st, tm);
+    if (rc < 0) return rc;
+    if (rc == 1) {
+        tm.begin("k_mt_stream");
+        hipLaunchKernelGGL(k_mt_stream, dim3(nstream), dim3(MT_NT), 0, st, nstream, d_seg, d_states,
+                           d_nnorm, d_zoff, d_Z, nuni, d_U);
+        tm.end();
+        HIP_TRY(hipGetLastError());
+    }
+    // where the streams stand now (the next group of a shared stream starts there)
+    std::vector<uint32_t> hp(nstream);
+    for (int g = 0; g < nstream; ++g)
+        HIP_TRY(hipMemcpyAsync(&hp[g], d_states + (size_t)g * MT_STATE_WORDS + MT_N, 4,
+                               hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int g = 0; g < nstream; ++g) pos0[g] = (int)hp[g];
+    return 0;
+}
+
 // Rv pinned by its limits at the value every fit starts from: the (offset, Av)
 // specialisation computes the same thing
 inline bool rv_pinned(const DevParams &p) { return p.rvmin == p.rvmax && p.rv_mean == p.rvmin; }
@@ -1179,20 +1430,29 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         HIP_TRY(hipStreamSynchronize(st));
         const int nuni = pp.ndraws * (pp.return_distreds ? 2 : 1);
         for (int s = 0; s < nstar; ++s) nnorm[s] = 3 * (int64_t)pp.nmc * hn[s];
+        std::vector<int> hpos(mt->nstream);
+        for (int g = 0; g < mt->nstream; ++g) hpos[g] = (int)mt->h_states[(size_t)g * MT_STATE_WORDS + MT_N];
+        // the caller's buffer: the first eighth (at least 64 MB) is scratch of the parallel
+        // stream walk (bitmap, sub-stream windows ...), the rest holds the normals
+        size_t zscratch = (mt->zbuf_doubles * 8 / 8 + 255) & ~(size_t)255;
+        if (zscratch < ((size_t)64 << 20)) zscratch = (size_t)64 << 20;
+        if (zscratch > mt->zbuf_doubles * 8 / 2) zscratch = 0;
+        double *zbase = mt->d_zbuf + zscratch / 8;
+        const size_t zdoubles = mt->zbuf_doubles - zscratch / 8;
         std::vector<int32_t> seg(nstar + 1);
         for (int s0 = 0; s0 < nstar;) {
             int s1 = s0;
             int64_t used = 0;
             while (s1 < nstar) {
                 const int64_t need = ((nnorm[s1] + 1) & ~(int64_t)1) + 2;      // even, padded
-                if (used + need > (int64_t)mt->zbuf_doubles) break;
+                if (used + need > (int64_t)zdoubles) break;
                 zoff[s1] = used;
                 used += need;
                 ++s1;
             }
             if (s1 == s0)
                 return fail(BRUTUS_ENOMEM, "normal buffer too small: object %d needs %lld doubles, "
-                            "buffer holds %zu", s0, (long long)nnorm[s0] + 3, mt->zbuf_doubles);
+                            "buffer holds %zu", s0, (long long)nnorm[s0] + 3, zdoubles);
             const int ng = s1 - s0;
             int nseg;
             uint32_t *d_states;
@@ -1209,16 +1469,21 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             HIP_TRY(hipMemcpyAsync(w.mt_nnorm, nnorm.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_seg, seg.data(), 4 * (size_t)(nseg + 1), hipMemcpyHostToDevice, st));
-            tm.begin("k_mt_stream");
-            hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(MT_NT), 0, st, nseg, w.mt_seg, d_states, w.mt_nnorm,
-                               w.mt_zoff, mt->d_zbuf, nuni, w.mt_uni);
-            tm.end();
+            {
+                std::vector<int32_t> segv(seg.begin(), seg.begin() + nseg + 1);
+                std::vector<int> p0(nseg);
+                for (int q = 0; q < nseg; ++q) p0[q] = hpos[mt->nstream == 1 ? 0 : s0 + q];
+                if (int rc = mt_walk(nseg, segv, d_states, p0, nnorm, w.mt_seg, w.mt_nnorm, w.mt_zoff, zbase,
+                                     nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm))
+                    return rc;
+                for (int q = 0; q < nseg; ++q) hpos[mt->nstream == 1 ? 0 : s0 + q] = p0[q];
+            }
             tm.begin("k_post_mc");
             {
                 const int nitem = PCH * ng;
                 HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
                 hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
-                                   capacity, PCH * s0, PCH * s1, w.mc_counter, (const double *)mt->d_zbuf,
+                                   capacity, PCH * s0, PCH * s1, w.mc_counter, (const double *)zbase,
                                    (const int64_t *)w.mt_zoff, w.mc_stage, d_sel_idx, d_sel_vals,
                                    d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga,
                                    w.rp, w.part_max, w.part_chi2);
@@ -1235,7 +1500,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             tm.end();
             tm.begin("k_post_draw");
             hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, ng), dim3(64), 0, st, pp, s0,
-                               (const double *)mt->d_zbuf, (const int64_t *)w.mt_zoff,
+                               (const double *)zbase, (const int64_t *)w.mt_zoff,
                                (const double *)w.mt_uni, capacity, d_sel_idx, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.cdf,
                                w.star_out, d_out_idx, d_out_vals);
@@ -1290,6 +1555,15 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
 }
 
+int brutus_set_mt_jump(const uint32_t *h_polys, int64_t stride0, int64_t stride1) {
+    if (!h_polys || stride0 != MT_J || stride1 != MT_J * MT_L1)
+        return fail(BRUTUS_EINVAL, "jump polynomials must be for strides %lld and %lld words",
+                    (long long)MT_J, (long long)(MT_J * MT_L1));
+    std::lock_guard<std::mutex> lk(g_mt_mu);
+    g_mt_polys.assign(h_polys, h_polys + 2 * MT_N);
+    return 0;
+}
+
 int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states, const int64_t *h_nnorm,
                            int nuni, double *d_z, double *d_u, void *stream) {
     // test hook: walk the stream(s) for objects that need h_nnorm[o] normals and nuni
@@ -1322,9 +1596,24 @@ int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states, const int6
     HIP_TRY(hipMemcpyAsync(d_nn, h_nnorm, 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_zo, zoff.data(), 8 * (size_t)nobj, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_seg, seg.data(), 4 * ((size_t)nseg + 1), hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_mt_stream, dim3(nseg), dim3(MT_NT), 0, st, nseg, d_seg, d_states, d_nn, d_zo, d_z,
-                       nuni, d_u);
-    HIP_TRY(hipGetLastError());
+    {
+        int64_t tot = 0;
+        for (int o = 0; o < nobj; ++o) tot += h_nnorm[o];
+        const size_t sbytes = ((size_t)256 << 20) + (size_t)tot / 4 + (size_t)nobj * 65536;
+        char *scratch = nullptr;
+        HIP_TRY(hipMalloc(&scratch, sbytes));
+        std::vector<int32_t> segv(seg.begin(), seg.begin() + nseg + 1);
+        std::vector<int> p0(nseg);
+        for (int g = 0; g < nseg; ++g) p0[g] = (int)h_states[(size_t)g * MT_STATE_WORDS + MT_N];
+        std::vector<int64_t> nn(h_nnorm, h_nnorm + nobj);
+        Timer tm(st);
+        int rc = mt_walk(nseg, segv, d_states, p0, nn, d_seg, d_nn, d_zo, d_z, nuni, d_u, scratch, sbytes,
+                         nobj, st, tm);
+        HIP_TRY(hipStreamSynchronize(st));
+        tm.collect();
+        (void)hipFree(scratch);
+        if (rc) return rc;
+    }
     HIP_TRY(hipMemcpyAsync(h_states, d_states, sizeof(uint32_t) * (size_t)nstream * MT_STATE_WORDS, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     (void)hipFree(d_states);

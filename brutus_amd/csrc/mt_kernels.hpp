@@ -226,4 +226,474 @@ k_mt_stream(int nseg, const int32_t *__restrict__ seg_obj0, uint32_t *__restrict
     }
 }
 
+
+// ===========================================================================
+// The same stream walked by MANY workgroups (jump-ahead)
+// ===========================================================================
+// A stream is cut into sub-streams of MT_J words whose start windows come from the
+// jump-ahead polynomials of tools/gen_mt_jump.py (brutus_amd/mt_jump.npz):
+//   window m words ahead:  W'[i] = XOR_{j : g_j = 1} X[1 + j + i],  g = x^(m-1) mod phi.
+// Everything the fit consumes is a multiple of 4 words when the number of uniforms per
+// object is even, so the stream is a grid of 4-word SLOTS from its first unread word: a
+// slot is either one polar candidate or two uniforms.  Which it is depends on where the
+// earlier objects stopped, i.e. on the rejections before it -- but whether a slot WOULD be
+// accepted as a candidate does not.  So:
+//   k_mt_bits     every sub-stream in parallel: 1 bit per slot, "accepted if a candidate"
+//   k_mt_sbcount + k_mt_sbscan   accepted-count prefix per 4096-slot superblock
+//   k_mt_resolve  one workgroup per stream, objects in order: object o starts at slot x_o,
+//                 its a_o-th accepted candidate (a_o pairs needed) ends it at y_o (a search
+//                 in the prefix + bitmap, no random numbers regenerated), its uniforms take
+//                 the next nuni / 2 slots
+//   k_mt_emit     every sub-stream in parallel again: candidates -> normals at their final
+//                 index, uniform slots -> uniforms
+//   k_mt_advance  the generator state after the last consumed word, in numpy's form.
+constexpr int64_t MT_J = 624 * 3360;          // words per sub-stream (mt_jump.npz strides[0])
+constexpr int MT_L1 = 128;                    // sub-streams per first-level jump (strides[1] = 128 J)
+constexpr int MT_SB = 4096;                   // slots per superblock
+constexpr int MT_JX = 34 * 624;                // words of X a jump generates (>= 19937 + 625)
+
+// Chain c: windows[dst0[c] + k * inner] = window `stride` words ahead of its predecessor
+// (the predecessor of k = 0 is windows[src0[c]]), k = 0..counts[c]-1.  One workgroup
+// (1024 threads) per chain.
+__global__ void __launch_bounds__(MT_NT)
+k_mt_jump(const uint32_t *__restrict__ poly, uint32_t *__restrict__ windows,
+          const int64_t *__restrict__ src0, const int64_t *__restrict__ dst0, int64_t inner,
+          const int32_t *__restrict__ counts) {
+    extern __shared__ uint32_t X[];            // MT_JX words, then the set-bit list
+    __shared__ int s_nset;
+    uint16_t *setpos = reinterpret_cast<uint16_t *>(X + MT_JX);
+    const int c = blockIdx.x, t = threadIdx.x;
+    const int count = counts[c];
+    if (count <= 0) return;
+    if (t == 0) s_nset = 0;
+    lds_barrier();
+    // positions of the set bits of g (unordered: XOR commutes)
+    for (int w = t; w < MT_N; w += MT_NT) {
+        uint32_t bits = poly[w];
+        while (bits) {
+            const int b = __ffs((int)bits) - 1;
+            bits &= bits - 1;
+            setpos[atomicAdd(&s_nset, 1)] = (uint16_t)(w * 32 + b);
+        }
+    }
+    for (int k = t; k < MT_N; k += MT_NT) X[k] = windows[src0[c] * MT_N + k];
+    lds_barrier();
+    const int nset = s_nset;
+    for (int k = 0; k < count; ++k) {
+        // X[624 ..] by the recurrence, block by block
+        for (int b = 0; b + MT_N < MT_JX; b += MT_N) mt_next_block(X + b, X + b + MT_N);
+        uint32_t acc = 0;
+        if (t < MT_N)
+            for (int q = 0; q < nset; ++q) acc ^= X[1 + setpos[q] + t];
+        lds_barrier();
+        if (t < MT_N) {
+            X[t] = acc;
+            windows[(dst0[c] + (int64_t)k * inner) * MT_N + t] = acc;
+        }
+        lds_barrier();
+    }
+}
+
+struct MtSub {           // one sub-stream
+    int64_t q0, q1;      // slots [q0, q1) of its stream
+    int64_t bit0;        // index of slot q0's bit in the bitmap (multiple of 64)
+    int32_t stream;      // which stream
+    int32_t skip;        // words of its window before slot q0
+};
+
+constexpr int MT_PT = 256;                    // threads of the parallel walkers
+constexpr int MT_PB = 4;                      // blocks per refill
+constexpr int MT_PW = MT_PB * MT_N + 4 * MT_PT;
+
+// Sequential word source of a sub-stream for the parallel walkers: `ensure(need)` makes
+// `need` (<= 4 * MT_PT) unread words available at wbuf[rp ..].
+struct MtWalk {
+    uint32_t (*blk)[MT_N];
+    uint32_t *wbuf;
+    int *s_nw, *s_rp;
+    __device__ __forceinline__ void init(const uint32_t *__restrict__ window, int skip) {
+        const int t = threadIdx.x;
+        for (int k = t; k < MT_N; k += MT_PT) blk[MT_PB - 1][k] = window[k];
+        lds_barrier();
+        for (int k = t; k < MT_N - skip; k += MT_PT) wbuf[k] = mt_temper(blk[MT_PB - 1][skip + k]);
+        if (t == 0) {
+            *s_nw = MT_N - skip;
+            *s_rp = 0;
+        }
+        lds_barrier();
+    }
+    __device__ __forceinline__ void ensure(int need) {
+        const int t = threadIdx.x;
+        while (*s_nw - *s_rp < need) {
+            const int left = *s_nw - *s_rp, rp = *s_rp;
+            uint32_t keep[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) keep[r] = (t + r * MT_PT < left) ? wbuf[rp + t + r * MT_PT] : 0u;
+            lds_barrier();
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                if (t + r * MT_PT < left) wbuf[t + r * MT_PT] = keep[r];
+            mt_next_block(blk[MT_PB - 1], blk[1]);
+            for (int k = t; k < MT_N; k += MT_PT) blk[0][k] = blk[1][k];
+            lds_barrier();
+            for (int b = 1; b < MT_PB; ++b) mt_next_block(blk[b - 1], blk[b]);
+            for (int k = t; k < MT_PB * MT_N; k += MT_PT) wbuf[left + k] = mt_temper(blk[k / MT_N][k % MT_N]);
+            if (t == 0) {
+                *s_nw = left + MT_PB * MT_N;
+                *s_rp = 0;
+            }
+            lds_barrier();
+        }
+    }
+};
+
+__device__ __forceinline__ double mt_u53(uint32_t a, uint32_t b) {
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
+// pass 1: bit of slot q = "x1^2 + x2^2 of its four words is in (0, 1)"
+__global__ void __launch_bounds__(MT_PT)
+k_mt_bits(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__ windows,
+          unsigned long long *__restrict__ bitmap) {
+#pragma clang fp contract(off)
+    __shared__ uint32_t blk[MT_PB][MT_N];
+    __shared__ uint32_t wbuf[MT_PW];
+    __shared__ int s_nw, s_rp;
+    const int g = blockIdx.x;
+    if (g >= nsub) return;
+    const MtSub sb = subs[g];
+    MtWalk wk{blk, wbuf, &s_nw, &s_rp};
+    wk.init(windows + (int64_t)g * MT_N, sb.skip);
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int64_t q = sb.q0; q < sb.q1; q += MT_PT) {
+        const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
+        wk.ensure(4 * ns);
+        const int rp = s_rp;
+        bool acc = false;
+        if (t < ns) {
+            const uint32_t *w = wbuf + rp + 4 * t;
+            const double x1 = 2.0 * mt_u53(w[0], w[1]) - 1.0, x2 = 2.0 * mt_u53(w[2], w[3]) - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            acc = r2 < 1.0 && r2 != 0.0;
+        }
+        const unsigned long long bal = __ballot(acc);
+        if (lane == 0 && (q - sb.q0) + 64 * wv < sb.q1 - sb.q0)      // words of this sub-stream only
+            bitmap[((sb.bit0 + (q - sb.q0)) >> 6) + wv] = bal;
+        lds_barrier();
+        if (t == 0) s_rp = rp + 4 * ns;
+        lds_barrier();
+    }
+}
+
+// accepted candidates per superblock of MT_SB slots (64 bitmap words)
+__global__ void k_mt_sbcount(int64_t nsb, const unsigned long long *__restrict__ bitmap,
+                             uint32_t *__restrict__ cnt) {
+    const int64_t sbi = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sbi >= nsb) return;
+    int c = __popcll(bitmap[sbi * 64 + (threadIdx.x & 63)]);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off, 64);
+    if ((threadIdx.x & 63) == 0) cnt[sbi] = (uint32_t)c;
+}
+
+// exclusive prefix of cnt over [lo, hi) per stream (one workgroup per stream)
+__global__ void __launch_bounds__(1024)
+k_mt_sbscan(const int64_t *__restrict__ sb_lo, const uint32_t *__restrict__ cnt,
+            int64_t *__restrict__ pre) {
+    __shared__ int64_t ws[16];
+    __shared__ int64_t carry;
+    const int st = blockIdx.x;
+    const int64_t lo = sb_lo[st], hi = sb_lo[st + 1];
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int64_t b = lo; b < hi; b += 1024) {
+        const int64_t i = b + threadIdx.x;
+        const int64_t v = i < hi ? cnt[i] : 0;
+        int64_t inc = v;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int64_t y = __shfl_up(inc, off, 64);
+            if (lane >= off) inc += y;
+        }
+        if (lane == 63) ws[wv] = inc;
+        __syncthreads();
+        int64_t base = carry;
+        for (int q = 0; q < wv; ++q) base += ws[q];
+        if (i < hi) pre[i + st] = base + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) pre[hi + st] = carry;   // one spare entry per stream: the total
+}
+
+struct MtObj {           // per object, written by k_mt_resolve
+    int64_t x, y;        // candidate slots [x, y), uniform slots [y, y + nuni / 2)
+    int64_t px;          // accepted candidates of the stream before slot x
+    int32_t c;           // 1: its first normal is the deviate cached by its predecessor
+    int32_t nxt;         // next object of the stream that draws normals (-1: none)
+};
+
+// One workgroup (64 threads) per stream, its objects in order.
+//   bit_base[st]  bitmap index of the stream's slot 0 (multiple of MT_SB)
+//   sb_lo[st]     first superblock of the stream (pre has one spare entry per stream:
+//                 stream st's superblock b sits at pre[sb_lo[st] + st + b])
+//   tslots[st]    slots that were generated for the stream
+__global__ void __launch_bounds__(64)
+k_mt_resolve(const int32_t *__restrict__ seg_obj0, const int64_t *__restrict__ nnorm, int nuni,
+             const uint32_t *__restrict__ states, const int64_t *__restrict__ bit_base,
+             const int64_t *__restrict__ sb_lo, const int64_t *__restrict__ tslots,
+             const unsigned long long *__restrict__ bitmap, const int64_t *__restrict__ pre,
+             const int64_t *__restrict__ zoff, double *__restrict__ Z, MtObj *__restrict__ objs,
+             int64_t *__restrict__ end_slot, int32_t *__restrict__ end_hasg,
+             int32_t *__restrict__ end_new, int32_t *__restrict__ fail) {
+    const int st = blockIdx.x, lane = threadIdx.x;
+    const uint32_t *stt = states + (int64_t)st * MT_STATE_WORDS;
+    int c = (int)stt[MT_N + 1];
+    const double gauss0 = __hiloint2double((int)stt[MT_N + 3], (int)stt[MT_N + 2]);
+    const unsigned long long *bm = bitmap + (bit_base[st] >> 6);
+    const int64_t *pr = pre + sb_lo[st] + st;
+    const int64_t nsb = sb_lo[st + 1] - sb_lo[st];
+    const int64_t T = tslots[st];
+    // accepted candidates before slot q
+    auto before = [&](int64_t q) -> int64_t {
+        const int64_t b = q >> 12;
+        const int w = (int)((q & (MT_SB - 1)) >> 6), bit = (int)(q & 63);
+        int cnt = 0;
+        if (lane < w) cnt = __popcll(bm[b * 64 + lane]);
+        else if (lane == w && bit) cnt = __popcll(bm[b * 64 + lane] & ((1ull << bit) - 1ull));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        return (b < nsb ? pr[b] : pr[nsb]) + cnt;
+    };
+    int64_t x = 0;
+    int prev_with_normals = -1;
+    bool bad = false, cnew = false;      // cnew: the pending cached deviate was made in this call
+    for (int o = seg_obj0[st]; o < seg_obj0[st + 1]; ++o) {
+        const int64_t n = nnorm[o];
+        MtObj ob;
+        ob.x = x;
+        ob.c = (n > 0) ? c : 0;
+        ob.nxt = -1;
+        if (n > 0) {
+            if (c && lane == 0) {
+                // the deviate cached before this call: from the incoming state for the first
+                // drawing object, else written by k_mt_emit (the predecessor's last pair)
+                if (prev_with_normals < 0) Z[zoff[o]] = gauss0;
+            }
+            if (prev_with_normals >= 0 && lane == 0) objs[prev_with_normals].nxt = o;
+            prev_with_normals = o;
+        }
+        const int64_t a = n > 0 ? (n - c + 1) >> 1 : 0;      // accepted pairs needed
+        const int64_t px = before(x);
+        ob.px = px;
+        int64_t y = x;
+        if (a > 0) {
+            const int64_t target = px + a;                    // the a-th accepted from x
+            // superblock: largest b with pr[b] < target
+            int64_t lo = x >> 12, hi = nsb;                   // pr[lo] <= px < target
+            while (hi - lo > 1) {
+                const int64_t mid = (lo + hi) >> 1;
+                if (pr[mid] < target) lo = mid; else hi = mid;
+            }
+            if (lo >= nsb || pr[nsb] < target) {
+                bad = true;
+                y = T;
+            } else {
+                const int wantin = (int)(target - pr[lo]);    // 1-based rank inside superblock lo
+                const unsigned long long wd = bm[lo * 64 + lane];
+                const int pc = __popcll(wd);
+                int inc = pc;
+#pragma unroll
+                for (int off = 1; off < 64; off <<= 1) {
+                    const int yv = __shfl_up(inc, off, 64);
+                    if (lane >= off) inc += yv;
+                }
+                const bool mine = inc >= wantin && inc - pc < wantin;
+                const unsigned long long who = __ballot(mine);
+                const int wl = __ffsll((long long)who) - 1;
+                int r = wantin - (__shfl(inc, wl, 64) - __shfl(pc, wl, 64));      // rank in the word
+                unsigned long long v = __shfl((long long)wd, wl, 64);
+                int bitpos = 0;
+                for (; r > 1; --r) v &= v - 1;                // drop r - 1 lowest set bits
+                bitpos = __ffsll((long long)v) - 1;
+                y = lo * MT_SB + wl * 64 + bitpos + 1;
+            }
+            if ((n - c) & 1) c = 1; else c = 0;
+            cnew = c == 1;
+        } else if (n > 0) {
+            c = 0;                                            // n == 1 served by the cached deviate
+            cnew = false;
+        }
+        ob.y = y;
+        x = y + nuni / 2;
+        if (x > T) bad = true;
+        if (lane == 0) {
+            // nxt is patched later by a successor; keep the value a successor may already
+            // have written?  (successors run after us in this loop, so plain store is fine)
+            objs[o].x = ob.x;
+            objs[o].y = ob.y;
+            objs[o].px = ob.px;
+            objs[o].c = ob.c;
+            objs[o].nxt = -1;
+        }
+    }
+    if (lane == 0) {
+        end_slot[st] = x;
+        end_hasg[st] = c;
+        end_new[st] = (c && cnew) ? 1 : 0;
+        if (bad) atomicAdd(fail, 1);
+    }
+}
+
+// pass 2: candidates -> normals at their final index, uniform slots -> uniforms
+__global__ void __launch_bounds__(MT_PT)
+k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__ windows,
+          const unsigned long long *__restrict__ bitmap, const int64_t *__restrict__ bit_base,
+          const int64_t *__restrict__ sb_lo, const int64_t *__restrict__ pre,
+          const int32_t *__restrict__ seg_obj0, const MtObj *__restrict__ objs,
+          const int64_t *__restrict__ nnorm, const int64_t *__restrict__ zoff,
+          double *__restrict__ Z, int nuni, double *__restrict__ U, double *__restrict__ end_gauss) {
+#pragma clang fp contract(off)
+    __shared__ uint32_t blk[MT_PB][MT_N];
+    __shared__ uint32_t wbuf[MT_PW];
+    __shared__ int s_nw, s_rp;
+    __shared__ int wcnt[MT_PT / 64];
+    __shared__ int64_t s_bound[2 * BRUTUS_MAX_BATCH + 1];
+    const int g = blockIdx.x;
+    if (g >= nsub) return;
+    const MtSub sb = subs[g];
+    const int st = sb.stream;
+    const int o0 = seg_obj0[st], no = seg_obj0[st + 1] - o0;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    // region boundaries of the stream: [x_0, y_0, x_1, y_1, ..., end]
+    for (int k = t; k < no; k += MT_PT) {
+        s_bound[2 * k] = objs[o0 + k].x;
+        s_bound[2 * k + 1] = objs[o0 + k].y;
+    }
+    if (t == 0) s_bound[2 * no] = no > 0 ? objs[o0 + no - 1].y + nuni / 2 : 0;
+    MtWalk wk{blk, wbuf, &s_nw, &s_rp};
+    wk.init(windows + (int64_t)g * MT_N, sb.skip);
+    if (sb.q0 >= s_bound[2 * no]) return;              // nothing of this sub-stream is consumed
+    // accepted candidates of the stream before slot q0 (q0 is a multiple of 64)
+    int64_t pcount;
+    {
+        const unsigned long long *bm = bitmap + (bit_base[st] >> 6);
+        const int64_t b = sb.q0 >> 12;
+        const int w = (int)((sb.q0 & (MT_SB - 1)) >> 6);
+        int cnt = (t < w) ? __popcll(bm[b * 64 + t]) : 0;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        if (lane == 0) wcnt[wv] = cnt;
+        lds_barrier();
+        pcount = pre[sb_lo[st] + st + b] + wcnt[0];     // w < 64: only wave 0 holds counts
+        lds_barrier();
+    }
+    const int64_t qend = sb.q1 < s_bound[2 * no] ? sb.q1 : s_bound[2 * no];
+    for (int64_t q = sb.q0; q < qend; q += MT_PT) {
+        const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
+        wk.ensure(4 * ns);
+        const int rp = s_rp;
+        const int64_t myq = q + t;
+        bool acc = false, accbit = false;
+        double x1 = 0., x2 = 0., r2 = 1., u1 = 0., u2 = 0.;
+        int reg = -1;
+        if (t < ns) {
+            const uint32_t *w = wbuf + rp + 4 * t;
+            u1 = mt_u53(w[0], w[1]);
+            u2 = mt_u53(w[2], w[3]);
+            x1 = 2.0 * u1 - 1.0;
+            x2 = 2.0 * u2 - 1.0;
+            r2 = x1 * x1 + x2 * x2;
+            accbit = r2 < 1.0 && r2 != 0.0;        // the bitmap's bit: every slot counts in the prefix
+            if (myq < s_bound[2 * no]) {
+                int lo = 0, hi = 2 * no;           // region: largest r with bound[r] <= myq
+                while (hi - lo > 1) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_bound[mid] <= myq) lo = mid; else hi = mid;
+                }
+                reg = lo;
+                acc = accbit && !(reg & 1);
+            }
+        }
+        const unsigned long long bal = __ballot(accbit);
+        if (lane == 0) wcnt[wv] = __popcll(bal);
+        lds_barrier();
+        int bef = __popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
+#pragma unroll
+        for (int w2 = 0; w2 < MT_PT / 64; ++w2) {
+            bef += w2 < wv ? wcnt[w2] : 0;
+            tot += wcnt[w2];
+        }
+        if (reg >= 0) {
+            const int o = o0 + (reg >> 1);
+            if (reg & 1) {
+                const int64_t ui = 2 * (myq - s_bound[reg]);
+                if (ui < nuni) U[(int64_t)o * nuni + ui] = u1;
+                if (ui + 1 < nuni) U[(int64_t)o * nuni + ui + 1] = u2;
+            } else if (acc) {
+                const MtObj ob = objs[o];
+                const int64_t m = (pcount + bef) - ob.px;            // pair index in the object
+                const int64_t j = ob.c + 2 * m, n = nnorm[o];
+                const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
+                double *zo = Z + zoff[o];
+                if (j < n) zo[j] = f * x2;
+                if (j + 1 < n) zo[j + 1] = f * x1;
+                else if (j < n) {                                     // cached for the next call
+                    if (ob.nxt >= 0) Z[zoff[ob.nxt]] = f * x1;
+                    else end_gauss[st] = f * x1;
+                }
+            }
+        }
+        pcount += tot;
+        lds_barrier();
+        if (t == 0) s_rp = rp + 4 * ns;
+        lds_barrier();
+    }
+}
+
+// state of a stream `skip` words into the given window (pos = 0), in numpy's form
+__global__ void __launch_bounds__(MT_PT)
+k_mt_advance(int nstream, const uint32_t *__restrict__ windows, const int64_t *__restrict__ widx,
+             const int64_t *__restrict__ skip, const int32_t *__restrict__ hasg,
+             const double *__restrict__ gauss_new, const int32_t *__restrict__ gauss_is_new,
+             uint32_t *__restrict__ states) {
+    __shared__ uint32_t a[MT_N], b[MT_N];
+    const int st = blockIdx.x, t = threadIdx.x;
+    if (st >= nstream) return;
+    uint32_t *cur = a, *nxt = b;
+    for (int k = t; k < MT_N; k += MT_PT) cur[k] = windows[widx[st] * MT_N + k];
+    lds_barrier();
+    int64_t r = skip[st];
+    while (r >= MT_N) {
+        mt_next_block(cur, nxt);
+        uint32_t *sw = cur;
+        cur = nxt;
+        nxt = sw;
+        r -= MT_N;
+    }
+    uint32_t *stt = states + (int64_t)st * MT_STATE_WORDS;
+    double g = __hiloint2double((int)stt[MT_N + 3], (int)stt[MT_N + 2]);
+    lds_barrier();
+    for (int k = t; k < MT_N; k += MT_PT) stt[k] = cur[k];
+    if (t == 0) {
+        stt[MT_N] = (uint32_t)r;
+        stt[MT_N + 1] = (uint32_t)hasg[st];
+        if (gauss_is_new[st]) g = gauss_new[st];
+        stt[MT_N + 2] = (uint32_t)__double2loint(g);
+        stt[MT_N + 3] = (uint32_t)__double2hiint(g);
+    }
+}
+
+
+// windows[base[st]] = key block of stream st
+__global__ void k_mt_keys(int nstream, const uint32_t *__restrict__ states,
+                          const int64_t *__restrict__ base, uint32_t *__restrict__ windows) {
+    const int st = blockIdx.x;
+    if (st >= nstream) return;
+    for (int k = threadIdx.x; k < MT_N; k += blockDim.x)
+        windows[base[st] * MT_N + k] = states[(int64_t)st * MT_STATE_WORDS + k];
+}
+
 }  // namespace

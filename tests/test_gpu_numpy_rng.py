@@ -178,3 +178,48 @@ def test_device_numpy_rng_equals_host_stage_full_size():
         assert np.array_equal(dev[i][0], host[i][0]), i
         for n, a, b in zip(NAMES[1:], host[i][1:], dev[i][1:]):
             assert relerr(a, b) < 1e-6, (i, n, relerr(a, b))
+
+
+def test_mt_stream_many_workgroups_equals_one_and_numpy():
+    """Streams long enough to be cut into many sub-streams (jump-ahead, two levels: more
+    than 128 sub-streams of 2 096 640 words): the parallel walk must give the same normals,
+    uniforms and final state as the single-workgroup walk, and as numpy."""
+    from brutus_amd.rng import state_to_words, words_to_state
+    cases = [([21000000, 0, 3, 5000001, 150], 500, 1), ([75 * 140000, 75 * 90001], 500, 2),
+             ([120000000, 7], 20, 1)]
+    for nnorm, nuni, nstream in cases:
+        outs = {}
+        for par in ("1", "0"):
+            os.environ["BRUTUS_MT_PARALLEL"] = par
+            if nstream == 1:
+                rs = np.random.RandomState(99)
+                rs.randint(0, 2 ** 31, size=101)
+                rs.normal(size=1)
+                st = state_to_words(rs.get_state()).reshape(1, -1).copy()
+            else:
+                st = np.stack([state_to_words(np.random.RandomState(700 + i).get_state())
+                               for i in range(len(nnorm))])
+            z, u = _walk(st, nnorm, nuni)
+            outs[par] = (z, u, st.copy())
+        os.environ.pop("BRUTUS_MT_PARALLEL", None)
+        for o in range(len(nnorm)):
+            assert np.array_equal(outs["1"][0][o], outs["0"][0][o]), (nnorm, o)
+            assert np.array_equal(outs["1"][1][o], outs["0"][1][o]), (nnorm, o)
+        for g in range(nstream if nstream > 1 else 1):
+            a = np.random.RandomState()
+            a.set_state(words_to_state(outs["1"][2][g]))
+            b = np.random.RandomState()
+            b.set_state(words_to_state(outs["0"][2][g]))
+            assert np.array_equal(a.random_sample(7), b.random_sample(7))
+            assert np.array_equal(a.normal(size=3), b.normal(size=3))
+        # and numpy itself
+        if nstream == 1:
+            ref = np.random.RandomState(99)
+            ref.randint(0, 2 ** 31, size=101)
+            ref.normal(size=1)
+            for o, n in enumerate(nnorm):
+                zr = ref.normal(size=n)
+                ur = ref.random_sample(nuni)
+                assert np.array_equal(outs["1"][1][o], ur), (nnorm, o)
+                if n:
+                    assert relerr(zr, outs["1"][0][o]) < 1e-15
