@@ -63,7 +63,7 @@ def parse():
                     help="host threads / HIP streams per GPU, each with its own "
                          "workspace, taking the steps round-robin (kernels of "
                          "consecutive batches overlap on the device)")
-    ap.add_argument("--e2e-stars", type=int, default=192,
+    ap.add_argument("--e2e-stars", type=int, default=1024,
                     help="stars of the sequential-RandomState end-to-end BruteForce.fit() "
                          "leg reported beside the metric (0 = skip all end-to-end legs); "
                          "rank 0, N=1 only")
@@ -131,12 +131,12 @@ def end_to_end(models, grid, stars, n, kw, with_par):
 
     n_shared = max(n, 1)
     big = synth.make_stars(models, 4096, seed=4242, with_parallax=with_par)
-    res = {"value": run(big, n_shared, 64, rstate=np.random.RandomState(862), reps=2),
+    res = {"value": run(big, n_shared, 128, rstate=np.random.RandomState(862), reps=2),
            "unit": "stars/s", "stars": n_shared,
            "note": "BruteForce.fit, one sequential numpy RandomState like the reference "
                    "(Nmc_prior=50, Ndraws=250, HDF5); lnpost on the device, numpy's stream "
                    "reproduced word for word"}
-    n2 = 1024
+    n2 = 2048
     # per-object numpy seeds go through _fit (fit() itself takes one rstate)
     from brutus_amd import h5io
     bf.batch_size = 128

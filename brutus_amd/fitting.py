@@ -279,9 +279,9 @@ class _Engine(object):
                 if zb is None:
                     import os
                     # normals of one group of objects; a 128-object batch of the bench
-                    # workload (1.4e5 kept models x 150 normals each) needs ~22 GB
+                    # workload (1.4e5 kept models x 150 normals each) needs ~22 GB + 1/8 scratch
                     free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
-                    gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(24., max(1., 0.25 * free))))
+                    gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.25 * free))))
                     zb = self._zbuf = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
                                                   device=g.device)
                 rc = L.brutus_post_batch_numpy(
