@@ -91,7 +91,7 @@ SIGNATURES = {
                                           _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                           _vp, _i32, _vp, _vp, _sz, _vp]),
     "brutus_debug_mt_stream": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
-    "brutus_set_mt_jump": (C.c_int, [_vp, _i64, _i64]),
+    "brutus_set_mt_jump": (C.c_int, [_vp, _i32, _i64, _i64]),
     "brutus_debug_rng": (C.c_int, [_u64, _u64, _i64, _vp, _vp, _vp]),
     "brutus_debug_galprior": (C.c_int, [C.POINTER(PostParams), _i32, _vp, _vp, _vp, _vp,
                                         _vp, _vp]),
@@ -132,7 +132,8 @@ def lib():
         import numpy as np
         z = np.load(jp)
         polys = np.ascontiguousarray(z["polys"], dtype=np.uint32)
-        check_rc = L.brutus_set_mt_jump(polys.ctypes.data, int(z["strides"][0]), int(z["strides"][1]))
+        check_rc = L.brutus_set_mt_jump(polys.ctypes.data, int(polys.shape[0]),
+                                        int(z["strides"][0]), int(z["strides"][1]))
         if check_rc != 0:
             raise BrutusError("brutus_amd: mt_jump.npz does not match the library")
     _lib = L

@@ -673,7 +673,7 @@ int fit_path(int64_t nmodel) {
 
 // ---- numpy stream on many workgroups (mt_kernels.hpp, second half) ----------------
 std::mutex g_mt_mu;
-std::vector<uint32_t> g_mt_polys;        // 2 x 624 words: strides MT_J and MT_L1 * MT_J
+std::vector<uint32_t> g_mt_polys;        // (1 + R) x 624 words: strides MT_J, MT_L1 * MT_J * 2^r
 
 struct MtPlanStream {
     int o0, o1;            // objects (global indices)
@@ -697,7 +697,7 @@ size_t mt_scratch_bytes(const std::vector<MtPlanStream> &ps, int nobj_total) {
         T += p.T;
     }
     const size_t ns = ps.size();
-    b += 2 * MT_N * 4 + 256;
+    b += 16 * MT_N * 4 + 256;
     b += (size_t)K * MT_N * 4 + 256;                 // windows
     b += (size_t)K * sizeof(MtSub) + 256;
     b += (size_t)(K + ns) * (8 + 8 + 4) * 2 + 1024;  // chain arrays (two levels)
@@ -723,7 +723,8 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         std::lock_guard<std::mutex> lk(g_mt_mu);
         polys = g_mt_polys;
     }
-    if (polys.size() != 2 * MT_N) return 1;
+    if (polys.size() < 2 * MT_N) return 1;
+    const int nlev = (int)(polys.size() / MT_N) - 1;       // first-level strides 128 J 2^r, r < nlev
     std::vector<MtPlanStream> ps(nstream);
     int64_t Ktot = 0, Ttot = 0;
     for (int g = 0; g < nstream; ++g) {
@@ -749,7 +750,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         off += (n + 255) & ~(size_t)255;
         return q;
     };
-    uint32_t *d_polys = (uint32_t *)take(2 * MT_N * 4);
+    uint32_t *d_polys = (uint32_t *)take(polys.size() * 4);
     uint32_t *d_win = (uint32_t *)take((size_t)Ktot * MT_N * 4);
     MtSub *d_subs = (MtSub *)take((size_t)Ktot * sizeof(MtSub));
     unsigned long long *d_bits = (unsigned long long *)take((size_t)Ttot / 8);
@@ -769,8 +770,9 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     int32_t *d_fail = (int32_t *)take(256);
     MtObj *d_objs = (MtObj *)take((size_t)nobj_total * sizeof(MtObj));
     // chains
-    std::vector<int64_t> c1s, c1d, c2s, c2d;
-    std::vector<int32_t> c1n, c2n;
+    std::vector<int64_t> c2s, c2d;
+    std::vector<int32_t> c2n;
+    std::vector<std::vector<int64_t>> r1s(16), r1d(16);      // chains of first-level round r
     std::vector<MtSub> subs(Ktot);
     std::vector<int64_t> hbase(nstream), hbit(nstream), hsblo(nstream + 1), hT(nstream);
     for (int g = 0; g < nstream; ++g) {
@@ -779,10 +781,17 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         hbit[g] = p.bit_base;
         hsblo[g] = p.bit_base / MT_SB;
         hT[g] = p.T;
-        if (p.K > 1) {
-            c1s.push_back(p.base);
-            c1d.push_back(p.base + MT_L1);
-            c1n.push_back((int32_t)((p.K - 1) / MT_L1));
+        {
+            // first-level windows (every MT_L1-th sub-stream) by a doubling tree: round r makes
+            // windows 2^r .. 2^(r+1) - 1 from windows 0 .. 2^r - 1 with the stride 128 J 2^r
+            const int64_t n1 = (p.K - 1) / MT_L1;          // first-level windows besides window 0
+            for (int r = 0; ((int64_t)1 << r) <= n1; ++r) {
+                if (r >= nlev) return 1;                   // stream longer than the polynomials reach
+                for (int64_t m = 0; m < ((int64_t)1 << r) && m + ((int64_t)1 << r) <= n1; ++m) {
+                    r1s[r].push_back(p.base + MT_L1 * m);
+                    r1d[r].push_back(p.base + MT_L1 * (m + ((int64_t)1 << r)));
+                }
+            }
         }
         for (int64_t m = 0; m < p.K; m += MT_L1) {
             const int64_t cnt = std::min<int64_t>(MT_L1 - 1, p.K - m - 1);
@@ -810,22 +819,33 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     }
     hsblo[nstream] = Ttot / MT_SB;
     auto upv = [&](void *d, const void *h, size_t n) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st); };
-    const size_t n1 = c1s.size(), n2 = c2s.size();
-    int64_t *d_c1s = (int64_t *)take(8 * (n1 + 1)), *d_c1d = (int64_t *)take(8 * (n1 + 1));
-    int32_t *d_c1n = (int32_t *)take(4 * (n1 + 1));
+    const size_t n2 = c2s.size();
+    size_t n1tot = 0;
+    for (int r = 0; r < 16; ++r) n1tot += r1s[r].size();
+    int64_t *d_c1s = (int64_t *)take(8 * (n1tot + 1)), *d_c1d = (int64_t *)take(8 * (n1tot + 1));
+    int32_t *d_c1n = (int32_t *)take(4 * (n1tot + 1));
     int64_t *d_c2s = (int64_t *)take(8 * (n2 + 1)), *d_c2d = (int64_t *)take(8 * (n2 + 1));
     int32_t *d_c2n = (int32_t *)take(4 * (n2 + 1));
     if (off > scratch_bytes) return 1;
-    HIP_TRY(upv(d_polys, polys.data(), 2 * MT_N * 4));
+    HIP_TRY(upv(d_polys, polys.data(), polys.size() * 4));
     HIP_TRY(upv(d_subs, subs.data(), sizeof(MtSub) * (size_t)Ktot));
     HIP_TRY(upv(d_base, hbase.data(), 8 * (size_t)nstream));
     HIP_TRY(upv(d_bitbase, hbit.data(), 8 * (size_t)nstream));
     HIP_TRY(upv(d_sblo, hsblo.data(), 8 * ((size_t)nstream + 1)));
     HIP_TRY(upv(d_tslots, hT.data(), 8 * (size_t)nstream));
-    if (n1) {
-        HIP_TRY(upv(d_c1s, c1s.data(), 8 * n1));
-        HIP_TRY(upv(d_c1d, c1d.data(), 8 * n1));
-        HIP_TRY(upv(d_c1n, c1n.data(), 4 * n1));
+    {
+        std::vector<int64_t> fs, fd;
+        for (int r = 0; r < 16; ++r) {
+            fs.insert(fs.end(), r1s[r].begin(), r1s[r].end());
+            fd.insert(fd.end(), r1d[r].begin(), r1d[r].end());
+        }
+        std::vector<int32_t> ones(n1tot + 1, 1);
+        if (n1tot) {
+            HIP_TRY(upv(d_c1s, fs.data(), 8 * n1tot));
+            HIP_TRY(upv(d_c1d, fd.data(), 8 * n1tot));
+            HIP_TRY(upv(d_c1n, ones.data(), 4 * n1tot));
+            HIP_TRY(hipStreamSynchronize(st));       // fs / fd / ones are locals
+        }
     }
     if (n2) {
         HIP_TRY(upv(d_c2s, c2s.data(), 8 * n2));
@@ -842,9 +862,17 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         HIP_TRY(hipFuncSetAttribute((const void *)k_mt_jump, hipFuncAttributeMaxDynamicSharedMemorySize, (int)jlds));
         attr_set = true;
     }
-    if (n1)
-        hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)n1), dim3(MT_NT), jlds, st, d_polys + MT_N, d_win,
-                           d_c1s, d_c1d, (int64_t)MT_L1, d_c1n);
+    {
+        size_t o1 = 0;
+        for (int r = 0; r < 16; ++r) {
+            const size_t nr = r1s[r].size();
+            if (!nr) continue;
+            hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)nr), dim3(MT_NT), jlds, st,
+                               d_polys + (size_t)(1 + r) * MT_N, d_win, d_c1s + o1, d_c1d + o1,
+                               (int64_t)1, d_c1n + o1);
+            o1 += nr;
+        }
+    }
     if (n2)
         hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)n2), dim3(MT_NT), jlds, st, d_polys, d_win, d_c2s,
                            d_c2d, (int64_t)1, d_c2n);
@@ -1555,12 +1583,12 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
 }
 
-int brutus_set_mt_jump(const uint32_t *h_polys, int64_t stride0, int64_t stride1) {
-    if (!h_polys || stride0 != MT_J || stride1 != MT_J * MT_L1)
-        return fail(BRUTUS_EINVAL, "jump polynomials must be for strides %lld and %lld words",
+int brutus_set_mt_jump(const uint32_t *h_polys, int npoly, int64_t stride0, int64_t stride1) {
+    if (!h_polys || npoly < 2 || npoly > 16 || stride0 != MT_J || stride1 != MT_J * MT_L1)
+        return fail(BRUTUS_EINVAL, "jump polynomials must be for strides %lld, %lld * 2^r words",
                     (long long)MT_J, (long long)(MT_J * MT_L1));
     std::lock_guard<std::mutex> lk(g_mt_mu);
-    g_mt_polys.assign(h_polys, h_polys + 2 * MT_N);
+    g_mt_polys.assign(h_polys, h_polys + (size_t)npoly * MT_N);
     return 0;
 }
 

@@ -248,7 +248,7 @@ k_mt_stream(int nseg, const int32_t *__restrict__ seg_obj0, uint32_t *__restrict
 //                 index, uniform slots -> uniforms
 //   k_mt_advance  the generator state after the last consumed word, in numpy's form.
 constexpr int64_t MT_J = 624 * 3360;          // words per sub-stream (mt_jump.npz strides[0])
-constexpr int MT_L1 = 128;                    // sub-streams per first-level jump (strides[1] = 128 J)
+constexpr int MT_L1 = 16;                     // sub-streams per first-level window (strides[1] = 16 J)
 constexpr int MT_SB = 4096;                   // slots per superblock
 constexpr int MT_JX = 34 * 624;                // words of X a jump generates (>= 19937 + 625)
 
@@ -282,9 +282,25 @@ k_mt_jump(const uint32_t *__restrict__ poly, uint32_t *__restrict__ windows,
     for (int k = 0; k < count; ++k) {
         // X[624 ..] by the recurrence, block by block
         for (int b = 0; b + MT_N < MT_JX; b += MT_N) mt_next_block(X + b, X + b + MT_N);
+        // ~10^4 terms per output word; eight independent chains hide the LDS latency
         uint32_t acc = 0;
-        if (t < MT_N)
-            for (int q = 0; q < nset; ++q) acc ^= X[1 + setpos[q] + t];
+        if (t < MT_N) {
+            uint32_t a0 = 0, a1 = 0, a2 = 0, a3 = 0, a4 = 0, a5 = 0, a6 = 0, a7 = 0;
+            const uint32_t *Xt = X + 1 + t;
+            int q = 0;
+            for (; q + 8 <= nset; q += 8) {
+                a0 ^= Xt[setpos[q]];
+                a1 ^= Xt[setpos[q + 1]];
+                a2 ^= Xt[setpos[q + 2]];
+                a3 ^= Xt[setpos[q + 3]];
+                a4 ^= Xt[setpos[q + 4]];
+                a5 ^= Xt[setpos[q + 5]];
+                a6 ^= Xt[setpos[q + 6]];
+                a7 ^= Xt[setpos[q + 7]];
+            }
+            for (; q < nset; ++q) a0 ^= Xt[setpos[q]];
+            acc = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;
+        }
         lds_barrier();
         if (t < MT_N) {
             X[t] = acc;

@@ -206,10 +206,12 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                             size_t zbuf_doubles, void *stream);
 
 /* Jump-ahead polynomials of MT19937 (brutus_amd/mt_jump.npz, made and checked against
- * numpy by tools/gen_mt_jump.py): h_polys = uint32 (2, 624), x^(stride - 1) mod phi for
- * stride0 = 2 096 640 words and stride1 = 128 * stride0.  With them loaded one stream is
- * walked by many workgroups (sub-streams of stride0 words); without them by one. */
-int brutus_set_mt_jump(const uint32_t *h_polys, int64_t stride0, int64_t stride1);
+ * numpy by tools/gen_mt_jump.py): h_polys = uint32 (npoly, 624), x^(stride - 1) mod phi
+ * for stride0 = 2 096 640 words and 128 * stride0 * 2^r, r = 0 .. npoly - 2.  With them
+ * loaded one stream is walked by many workgroups (sub-streams of stride0 words, their
+ * start windows from a doubling tree of jumps); without them by one. */
+int brutus_set_mt_jump(const uint32_t *h_polys, int npoly, int64_t stride0,
+                       int64_t stride1);
 
 /* Test hook: walk numpy stream(s) for nobj objects needing h_nnorm[o] normals and nuni
  * uniforms each (normals of object o at d_z + sum over earlier objects of

@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--batch", type=int, default=128)
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--top", type=int, default=30)
+    ap.add_argument("--rng", choices=("philox", "numpy"), default="philox",
+                    help="numpy: one sequential numpy RandomState (the reference's semantics)")
+    ap.add_argument("--no-cprofile", action="store_true")
     a = ap.parse_args()
     models, labels, lmask = synth.make_mist_like_grid(750000, 12)
     with_par = a.config == 3
@@ -41,12 +44,15 @@ def main():
                    parallax_err=st["parallax_err"] if with_par else None,
                    data_coords=st["coords"], lngalprior=gal_lnprior,
                    rv_gauss=(3.32, 1e-6) if a.config == 2 else (3.32, 0.18),
-                   rstate=PhiloxRandomState(862), verbose=False)
+                   rstate=(PhiloxRandomState(862) if a.rng == "philox"
+                           else np.random.RandomState(862)), verbose=False)
             return time.perf_counter() - t0
 
     run()
     dt = run()
     print("fit(): %.3f s for %d stars = %.0f stars/s" % (dt, a.stars, a.stars / dt))
+    if a.no_cprofile:
+        return
     pr = cProfile.Profile()
     pr.enable()
     run()

@@ -161,7 +161,9 @@ def main():
     assert phi.bit_length() - 1 == N and (phi & 1)
     print("phi: degree %d, weight %d" % (N, bin(phi).count("1")))
     J = 624 * 3360                      # 2 096 640 words per sub-stream
-    strides = [J, 128 * J]
+    # first-level strides 16 J * 2^r: the first-level windows of a long stream come from a
+    # doubling tree (depth log2 instead of a sequential chain)
+    strides = [J] + [16 * J * 2 ** r for r in range(14)]
     polys = []
     for m in strides:
         g = xpow_mod(m - 1, phi, N)
@@ -172,13 +174,18 @@ def main():
     X = raw_words(key, 60000)                                  # first output = temper(X[624])
     for m in (1, 625, 1000, 50001):
         assert np.array_equal(jump_window(key, xpow_mod(m - 1, phi, N)), X[m:m + 624]), m
-    for m, g in zip(strides, polys):
+    for m, g in zip(strides[:2], polys[:2]):
         a = np.random.RandomState(12345)
         a.bytes(4 * m)                          # consume m words (m is a multiple of 624)
         k2 = a.get_state()
         assert k2[2] == 624
         assert np.array_equal(jump_window(key, g), k2[1]), "jump by %d words disagrees with numpy" % m
         print("jump by %d words == numpy" % m)
+    # the longer strides by composition: two jumps of m == one jump of 2 m
+    for r in range(2, len(strides)):
+        half = jump_window(jump_window(key, polys[r - 1]), polys[r - 1])
+        assert np.array_equal(jump_window(key, polys[r]), half), strides[r]
+        print("jump by %d words == 2 x jump by %d" % (strides[r], strides[r - 1]))
     out = np.zeros((len(polys), 624), dtype=np.uint32)
     for r, g in enumerate(polys):
         by = g.to_bytes(624 * 4, "little")
