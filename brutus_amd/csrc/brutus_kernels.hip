@@ -1284,6 +1284,8 @@ PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
     return w;
 }
 
+thread_local DustCtx g_dust{};
+
 struct MtArgs {            // numpy-stream mode of post_batch_impl
     int nstream;           // 1: one stream serves all objects in order; nstar: one per object
     uint32_t *h_states;    // (nstream, MT_STATE_WORDS) in / out
@@ -1388,8 +1390,11 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
     hipStream_t st = (hipStream_t)stream;
     Timer tm(st);
     const dim3 g2(PCH, nstar), blk(TILE);
+    DustCtx dc = g_dust;                 // one-shot: set by brutus_post_set_dust on this thread
+    g_dust = DustCtx{};
+    if (dc.d_los && (dc.nd < 2 || dc.nd > 4096)) return fail(BRUTUS_EINVAL, "bad dust table");
     hipLaunchKernelGGL(k_post_geom, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, d_coords,
-                       d_parallax, d_parallax_err, w.geom);
+                       d_parallax, d_parallax_err, dc, w.geom);
     tm.begin("k_post_lnp1");
     hipLaunchKernelGGL(k_post_lnp1, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
                        w.geom, d_lnprior, d_feh, d_loga, w.lnp1, w.part);
@@ -1581,6 +1586,12 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
     return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
+}
+
+int brutus_post_set_dust(const double *d_los, const int32_t *d_ok, int nd, double offset,
+                         double scale, double smooth, double scatter) {
+    g_dust = DustCtx{d_los, d_ok, nd, offset, scale, smooth, scatter};
+    return 0;
 }
 
 int brutus_set_mt_jump(const uint32_t *h_polys, int npoly, int64_t stride0, int64_t stride1) {

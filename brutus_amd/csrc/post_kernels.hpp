@@ -119,7 +119,47 @@ struct StarGeom {      // per object: sightline unit vector and parallax
     double cb_cl, cb_sl, sb;     // cos b cos l, cos b sin l, sin b
     double par, par_ivar, par_lnorm;
     int has_par;
+    // line-of-sight dust prior (pdf.py:752-840 with a caller-supplied table): los points
+    // at dist[nd], Av_mean[nd], Av_err[nd] of this object's sightline
+    int dust_on, nd;
+    const double *los;
+    double d_off, d_scale, d_smooth, d_scat2;
 };
+
+struct DustCtx {       // host side of brutus_post_set_dust
+    const double *d_los;     // (nstar, 3, nd)
+    const int32_t *d_ok;     // (nstar,) 0: no coverage on that sightline -> flat prior
+    int nd;
+    double offset, scale, smooth, scatter;
+};
+
+// ln prior of Av at distance `dist` [kpc]: Gaussian around the profile interpolated like
+// numpy.interp (end values outside the table)
+__device__ __forceinline__ double dust_lnp(const StarGeom &g, double dist, double av) {
+    const double *xp = g.los, *fm = g.los + g.nd, *fe = g.los + 2 * g.nd;
+    double m, e;
+    if (!(dist > xp[0])) {
+        m = dist == dist ? fm[0] : dist;
+        e = fe[0];
+    } else if (dist >= xp[g.nd - 1]) {
+        m = fm[g.nd - 1];
+        e = fe[g.nd - 1];
+    } else {
+        int lo = 0, hi = g.nd - 1;                 // xp[lo] <= dist < xp[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (xp[mid] <= dist) lo = mid; else hi = mid;
+        }
+        const double dx = xp[lo + 1] - xp[lo], t = dist - xp[lo];
+        m = (fm[lo + 1] - fm[lo]) / dx * t + fm[lo];
+        e = (fe[lo + 1] - fe[lo]) / dx * t + fe[lo];
+    }
+    const double mean = g.d_scale * m + g.d_off;
+    const double er = g.d_smooth * g.d_scale * e;
+    const double e2 = er * er + g.d_scat2;
+    const double dv = av - mean;
+    return -0.5 * (dv * dv / e2 + log(2. * M_PI * e2));
+}
 
 __device__ __forceinline__ double lse3(double a, double b, double c) {
     double m = a > b ? a : b;
@@ -243,7 +283,9 @@ k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
             double Fc[3], Ac[3];
             label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
             const double scale = sel_vals[2 * cap + r];
-            const double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, 1. / sqrt(scale), Fc, Ac, s_tbl);
+            const double dist = 1. / sqrt(scale);
+            double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, dist, Fc, Ac, s_tbl);
+            if (g.dust_on) v += dust_lnp(g, dist, sel_vals[3 * cap + r]);      // fitting.py:1009-1010
             lnp1[r] = v;
             if (v > m) m = v;
         }
@@ -461,6 +503,7 @@ __device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGe
     lin = gal_prior_lin(pp, g, dist, Fc, Ac, tbl);
     const double dp = par - g.par;                              // pdf.py:166-173
     epar = g.has_par ? -0.5 * (dp * dp * g.par_ivar) : 0.;
+    if (g.dust_on) epar += dust_lnp(g, dist, a_mc);             // fitting.py:1084-1085
     inb = s_mc >= 1e-20 && a_mc >= pp.avlim[0] && a_mc <= pp.avlim[1] &&
           r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
 }
@@ -479,7 +522,7 @@ __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (
     double lin, epar;
     mc_sample_lin(pp, g, z0, z1, z2, s0, a0, r0, L, Fc, Ac, tbl, dist, a_mc, r_mc, inb, lin, epar);
     double v = pp.lnK + fast_log_r(lin);
-    if (g.has_par) v += epar - 0.5 * g.par_lnorm;
+    if (g.has_par || g.dust_on) v += epar - (g.has_par ? 0.5 * g.par_lnorm : 0.);
     if (!inb) v = -BIG;
     return v;
 }
@@ -589,7 +632,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                                       zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)], s0, a0, r0, L, Fc, Ac,
                                       s_tbl, d_, a_, r_, inb, lin, epar);
                         ninb += inb ? 1 : 0;
-                        if (g.has_par) {
+                        if (g.has_par || g.dust_on) {
                             const double dM = epar - M;
                             const double ex = fast_exp_bf(-fabs(dM), s_tbl);
                             const bool up = inb && dM > 0.;
@@ -603,7 +646,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
                     // sample in bounds the reference yields +inf -> not finite -> -BIG
                     double lse = pp.lnK + log(acc);
-                    if (g.has_par) lse += M - 0.5 * g.par_lnorm;
+                    if (g.has_par || g.dust_on) lse += M - (g.has_par ? 0.5 * g.par_lnorm : 0.);
                     double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
                     if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
                     rp.lnp[o] = lnp;
@@ -840,7 +883,7 @@ __global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
 // per-object geometry / parallax constants
 __global__ void k_post_geom(int nstar, const double *__restrict__ coords,
                             const double *__restrict__ par, const double *__restrict__ perr,
-                            StarGeom *__restrict__ geom) {
+                            DustCtx dc, StarGeom *__restrict__ geom) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nstar) return;
     const double l = coords[2 * s] * (M_PI / 180.), b = coords[2 * s + 1] * (M_PI / 180.);
@@ -853,6 +896,13 @@ __global__ void k_post_geom(int nstar, const double *__restrict__ coords,
     g.par = g.has_par ? p : 0.;
     g.par_ivar = g.has_par ? 1. / (pe * pe) : 0.;
     g.par_lnorm = g.has_par ? log(2. * M_PI * pe * pe) : 0.;
+    g.dust_on = (dc.d_los && dc.d_ok[s]) ? 1 : 0;
+    g.nd = dc.nd;
+    g.los = dc.d_los ? dc.d_los + (int64_t)s * 3 * dc.nd : nullptr;
+    g.d_off = dc.offset;
+    g.d_scale = dc.scale;
+    g.d_smooth = dc.smooth;
+    g.d_scat2 = dc.scatter * dc.scatter;
     geom[s] = g;
 }
 
@@ -875,6 +925,7 @@ __global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict_
     g.cb_sl = cos(b) * sin(l);
     g.sb = sin(b);
     g.has_par = 0;
+    g.dust_on = 0;
     double Fc[3], Ac[3];
     label_terms(pp, feh[i], loga[i], Fc, Ac);
     out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac, kExp2Tbl);

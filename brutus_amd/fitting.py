@@ -984,8 +984,18 @@ class BruteForce(object):
                 np_mode = "per_object"
             elif numpy_stream(rstate) is not None:
                 np_mode = "shared"
-        if (self.device_lnpost and lnprior_ext is None and not apply_av_prior
-                and lndustprior is None and wt_thresh is not None and wt_thresh > 0
+        # the built-in line-of-sight dust prior (pdf.dust_lnprior with a caller-supplied
+        # table) is evaluated on the device too; any other dust hook keeps the host stage
+        from . import pdf as _pdf
+        dust_tables = None
+        if apply_av_prior and lndustprior is _pdf.dust_lnprior:
+            try:
+                dust_tables = _pdf.los_tables(dustfile, data_coords)
+            except Exception:
+                dust_tables = None
+        dust_ok = (not apply_av_prior and lndustprior is None) or dust_tables is not None
+        if (self.device_lnpost and lnprior_ext is None and dust_ok
+                and wt_thresh is not None and wt_thresh > 0
                 and getattr(lngalprior, "device_params", None) is not None
                 and Ndraws <= 4096
                 and (philox_per_object
@@ -999,7 +1009,7 @@ class BruteForce(object):
                     Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim, rvlim,
                     mem_lim, return_distreds, rstate,
                     seed0 if (philox_per_object or (not philox and np_mode == "per_object")) else None,
-                    np_mode=None if philox else np_mode):
+                    np_mode=None if philox else np_mode, dust_tables=dust_tables):
                 yield out
             return
         pool = None
@@ -1074,7 +1084,8 @@ class BruteForce(object):
     def _fit_device_post(self, eng, params, step, data, data_err, data_mask,
                          parallax, parallax_err, data_coords, lnprior, lngalprior,
                          dlabels, Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim,
-                         rvlim, mem_lim, return_distreds, rstate, seed0, np_mode=None):
+                         rvlim, mem_lim, return_distreds, rstate, seed0, np_mode=None,
+                         dust_tables=None):
         """`_fit` with `lnpost` and the resampling on the device
         (`brutus_post_batch`): built-in priors, Philox random stream.  Yields
         exactly what the host stage yields for the same `rstate` -- one shared
@@ -1164,6 +1175,12 @@ class BruteForce(object):
                             getattr(pp, k)[:] = list(val)
                         else:
                             setattr(pp, k, val)
+                    if dust_tables is not None:      # one-shot context of the next post call
+                        los, ok = dust_tables
+                        t_los = torch.from_numpy(np.ascontiguousarray(los[a:b])).to(dev)
+                        t_ok = torch.from_numpy(np.ascontiguousarray(ok[a:b])).to(dev)
+                        _lib.check(eng.L.brutus_post_set_dust(t_los.data_ptr(), t_ok.data_ptr(),
+                                                              int(los.shape[2]), 0., 1., 1., 0.2))
                     out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
                         sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
                         parallax[a:b], parallax_err[a:b], pp, np_states=np_states)

@@ -161,6 +161,23 @@ def _los_provider(dustfile):
         "(see brutus_amd.pdf.LOSTable)" % (dustfile,))
 
 
+def los_tables(dustfile, coords):
+    """Line-of-sight profiles of many objects as one array for the device stage:
+    `(los (N, 3, nd) = dist, Av_mean, Av_err; ok (N,) int32)`; raises if the provider
+    returns profiles of different lengths."""
+    q = _los_provider(dustfile)
+    rows, ok = [], []
+    for c in np.asarray(coords, dtype=np.float64):
+        d, m, e = (np.asarray(x, dtype=np.float64) for x in q(c))
+        good = bool(np.all(np.isfinite(m) & np.isfinite(e)))
+        ok.append(1 if good else 0)
+        rows.append(np.stack([d, np.where(np.isfinite(m), m, 0.), np.where(np.isfinite(e), e, 0.)]))
+    nd = {r.shape[1] for r in rows}
+    if len(nd) != 1 or nd.pop() < 2:
+        raise ValueError("line-of-sight profiles must share one distance grid length")
+    return np.stack(rows), np.asarray(ok, dtype=np.int32)
+
+
 def dust_lnprior(dists, coord, avs, dustfile=None, offset=0., scale=1., smooth=1.,
                  scatter=0.2, return_components=False):
     """ln prior of a 3-D dust model: Gaussian in Av around the line-of-sight

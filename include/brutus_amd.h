@@ -205,6 +205,16 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                             int nstream, uint32_t *h_states, double *d_zbuf,
                             size_t zbuf_doubles, void *stream);
 
+/* Line-of-sight dust prior for the NEXT brutus_post_batch / brutus_post_batch_numpy call
+ * of the calling thread (one-shot): the reference's `dust_lnprior` (pdf.py:752-840,
+ * Gaussian in Av around the profile interpolated at the distance) with the profile of every
+ * object's sightline supplied by the caller instead of the Bayestar map:
+ *   d_los (nstar, 3, nd) f64: dist [kpc], Av_mean, Av_err;  d_ok (nstar,) i32: 0 = no
+ *   coverage (flat prior, like the reference).  Applied at the MLE point (fitting.py:1009-
+ *   1010) and to every Monte Carlo sample (fitting.py:1084-1085). */
+int brutus_post_set_dust(const double *d_los, const int32_t *d_ok, int nd,
+                         double offset, double scale, double smooth, double scatter);
+
 /* Jump-ahead polynomials of MT19937 (brutus_amd/mt_jump.npz, made and checked against
  * numpy by tools/gen_mt_jump.py): h_polys = uint32 (npoly, 624), x^(stride - 1) mod phi
  * for stride0 = 2 096 640 words and 128 * stride0 * 2^r, r = 0 .. npoly - 2.  With them

@@ -401,3 +401,50 @@ def test_device_psd_repair_on_crafted_records():
     for a, b in ((ref[9], v[:, 13]), (ref[10], v[:, 14]), (ref[11], v[:, 15]),
                  (ref[12], v[:, 16])):
         assert relerr(a, b) < 1e-8
+
+
+def test_device_lnpost_with_los_dust_prior_vs_oracle():
+    """`fit(dustfile=LOSTable(...))`: the built-in line-of-sight dust prior (reference
+    pdf.py:752-840, host version pinned by tests/golden/dust.npz) evaluated on the device at
+    the MLE point and for every Monte Carlo sample; indices bit-exact against the oracle
+    with the same hook and stream, Philox and numpy streams, one sightline without
+    coverage."""
+    from brutus_amd import fitting
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.pdf import LOSTable, dust_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup()
+    n = len(st["flux"])
+    rng = np.random.RandomState(4)
+    dist = np.concatenate([[0.05], 10. ** np.linspace(-1., 1.5, 30)])
+    mean = np.cumsum(rng.uniform(0., 0.15, size=(n, dist.size)), axis=1)
+    err = 0.05 + 0.1 * rng.uniform(size=(n, dist.size))
+    mean[2, 7] = np.nan                          # no coverage on that sightline: flat prior
+    tab = LOSTable(st["coords"][:, 0], st["coords"][:, 1], dist, mean, err)
+    hook = lambda d, c, a, dustfile=None: dust_lnprior(d, c, a, dustfile=tab)
+    calls = {"n": 0}
+    orig = fitting._Engine.post_batch_device
+
+    def spy(self, *a, **k):
+        calls["n"] += 1
+        return orig(self, *a, **k)
+    fitting._Engine.post_batch_device = spy
+    try:
+        for mk in (lambda: PhiloxRandomState(11), lambda: np.random.RandomState(11)):
+            BF.batch_size = 5
+            rs, ro = mk(), mk()
+            before = calls["n"]
+            dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                               parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                               lngalprior=gal_lnprior, dustfile=tab, data_coords=st["coords"],
+                               Ndraws=60, rstate=rs))
+            assert calls["n"] - before == 2          # the device stage ran (2 batches)
+            for i in range(n):
+                ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                                 labels, st["coords"][i], st["parallax"][i],
+                                 st["parallax_err"][i], ro, gal_lnprior, lndustprior=hook,
+                                 Nmc_prior=20, Ndraws=60)
+                _compare(dev[i], ref, ("dust", i))
+    finally:
+        fitting._Engine.post_batch_device = orig
