@@ -337,6 +337,17 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
 constexpr int FS_TILES_PER_BLOCK = 8;
 constexpr int PERSIST_BLOCKS = 4096;
 
+template <int NB, bool RVF>
+void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, int64_t nmodel_pad,
+                  int nstar, const StarPrep *stars, const DevParams &p, const int32_t *k1,
+                  const int32_t *k2, const int32_t *surv_idx, const int64_t *surv_off,
+                  const int32_t *wbase, const Planes &pl, double *part, float *surv32,
+                  const double *thr_cull) {
+    hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
+                       nmodel_pad, nstar, stars, p, k1, k2, first, surv_idx, surv_off, wbase, pl, part,
+                       surv32, thr_cull);
+}
+
 template <int NB, int KS, int G, bool RVF>
 int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> &ids,
                  const std::vector<int32_t> &kfix, const DevParams &p, Workspace &w, int accept,
@@ -381,7 +392,7 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                        nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
                        w.wbase_sel, w.pl, capacity, d_sel_vals,
-                       path == 2 ? (const float *)w.lnlp32 : (const float *)nullptr);
+                       path == 2 ? (const float *)w.lnlp32 : (const float *)nullptr, w.surv_off);
     tm.end();
     HIP_TRY(hipGetLastError());
     return 0;
@@ -447,9 +458,9 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
-                           nmodel_pad, nstar, w.stars, p, w.k1, w.k2, first, w.surv_idx, w.surv_off,
-                           w.wbase_surv, w.pl, w.part, (float *)nullptr, (const double *)nullptr);
+        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
+                              w.surv_idx, w.surv_off, w.wbase_surv, w.pl, w.part, (float *)nullptr,
+                              (const double *)nullptr);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
@@ -622,9 +633,8 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), blk, 0, st, grid, nmodel,
-                           nmodel_pad, nstar, w.stars, p, w.k1, w.k2, first, w.surv_idx, w.surv_off,
-                           w.wbase_surv, w.pl, w.part, w.lnlp32, w.thr_cull);
+        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
+                              w.surv_idx, w.surv_off, w.wbase_surv, w.pl, w.part, w.lnlp32, w.thr_cull);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
@@ -648,7 +658,8 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
                        w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
     tm.begin("k_sel_classify");
     hipLaunchKernelGGL(k_sel_classify, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.s32, w.lnlp32,
-                       w.lnpr32, w.pl.lnprob, w.thr_sel, w.counts, w.mask, w.surv_idx, w.bandn);
+                       w.lnpr32, w.pl.lnprob, w.surv_off, w.thr_sel, w.counts, w.mask, w.surv_idx,
+                       w.bandn);
     tm.end();
     tm.begin("k_sel_band");      // (the candidate lists in surv_idx are no longer needed)
     hipLaunchKernelGGL((k_sel_band<NB, RVF>), dim3(NCHUNK, nstar), blk, 0, st, grid, nmodel, nmodel_pad,

@@ -19,8 +19,9 @@
 //   k_cmp_count32 + k_offsets + k_cmp_scatter
 //              ordered list of the models with lnl_p~ >= threshold - eps.
 //   k_fflux    (fit_kernels.hpp, second-generation mode) exact cull test in float64, flux
-//              iterations for the survivors, survivor marks (+inf / -inf) into the
-//              lnl_p~ plane.
+//              iterations for the survivors; results staged in candidate-list order
+//              (full-line writes, dense read-back), the survivor's list position left as
+//              a tag in the lnl_p~ plane (surv_tag), -inf for a failed candidate.
 //   k_top (B)  exact maximum of lnprob over the non-survivors that could exceed the
 //              survivors' maximum  ->  EXACT first-cut threshold.
 //   k_sel_classify + k_sel_band
@@ -28,7 +29,7 @@
 //              models inside the band are queued and re-evaluated in float64 with dense
 //              lanes; survivors by their final value.
 //   k_offsets + k_cmp_scatter + k_emit   ordered records, each written once: survivors
-//              from the result planes, the rest derived (K1 sweeps + full MLE).
+//              from the staged results, the rest derived (K1 sweeps + full MLE).
 //
 // float32 never produces an output value or a decision: a lane whose float32 value
 // is NaN or inside the error band is re-evaluated in float64.  `eps` is a per-star
@@ -485,7 +486,7 @@ __device__ __forceinline__ int64_t mword(int s, int ntile, int t, int w) {
 // ---------------------------------------------------------------------------
 // mode 0: nominees = !(lnlp32 < nom[s])                          -> max lnl_p
 // mode 1: nominees = non-survivors with !(lnpr32 < nom[s])       -> max lnprob (mag-phase value)
-//         (survivors carry +inf in the lnl_p~ plane, see k_fflux)
+//         (survivors carry a tag in the lnl_p~ plane, see surv_tag)
 // A (block, star) whose float32 block maximum (part32 column 6 + mode) is below nom[s]
 // and that holds no NaN lane is skipped outright.
 // part[(bx * nstar + s)] = block maximum (-inf if no nominee)
@@ -532,7 +533,7 @@ k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ns
                 bool nm = false;
                 if (live) {
                     nm = !(plane32[(int64_t)s * nmodel + i] < nom[s]);
-                    if (mode == 1 && nm) nm = surv32[(int64_t)s * nmodel + i] != INFINITY;
+                    if (mode == 1 && nm) nm = !surv_is(surv32[(int64_t)s * nmodel + i]);
                 }
                 need[g] = __ballot(nm);
                 any = any || need[g] != 0ull;
@@ -636,8 +637,9 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 // ---------------------------------------------------------------------------
 // k_sel_classify + k_sel_band: the first cut of lnpost as a bit-mask (fitting.py:976-991)
 // ---------------------------------------------------------------------------
-// grid = (NCHUNK, nstar), one star per workgroup.  Survivors (+inf in the lnl_p~ plane)
-// are tested on their final float64 lnprob; the rest on lnprob~ with the margin eps.
+// grid = (NCHUNK, nstar), one star per workgroup.  Survivors (tagged in the lnl_p~ plane)
+// are tested on their final float64 lnprob (staged in candidate order); the rest on
+// lnprob~ with the margin eps.
 // Models inside the band |lnprob~ - thr| <= eps (or NaN) go to the block's region of
 // `bandq` (starts at s * nmodel + first model of the chunk: cannot overflow) and are
 // re-evaluated in float64, with dense lanes, by k_sel_band, which ORs the outcome into
@@ -645,7 +647,8 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 __global__ void __launch_bounds__(TILE)
 k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
                const float *__restrict__ lnlp32, const float *__restrict__ lnpr32,
-               const double *__restrict__ lnprob_pl, const double *__restrict__ thr_sel,
+               const double *__restrict__ lnprob_st, const int64_t *__restrict__ cand_off,
+               const double *__restrict__ thr_sel,
                int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
                int32_t *__restrict__ bandq, int32_t *__restrict__ bandn) {
     __shared__ int qn;
@@ -656,6 +659,7 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
     const double th = thr_sel[s];
     const double e = (double)s32[s].eps;
+    const int64_t cbase = cand_off[s];
     int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
     int n = 0;
     constexpr int U = 4;      // tiles in flight per lane
@@ -675,8 +679,8 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
             const int64_t i = (int64_t)t * TILE + threadIdx.x;
             bool yes = false, bd = false;
             if (i < nmodel) {
-                if (a[u] == INFINITY) {
-                    yes = lnprob_pl[(int64_t)s * nmodel + i] > th;
+                if (surv_is(a[u])) {
+                    yes = lnprob_st[cbase + surv_slot(a[u])] > th;
                 } else {
                     const double v = (double)v32[u];
                     yes = v >= th + e;

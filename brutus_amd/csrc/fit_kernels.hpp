@@ -606,6 +606,19 @@ k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ 
     }
 }
 
+// Second generation (fit2_kernels.hpp): the float32 lnl_p~ plane doubles as the survivor
+// map.  Its genuine entries are negative, -inf or NaN; k_fflux overwrites a candidate's
+// entry with -inf (failed the exact cull test) or with the bit pattern 1 + (position in
+// the star's candidate list), a positive finite word.  The flux-phase results live in
+// candidate-list order ("staging": the Planes arrays indexed by list position), so they
+// are written as full lines and read back densely.
+__device__ __forceinline__ float surv_tag(int64_t slot) { return __int_as_float((int)slot + 1); }
+__device__ __forceinline__ bool surv_is(float x) {
+    const int b = __float_as_int(x);
+    return b > 0 && b < 0x7F800000;
+}
+__device__ __forceinline__ int surv_slot(float x) { return __float_as_int(x) - 1; }
+
 // Map a work item (TILE consecutive entries of one star's compact list) to its star.
 __device__ __forceinline__ int star_of_item(const int32_t *__restrict__ wbase, int nstar, int item) {
     int lo = 0, hi = nstar;   // largest s with wbase[s] <= item
@@ -643,12 +656,13 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
 // workgroups looping over work items.  First launch: rebuild (av, rv) from K1
 // sweeps, two iterations from lnl_old = -1e300; continuation: one iteration from
 // the state planes.  Writes the state/result planes at the survivors' positions
-// and, per work item, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
+// and, per work item and wave, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
 // M = max final lnprob.
 // Second-generation mode (surv32 != nullptr, fit2_kernels.hpp): the list holds the
 // CANDIDATES (lnl_p~ >= threshold - eps); the first launch applies the exact cull test
 // lnl_p > thr_cull[s] (fitting.py:758-759) and marks the outcome in the float32 plane
-// (+inf survivor, -inf not); only survivors iterate, store and enter the statistics.
+// (survivor tag / -inf, see surv_tag); only survivors iterate, store and enter the
+// statistics, and they store at their LIST POSITION q, not at (star, model).
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
@@ -657,7 +671,6 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
         double *__restrict__ part, float *__restrict__ surv32,
         const double *__restrict__ thr_cull) {
-    __shared__ double slot[12];
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
@@ -675,8 +688,9 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         if (live) {
             i = surv_idx[q];
             o = (int64_t)s * pl.nmodel + i;
-            if (surv32 && !first) go = surv32[o] == INFINITY;
+            if (surv32 && !first) go = surv_is(surv32[o]);
         }
+        const int64_t os = surv32 ? q : o;       // where this entry's state / results live
         if (go) {
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
@@ -710,17 +724,17 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 step = 1.0;
                 lnl_old = -BIG;
             } else {
-                av = pl.av[o];
-                rv = pl.rv[o];
-                step = pl.step[o];
-                lnl_old = -0.5 * pl.chi2[o];
+                av = pl.av[os];
+                rv = pl.rv[os];
+                step = pl.step[os];
+                lnl_old = -0.5 * pl.chi2[os];
             }
             Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             if (surv32 && first) {
                 go = cull_stat(sp, m) > thr_cull[s];
-                surv32[o] = go ? INFINITY : -INFINITY;
+                surv32[o] = go ? surv_tag(q - surv_off[s]) : -INFINITY;
             }
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; go && it < niter; ++it) {
@@ -745,14 +759,14 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = lnl_new;
             }
             if (go) {
-                store_mle(pl, o, m);
-                pl.av[o] = av;
-                pl.rv[o] = rv;
-                pl.step[o] = step;
+                store_mle(pl, os, m);
+                pl.av[os] = av;
+                pl.rv[os] = rv;
+                pl.step[os] = step;
                 const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
                 const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
-                pl.lnl[o] = lnl;
-                pl.lnprob[o] = lnprob;
+                pl.lnl[os] = lnl;
+                pl.lnprob[os] = lnprob;
                 M = lnprob;
                 if (lnl_new == lnl_new) {
                     L = lnl_new;
@@ -760,8 +774,17 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 }
             }
         }
-        double *out = part + (int64_t)item * 3;
-        block_max_store3(L, T, M, slot, out);
+        // one partial per wave: no workgroup barrier in the loop, the four waves drift
+        // apart and overlap each other's gather latency
+        L = wave_max(L);
+        T = wave_max(T);
+        M = wave_max(M);
+        if ((threadIdx.x & 63) == 0) {
+            double *out = part + ((int64_t)item * (TILE / 64) + (threadIdx.x >> 6)) * 3;
+            out[0] = L;
+            out[1] = T;
+            out[2] = M;
+        }
     }
 }
 
@@ -774,7 +797,8 @@ __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
     const int s = blockIdx.x;
     if (k2state[s] < 0) return;
     double v[3] = {-INFINITY, -INFINITY, -INFINITY};
-    for (int it = wbase[s] + threadIdx.x; it < wbase[s + 1]; it += blockDim.x)
+    const int per = TILE / 64;       // k_fflux leaves one partial per wave
+    for (int it = wbase[s] * per + threadIdx.x; it < wbase[s + 1] * per; it += blockDim.x)
         for (int q = 0; q < 3; ++q) {
             const double x = part[(int64_t)it * 3 + q];
             v[q] = x > v[q] ? x : v[q];
@@ -817,74 +841,126 @@ __global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
 // Survivors of the cull are read from the result planes; the others are
 // re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
 // full-grid scan write eleven planes.
+// A work item is TILE consecutive entries of one star's list.  The two kinds are
+// interleaved in runs of 10-20 models, so the workgroup first sorts its entries by kind
+// (ballot ranks, a permutation in LDS): whole waves then run ONE of the two branches
+// instead of both.  Records go through LDS back to list order and leave as full
+// 2 KB rows per value.
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
        const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
        const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
-       int64_t capacity, double *__restrict__ sel_vals, const float *__restrict__ surv32) {
+       int64_t capacity, double *__restrict__ sel_vals, const float *__restrict__ surv32,
+       const int64_t *__restrict__ cand_off) {
     __shared__ double s_tbl[64];
+    __shared__ double s_rec[BRUTUS_NVALS][TILE];
+    __shared__ int32_t s_idx[TILE];
+    __shared__ int32_t s_slot[TILE];
+    __shared__ int16_t s_pos[TILE];
+    __shared__ int32_t s_cnt[2][TILE / 64];
     stage_exp_table(s_tbl);
     __syncthreads();
     const int nitem = wbase[nstar];
+    const int t = threadIdx.x, w = t >> 6;
+    const uint64_t below = (1ull << (t & 63)) - 1ull;
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
         const int s = star_of_item(wbase, nstar, item);
         const StarPrep &sp = stars[s];
-        const int64_t q = sel_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
-        if (q >= sel_off[s + 1] || q >= capacity) continue;
-        const int64_t i = sel_idx[q];
-        const int64_t o = (int64_t)s * pl.nmodel + i;
-        double rec[BRUTUS_NVALS];
-        // survivor of the cull: float64 plane (path 1) / mark left by k_fflux (path 2)
-        const bool surv = surv32 ? surv32[o] == INFINITY : pl.lnlp[o] > thr_cull[s];
-        if (surv) {
-            rec[0] = pl.lnl[o];
-            rec[1] = pl.chi2[o];
-            rec[2] = pl.scale[o];
-            rec[3] = pl.av[o];
-            rec[4] = pl.rv[o];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rec[5 + k] = pl.icov[k][o];
-        } else {
-            Coef<NB> c;
-            gather_coef<NB>(grid, nmodel_pad, i, c);
-            double F0[NB];
-            compute_F0_tbl<NB>(c, s_tbl, F0);
-            double av = p.av_mean, rv = p.rv_mean;
-            const int K = k1[s];
-            Mle m;
-            if constexpr (RVF) {
-                double R[NB];
-                coef_R<NB>(c, rv, R);
-                GramR G;
-                gram_init_rf<NB>(c, R, sp, G);
-                double a_, c_;
-                if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
-                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+        const int64_t q0 = sel_off[s] + (int64_t)(item - wbase[s]) * TILE;
+        int64_t lim = sel_off[s + 1] < capacity ? sel_off[s + 1] : capacity;
+        const int n = (int)(lim - q0 < TILE ? lim - q0 : TILE);
+        if (n <= 0) continue;                 // uniform over the workgroup
+        const int64_t sbase = (int64_t)s * pl.nmodel;
+        bool surv = false;
+        if (t < n) {
+            const int32_t i = sel_idx[q0 + t];
+            s_idx[t] = i;
+            // survivor of the cull: float64 plane (path 1) / tag left by k_fflux (path 2)
+            if (surv32) {
+                const float tag = surv32[sbase + i];
+                surv = surv_is(tag);
+                s_slot[t] = surv_slot(tag);
             } else {
-                Gram G;
-                gram_init<NB>(c, sp, G);
-                for (int k = 0; k < K; ++k) {
-                    double a_, b_, c_;
-                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
-                }
-                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                surv = pl.lnlp[sbase + i] > thr_cull[s];
             }
-            rec[0] = final_lnl<RVF>(sp, p, m.chi2, false);
-            rec[1] = m.chi2;
-            rec[2] = m.scale;
-            rec[3] = av;
-            rec[4] = rv;
-            rec[5] = m.i00;
-            rec[6] = m.i01;
-            rec[7] = m.i02;
-            rec[8] = m.i11;
-            rec[9] = m.i12;
-            rec[10] = m.i22;
         }
+        const uint64_t bs = __ballot(surv), bd = __ballot(t < n && !surv);
+        if ((t & 63) == 0) {
+            s_cnt[0][w] = __popcll(bs);
+            s_cnt[1][w] = __popcll(bd);
+        }
+        __syncthreads();
+        int nS = 0, rs = 0, rd = 0;
 #pragma unroll
-        for (int k = 0; k < BRUTUS_NVALS; ++k) sel_vals[(int64_t)k * capacity + q] = rec[k];
+        for (int v = 0; v < TILE / 64; ++v) {
+            if (v < w) {
+                rs += s_cnt[0][v];
+                rd += s_cnt[1][v];
+            }
+            nS += s_cnt[0][v];
+        }
+        if (surv) s_pos[rs + __popcll(bs & below)] = (int16_t)t;
+        else if (t < n) s_pos[nS + rd + __popcll(bd & below)] = (int16_t)t;
+        __syncthreads();
+        if (t < n) {
+            const int mp = s_pos[t];
+            const int64_t i = s_idx[mp];
+            if (t < nS) {
+                const int64_t o = surv32 ? cand_off[s] + s_slot[mp] : sbase + i;
+                s_rec[0][mp] = pl.lnl[o];
+                s_rec[1][mp] = pl.chi2[o];
+                s_rec[2][mp] = pl.scale[o];
+                s_rec[3][mp] = pl.av[o];
+                s_rec[4][mp] = pl.rv[o];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) s_rec[5 + k][mp] = pl.icov[k][o];
+            } else {
+                Coef<NB> c;
+                gather_coef<NB>(grid, nmodel_pad, i, c);
+                double F0[NB];
+                compute_F0_tbl<NB>(c, s_tbl, F0);
+                double av = p.av_mean, rv = p.rv_mean;
+                const int K = k1[s];
+                Mle m;
+                if constexpr (RVF) {
+                    double R[NB];
+                    coef_R<NB>(c, rv, R);
+                    GramR G;
+                    gram_init_rf<NB>(c, R, sp, G);
+                    double a_, c_;
+                    if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
+                    mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+                } else {
+                    Gram G;
+                    gram_init<NB>(c, sp, G);
+                    for (int k = 0; k < K; ++k) {
+                        double a_, b_, c_;
+                        gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                    }
+                    mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                }
+                s_rec[0][mp] = final_lnl<RVF>(sp, p, m.chi2, false);
+                s_rec[1][mp] = m.chi2;
+                s_rec[2][mp] = m.scale;
+                s_rec[3][mp] = av;
+                s_rec[4][mp] = rv;
+                s_rec[5][mp] = m.i00;
+                s_rec[6][mp] = m.i01;
+                s_rec[7][mp] = m.i02;
+                s_rec[8][mp] = m.i11;
+                s_rec[9][mp] = m.i12;
+                s_rec[10][mp] = m.i22;
+            }
+        }
+        __syncthreads();
+        if (t < n) {
+#pragma unroll
+            for (int k = 0; k < BRUTUS_NVALS; ++k) sel_vals[(int64_t)k * capacity + q0 + t] = s_rec[k][t];
+        }
+        // (the next item's writes to s_idx / s_cnt / s_pos / s_rec are each separated from
+        // this item's reads of them by one of the barriers above)
     }
 }
 
