@@ -838,14 +838,16 @@ __global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
 }
 
 // Emit the records of the selected models (ordered lists from k_cmp_scatter).
-// Survivors of the cull are read from the result planes; the others are
+// Survivors of the cull are read from the flux-phase results; the others are
 // re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
 // full-grid scan write eleven planes.
-// A work item is TILE consecutive entries of one star's list.  The two kinds are
-// interleaved in runs of 10-20 models, so the workgroup first sorts its entries by kind
-// (ballot ranks, a permutation in LDS): whole waves then run ONE of the two branches
-// instead of both.  Records go through LDS back to list order and leave as full
-// 2 KB rows per value.
+// A work item is TILE consecutive entries of one star's list and belongs to ONE WAVE.
+// The two kinds are interleaved in runs of 10-20 models, so the wave first sorts its
+// entries by kind (ballot ranks, two position lists in its private LDS) and then runs
+// dense rounds of 64 lanes of one kind each.  No workgroup barrier anywhere: the waves
+// of a CU sit in different phases (index / tag loads, row gathers, float64 MLE, record
+// stores) and cover each other's latency.  A record row is written by 64 lanes with
+// gaps that another round of the same wave fills microseconds later (merged in L2).
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
@@ -854,113 +856,153 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
        const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
        int64_t capacity, double *__restrict__ sel_vals, const float *__restrict__ surv32,
        const int64_t *__restrict__ cand_off) {
+    constexpr int NW = TILE / 64;
     __shared__ double s_tbl[64];
-    __shared__ double s_rec[BRUTUS_NVALS][TILE];
-    __shared__ int32_t s_idx[TILE];
-    __shared__ int32_t s_slot[TILE];
-    __shared__ int16_t s_pos[TILE];
-    __shared__ int32_t s_cnt[2][TILE / 64];
+    __shared__ int32_t s_idx[NW][TILE];
+    __shared__ int32_t s_slot[NW][TILE];
+    __shared__ int16_t s_ps[NW][TILE];      // list positions of the survivors, then ...
+    __shared__ int16_t s_pd[NW][TILE];      // ... of the re-derived entries
     stage_exp_table(s_tbl);
     __syncthreads();
     const int nitem = wbase[nstar];
-    const int t = threadIdx.x, w = t >> 6;
-    const uint64_t below = (1ull << (t & 63)) - 1ull;
-    for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
-        const int s = star_of_item(wbase, nstar, item);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint64_t below = (1ull << lane) - 1ull;
+    // geometry of a work item: star, first list position, live entries (0 past the end)
+    auto geom = [&](int item, int &s, int64_t &q0, int &n) {
+        s = 0;
+        q0 = 0;
+        n = 0;
+        if (item >= nitem) return;
+        s = star_of_item(wbase, nstar, item);
+        q0 = sel_off[s] + (int64_t)(item - wbase[s]) * TILE;
+        const int64_t lim = sel_off[s + 1] < capacity ? sel_off[s + 1] : capacity;
+        n = (int)(lim - q0 < TILE ? lim - q0 : TILE);
+        n = n > 0 ? n : 0;
+    };
+    // the entries' models / their kind words (survivor tag, see surv_tag; path 1: 1 or -0.)
+    auto load_idx = [&](int64_t q0, int n, int32_t (&iv)[NW]) {
+#pragma unroll
+        for (int r = 0; r < NW; ++r) iv[r] = r * 64 + lane < n ? sel_idx[q0 + r * 64 + lane] : 0;
+    };
+    auto load_kind = [&](int s, int n, const int32_t (&iv)[NW], float (&kd)[NW]) {
+        const int64_t sb = (int64_t)s * pl.nmodel;
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            kd[r] = -0.f;
+            if (r * 64 + lane < n) {
+                if (surv32) kd[r] = surv32[sb + iv[r]];
+                else kd[r] = pl.lnlp[sb + iv[r]] > thr_cull[s] ? surv_tag(0) : -0.f;
+            }
+        }
+    };
+    const int stride = gridDim.x * NW;
+    int item = blockIdx.x * NW + w;
+    int s, n, s_n, n_n;
+    int64_t q0, q0_n;
+    int32_t iv[NW], iv_n[NW];
+    float kd[NW], kd_n[NW];
+    geom(item, s, q0, n);
+    load_idx(q0, n, iv);
+    load_kind(s, n, iv, kd);
+    for (; item < nitem; item += stride) {
+        // the next item's models are requested now, its kind words once those have
+        // arrived (after the copy rounds): both latencies run under this item's work
+        geom(item + stride, s_n, q0_n, n_n);
+        load_idx(q0_n, n_n, iv_n);
         const StarPrep &sp = stars[s];
-        const int64_t q0 = sel_off[s] + (int64_t)(item - wbase[s]) * TILE;
-        int64_t lim = sel_off[s + 1] < capacity ? sel_off[s + 1] : capacity;
-        const int n = (int)(lim - q0 < TILE ? lim - q0 : TILE);
-        if (n <= 0) continue;                 // uniform over the workgroup
         const int64_t sbase = (int64_t)s * pl.nmodel;
-        bool surv = false;
-        if (t < n) {
-            const int32_t i = sel_idx[q0 + t];
-            s_idx[t] = i;
-            // survivor of the cull: float64 plane (path 1) / tag left by k_fflux (path 2)
-            if (surv32) {
-                const float tag = surv32[sbase + i];
-                surv = surv_is(tag);
-                s_slot[t] = surv_slot(tag);
-            } else {
-                surv = pl.lnlp[sbase + i] > thr_cull[s];
+        bool sv[NW];
+#pragma unroll
+        for (int r = 0; r < NW; ++r) {
+            const int t = r * 64 + lane;
+            sv[r] = false;
+            if (t < n) {
+                sv[r] = surv_is(kd[r]);
+                s_slot[w][t] = surv_slot(kd[r]);
+                s_idx[w][t] = iv[r];
             }
         }
-        const uint64_t bs = __ballot(surv), bd = __ballot(t < n && !surv);
-        if ((t & 63) == 0) {
-            s_cnt[0][w] = __popcll(bs);
-            s_cnt[1][w] = __popcll(bd);
-        }
-        __syncthreads();
-        int nS = 0, rs = 0, rd = 0;
+        int nS = 0, nD = 0;
 #pragma unroll
-        for (int v = 0; v < TILE / 64; ++v) {
-            if (v < w) {
-                rs += s_cnt[0][v];
-                rd += s_cnt[1][v];
-            }
-            nS += s_cnt[0][v];
+        for (int r = 0; r < NW; ++r) {
+            const int t = r * 64 + lane;
+            const uint64_t bs = __ballot(sv[r]), bd = __ballot(t < n && !sv[r]);
+            if (sv[r]) s_ps[w][nS + __popcll(bs & below)] = (int16_t)t;
+            else if (t < n) s_pd[w][nD + __popcll(bd & below)] = (int16_t)t;
+            nS += __popcll(bs);
+            nD += __popcll(bd);
         }
-        if (surv) s_pos[rs + __popcll(bs & below)] = (int16_t)t;
-        else if (t < n) s_pos[nS + rd + __popcll(bd & below)] = (int16_t)t;
-        __syncthreads();
-        if (t < n) {
-            const int mp = s_pos[t];
-            const int64_t i = s_idx[mp];
-            if (t < nS) {
-                const int64_t o = surv32 ? cand_off[s] + s_slot[mp] : sbase + i;
-                s_rec[0][mp] = pl.lnl[o];
-                s_rec[1][mp] = pl.chi2[o];
-                s_rec[2][mp] = pl.scale[o];
-                s_rec[3][mp] = pl.av[o];
-                s_rec[4][mp] = pl.rv[o];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // ---- survivors: copy ---------------------------------------------------------
+        for (int k = lane; k < nS; k += 64) {
+            const int mp = s_ps[w][k];
+            const int64_t o = surv32 ? cand_off[s] + s_slot[w][mp] : sbase + s_idx[w][mp];
+            double rec[BRUTUS_NVALS];
+            rec[0] = pl.lnl[o];
+            rec[1] = pl.chi2[o];
+            rec[2] = pl.scale[o];
+            rec[3] = pl.av[o];
+            rec[4] = pl.rv[o];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) s_rec[5 + k][mp] = pl.icov[k][o];
+            for (int v = 0; v < 6; ++v) rec[5 + v] = pl.icov[v][o];
+#pragma unroll
+            for (int v = 0; v < BRUTUS_NVALS; ++v) sel_vals[(int64_t)v * capacity + q0 + mp] = rec[v];
+        }
+        load_kind(s_n, n_n, iv_n, kd_n);
+        // ---- the rest: K1 sweeps + full MLE from the model's row -----------------------
+        for (int k = lane; k < nD; k += 64) {
+            const int mp = s_pd[w][k];
+            const int64_t i = s_idx[w][mp];
+            Coef<NB> c;
+            gather_coef<NB>(grid, nmodel_pad, i, c);
+            double F0[NB];
+            compute_F0_tbl<NB>(c, s_tbl, F0);
+            double av = p.av_mean, rv = p.rv_mean;
+            const int K = k1[s];
+            Mle m;
+            if constexpr (RVF) {
+                double R[NB];
+                coef_R<NB>(c, rv, R);
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                double a_, c_;
+                if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
+                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
             } else {
-                Coef<NB> c;
-                gather_coef<NB>(grid, nmodel_pad, i, c);
-                double F0[NB];
-                compute_F0_tbl<NB>(c, s_tbl, F0);
-                double av = p.av_mean, rv = p.rv_mean;
-                const int K = k1[s];
-                Mle m;
-                if constexpr (RVF) {
-                    double R[NB];
-                    coef_R<NB>(c, rv, R);
-                    GramR G;
-                    gram_init_rf<NB>(c, R, sp, G);
-                    double a_, c_;
-                    if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
-                    mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
-                } else {
-                    Gram G;
-                    gram_init<NB>(c, sp, G);
-                    for (int k = 0; k < K; ++k) {
-                        double a_, b_, c_;
-                        gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
-                    }
-                    mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int kk = 0; kk < K; ++kk) {
+                    double a_, b_, c_;
+                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
                 }
-                s_rec[0][mp] = final_lnl<RVF>(sp, p, m.chi2, false);
-                s_rec[1][mp] = m.chi2;
-                s_rec[2][mp] = m.scale;
-                s_rec[3][mp] = av;
-                s_rec[4][mp] = rv;
-                s_rec[5][mp] = m.i00;
-                s_rec[6][mp] = m.i01;
-                s_rec[7][mp] = m.i02;
-                s_rec[8][mp] = m.i11;
-                s_rec[9][mp] = m.i12;
-                s_rec[10][mp] = m.i22;
+                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             }
+            double *out = sel_vals + q0 + mp;
+            out[0] = final_lnl<RVF>(sp, p, m.chi2, false);
+            out[(int64_t)1 * capacity] = m.chi2;
+            out[(int64_t)2 * capacity] = m.scale;
+            out[(int64_t)3 * capacity] = av;
+            out[(int64_t)4 * capacity] = rv;
+            out[(int64_t)5 * capacity] = m.i00;
+            out[(int64_t)6 * capacity] = m.i01;
+            out[(int64_t)7 * capacity] = m.i02;
+            out[(int64_t)8 * capacity] = m.i11;
+            out[(int64_t)9 * capacity] = m.i12;
+            out[(int64_t)10 * capacity] = m.i22;
         }
-        __syncthreads();
-        if (t < n) {
+        // the next item's LDS writes must not pass this item's reads
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        s = s_n;
+        n = n_n;
+        q0 = q0_n;
 #pragma unroll
-            for (int k = 0; k < BRUTUS_NVALS; ++k) sel_vals[(int64_t)k * capacity + q0 + t] = s_rec[k][t];
+        for (int r = 0; r < NW; ++r) {
+            iv[r] = iv_n[r];
+            kd[r] = kd_n[r];
         }
-        // (the next item's writes to s_idx / s_cnt / s_pos / s_rec are each separated from
-        // this item's reads of them by one of the barriers above)
     }
 }
 
