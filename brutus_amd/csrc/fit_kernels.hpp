@@ -676,8 +676,20 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     __syncthreads();
     const int nitem = wbase[nstar];
     const int niter = first ? 2 : 1;
+    // this lane's model in a work item, requested one item ahead (a dead lane reads the
+    // item's last entry: no select on the loaded value, so nothing waits for it here)
+    auto lane_model = [&](int item) -> int32_t {
+        if (item >= nitem) return 0;
+        const int s = star_of_item(wbase, nstar, item);
+        const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
+        const int64_t last = surv_off[s + 1] - 1;
+        return surv_idx[q < last ? q : last];
+    };
+    int32_t i_nxt = lane_model(blockIdx.x);
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
         const int s = star_of_item(wbase, nstar, item);
+        const int32_t i_me = i_nxt;
+        i_nxt = lane_model(item + gridDim.x);
         if (k2state[s] < 0) continue;
         const StarPrep &sp = stars[s];
         const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
@@ -686,7 +698,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         bool go = live;
         int64_t i = 0, o = 0;
         if (live) {
-            i = surv_idx[q];
+            i = i_me;
             o = (int64_t)s * pl.nmodel + i;
             if (surv32 && !first) go = surv_is(surv32[o]);
         }

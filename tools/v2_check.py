@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--nmodel", type=int, default=750000)
     ap.add_argument("--nfilt", type=int, default=12)
     ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--reps", type=int, default=8, help="timed repetitions of path 2")
     ap.add_argument("--random-grid", action="store_true")
     args = ap.parse_args()
     import torch
@@ -72,10 +73,15 @@ def main():
     for path in (1, 2):
         os.environ["BRUTUS_FIT_PATH"] = str(path)
         os.environ["BRUTUS_AUDIT"] = "1"
-        for rep in range(2):
+        acc = {}
+        nrep = args.reps if path == 2 else 2
+        for rep in range(1 + nrep):
             out = eng.fit_batch_device(*up, params, sel_buffers=bufs[path - 1])
             torch.cuda.synchronize()
-        res[path] = dict(out=out, t=timing(L))
+            if rep:     # mean over the repetitions after the warm-up call
+                for k, v in timing(L).items():
+                    acc[k] = acc.get(k, 0.) + v / nrep
+        res[path] = dict(out=out, t={k: round(v, 3) for k, v in acc.items()})
         print("path", path, "kernel ms:", res[path]["t"], "sum %.3f" % sum(res[path]["t"].values()))
         if path == 1:
             lnlp64 = copy(0, torch.float64, (S, M))
