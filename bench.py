@@ -231,12 +231,16 @@ def bench_cluster(args):
     phot, err, par, perr = synth.make_cluster(iso, nobj, seed=11 + rank)
     theta0 = np.array([-0.1, 9.6, 0.2, 3.3, 850., 0.05])
 
+    walk = np.random.RandomState(5).normal(size=(args.steps + args.warmup + 64, 6))
+
     def call(k):
-        th = theta0 + np.array([1e-3, 1e-3, 1e-3, 0., 0.5, 0.]) * (k % 7)
+        # a sampler's walk: every evaluation has a theta of its own (no point table is
+        # ever asked for twice; the catalogue-only terms are what the cache keeps)
+        th = theta0 + np.array([1e-3, 1e-3, 1e-3, 0., 0.5, 1e-3]) * walk[k]
         return cluster.isochrone_loglike(th, iso, phot, err, parallax=par,
                                          parallax_err=perr, device=dev)
     for k in range(args.warmup):
-        call(k)
+        call(args.steps + k)
 
     def barrier():
         if world > 1:
@@ -252,9 +256,24 @@ def bench_cluster(args):
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # the same with the plug-in's time taken out, and with a point table that is revisited
+    t_plug = 0.
+    for k in range(min(args.steps, 16)):
+        th = theta0 + np.array([1e-3, 1e-3, 1e-3, 0., 0.5, 1e-3]) * walk[k]
+        t1 = time.perf_counter()
+        iso.get_seds_grid(smf_grid=iso.smf_grid, feh=th[0], loga=th[1], av=th[2], rv=th[3],
+                          eep=np.linspace(202., 808., 2000), dist=th[4])
+        t_plug += time.perf_counter() - t1
+    t_plug /= min(args.steps, 16)
+    torch.cuda.synchronize()
+    t1 = time.perf_counter()
+    for k in range(args.steps):
+        call(0)
+    torch.cuda.synchronize()
+    dt_hit = (time.perf_counter() - t1) / args.steps
     # device block alone (HIP events on the launch stream)
     L.brutus_enable_timing(1)
-    call(0)
+    call(1)
     n = C.c_int(0)
     names = (C.c_char_p * 8)()
     ms = (C.c_float * 8)()
@@ -262,6 +281,7 @@ def bench_cluster(args):
     L.brutus_enable_timing(0)
     k_ms = dict((names[j].decode(), float(ms[j])) for j in range(n.value)).get("k_cluster")
     npts = 2000 + 14 * int(np.sum(iso.eep_grid <= 480.))     # evolved points only in slice 0
+    npts_run = 15 * 2000                                     # the kernel walks the dropped ones too
     pairs = float(nobj) * npts
     line = {
         "metric": "isochrone_loglike evaluations/s (5k stars x 12 bands x 15 SMF x 2000 EEP)",
@@ -274,6 +294,9 @@ def bench_cluster(args):
                    "parallelism": "replicas only, %d rank(s)" % world,
                    "timed_region": "whole isochrone_loglike call: host arrays in, lnl_tot out"},
         "star_points_per_s": world * pairs * args.steps / dt,
+        "plugin_ms_per_step": 1e3 * t_plug,
+        "library_ms_per_step": 1e3 * (dt / args.steps - t_plug),
+        "revisited_table_evaluations_per_s": 1. / dt_hit,
     }
     if k_ms:
         # the block re-reads only the 2.9 MB point table per 64-object workgroup:

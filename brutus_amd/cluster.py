@@ -9,6 +9,7 @@ secondary-mass-fraction slice, the chi-square/normal log-pdf and the
 marginalisation over mass and mass fraction (cluster.py:379-407) -- runs in the
 HIP kernel `k_cluster` through `brutus_cluster_lnl`.
 """
+import collections
 import warnings
 
 import numpy as np
@@ -19,6 +20,48 @@ __all__ = ["isochrone_loglike"]
 
 _DEFAULT_SMF = (0., 0.2, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8,
                 0.85, 0.9, 0.95, 1.0)
+
+
+# Per-dataset terms (masks, chi-square outlier level, device copies of the photometry)
+# and point tables are kept between calls: a sampler evaluates the same catalogue many
+# thousand times, and revisits a point table whenever only dist / fout / offsets move.
+_DATA_CACHE = collections.OrderedDict()
+_TABLE_CACHE = collections.OrderedDict()
+_DATA_CACHE_MAX, _TABLE_CACHE_MAX = 4, 16
+
+
+def clear_caches():
+    """Drop the cached per-dataset terms and isochrone point tables."""
+    _DATA_CACHE.clear()
+    _TABLE_CACHE.clear()
+
+
+try:
+    from xxhash import xxh3_64_intdigest as _digest
+except ImportError:                                   # pragma: no cover
+    from zlib import adler32 as _digest
+
+
+def _fingerprint(a):
+    """Address, layout and a digest of the CONTENT of an input array (an array edited in
+    place is a different catalogue)."""
+    if a is None:
+        return None
+    a = np.asarray(a)
+    return (a.ctypes.data, a.shape, a.strides, _digest(np.ascontiguousarray(a).data))
+
+
+def _lru_get(cache, key):
+    val = cache.get(key)
+    if val is not None:
+        cache.move_to_end(key)
+    return val
+
+
+def _lru_put(cache, key, val, cap):
+    cache[key] = val
+    while len(cache) > cap:
+        cache.popitem(last=False)
 
 
 def _take(theta, pos, spec, n):
@@ -38,7 +81,7 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
                       offsets='fixed', corr_params='fixed', mini_bound=0.08,
                       eep_binary_max=480., smf_grid=None, eep_grid=None,
                       parallax=None, parallax_err=None, cluster_prob=0.95,
-                      dim_prior=True, return_lnls=False, device=None):
+                      dim_prior=True, return_lnls=False, device=None, cache=True):
     """ln-likelihood of a co-eval stellar population.  Arguments, defaults and
     return value follow reference cluster.py:23-168: `theta` packs
     `(feh, loga, av, rv, dist[pc], fout)`, then per-band multiplicative offsets
@@ -46,7 +89,14 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
     declared free.  `isochrone` must provide
     `get_seds(feh=, loga=, av=, rv=, eep=, smf=, dist=, mini_bound=,
     eep_binary_max=, corr_params=) -> (seds (Neep, Nbands) mags, params, params2)`
-    with `params['mini']` the initial-mass grid."""
+    with `params['mini']` the initial-mass grid.
+
+    Extensions: `device`; `cache` (default True) keeps the per-dataset terms and the
+    isochrone point tables of recent calls (`clear_caches()` drops them; the plug-in is
+    assumed deterministic).  A plug-in that also offers
+    `get_seds_grid(smf_grid=, ...same keywords...[, out=]) -> (seds (Nsmf, Neep, Nbands), mini)`
+    is asked once per call instead of once per mass fraction (with `out=`, it fills the
+    page-locked buffer the device copy starts from)."""
     from .fitting import _torch, _stream_ptr
     from scipy.stats import chi2 as chisquare
     if phot is None:
@@ -58,10 +108,6 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
     phot = np.asarray(phot, dtype=np.float64)
     err = np.asarray(err, dtype=np.float64)
     Nobjs, Nbands = phot.shape
-    phot_mask = np.isfinite(phot) & np.isfinite(err)
-    phot_n = np.sum(phot_mask, axis=1)
-    if np.any(phot_n == 0):
-        raise ValueError("At least one object has no valid data entries!")
     smf_grid = np.asarray(_DEFAULT_SMF if smf_grid is None else smf_grid, float)
     grad_smf = np.gradient(smf_grid) if len(smf_grid) > 1 else np.array([1.])
     if eep_grid is None:
@@ -104,85 +150,205 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
     else:
         corr_coef, pos = _take(theta, pos, corr_params, 4)
 
-    # ---- per-object terms (cluster.py:292-325) ----------------------------------
+    ds = _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache)
+    torch, dev = _torch(), ds.dev
+    L = _lib.lib()
+
+    # ---- per-object terms that move with theta (cluster.py:292-325) ---------------
     chi2_p = np.zeros(Nobjs)
-    lnorm_p = np.zeros(Nobjs)
-    pmask = np.zeros(Nobjs, dtype=bool)
-    if parallax is not None and parallax_err is not None:
-        parallax = np.asarray(parallax, dtype=np.float64)
-        parallax_err = np.asarray(parallax_err, dtype=np.float64)
-        pmask = np.isfinite(parallax) & np.isfinite(parallax_err)
-        chi2_p[pmask] = (parallax[pmask] - 1e3 / dist) ** 2 / parallax_err[pmask] ** 2
-        lnorm_p[pmask] = np.log(2. * np.pi * parallax_err[pmask] ** 2)
-        phot_n = phot_n + pmask
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        if dim_prior:
-            lnl_outlier = chisquare.logpdf(chisquare.ppf(1. - 1e-5, phot_n), phot_n)
-        else:
-            side = np.nanmax(phot + 3. * err, axis=0) - np.nanmin(phot - 3. * err, axis=0)
-            frac = np.where(phot_mask, 6. * err / side, 1.)
-            vol = np.prod(frac, axis=1)
-            if parallax is not None and parallax_err is not None:
-                span = (np.nanmax((parallax + 3. * parallax_err)[pmask])
-                        - np.nanmin((parallax - 3. * parallax_err)[pmask]))
-                vol[pmask] *= 6. * parallax_err[pmask] / span
-            lnl_outlier = np.log(1. / vol)
+    if ds.pmask is not None:
+        chi2_p[ds.pmask] = (ds.par[ds.pmask] - 1e3 / dist) ** 2 * ds.par_ivar[ds.pmask]
     ln_fin = np.log(cluster_prob * (1. - fout))
     ln_fout = np.log(1. - cluster_prob * (1. - fout))
 
-    # ---- isochrone points of every SMF slice (cluster.py:336-366) -----------------
-    flux_parts, lnw_parts = [], []
-    first = True
-    with warnings.catch_warnings(), np.errstate(all="ignore"):
-        warnings.simplefilter("ignore")
-        for i, smf in enumerate(smf_grid):
-            seds, params, _ = isochrone.get_seds(
-                feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, smf=smf,
-                dist=dist, mini_bound=mini_bound, eep_binary_max=eep_binary_max,
-                corr_params=corr_coef)
-            mini = np.asarray(params['mini'], dtype=np.float64)
-            gmini = np.gradient(mini)
-            keep = np.any(np.isfinite(seds), axis=1) & (gmini > 0.)
-            if not first:   # evolved-star models do not depend on the SMF
-                keep &= eep_grid <= eep_binary_max
-            first = False
-            if np.any(keep):
-                flux_parts.append(10. ** (-0.4 * np.asarray(seds, float)[keep]))
-                lnw_parts.append(np.log(gmini[keep]) + np.log(grad_smf[i]))
-    if not flux_parts:
-        lnl = np.full(Nobjs, -np.inf)
-    else:
-        pts_flux = np.ascontiguousarray(np.concatenate(flux_parts))
-        pts_lnw = np.ascontiguousarray(np.concatenate(lnw_parts))
-        phot_t, err_t = phot * Xb, err * Xb
-        with np.errstate(all="ignore"):
-            ivar = np.where(phot_mask, 1. / err_t ** 2, 0.)
-            lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + lnorm_p
-        d = np.where(phot_mask, phot_t, 0.)
-        torch = _torch()
-        L = _lib.lib()
-        dev = torch.device(device if device is not None
-                           else "cuda:%d" % torch.cuda.current_device())
-        with torch.cuda.device(dev):
-            up = lambda a, dt=np.float64: torch.from_numpy(
-                np.ascontiguousarray(a, dtype=dt)).to(dev)
-            t_flux, t_lnw, t_d, t_iv = up(pts_flux), up(pts_lnw), up(d), up(ivar)
-            t_cp, t_ln, t_n = up(chi2_p), up(lnorm), up(phot_n, np.int32)
-            ws = torch.empty(L.brutus_cluster_workspace_bytes(Nobjs),
-                             dtype=torch.uint8, device=dev)
-            out = torch.empty(Nobjs, dtype=torch.float64, device=dev)
+    with torch.cuda.device(dev):
+        up = lambda a, dt=np.float64: torch.from_numpy(
+            np.ascontiguousarray(a, dtype=dt)).to(dev)
+        # ---- isochrone points of every SMF slice (cluster.py:336-366) -------------
+        tab = _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf,
+                           eep_grid, mini_bound, eep_binary_max, Nbands, dev, torch, L, up,
+                           cache)
+        if tab is None:
+            lnl = np.full(Nobjs, -np.inf)
+        else:
+            t_flux, t_lnw = tab
+            t_ln = None
+            if np.all(Xb == 1.):
+                t_d, t_iv, t_ln = ds.t_d, ds.t_iv, ds.t_ln0
+            else:                                  # multiplicative offsets (cluster.py:327-333)
+                phot_t, err_t = phot * Xb, err * Xb
+                with np.errstate(all="ignore"):
+                    ivar = np.where(ds.phot_mask, 1. / err_t ** 2, 0.)
+                    lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + ds.lnorm_p
+                t_d, t_iv = up(np.where(ds.phot_mask, phot_t, 0.)), up(ivar)
+            ds.h_cp.numpy()[...] = chi2_p
+            t_cp = ds.t_cp.copy_(ds.h_cp, non_blocking=True)
+            if t_ln is None:
+                t_ln = up(lnorm)
             _lib.check(L.brutus_cluster_lnl(
-                Nobjs, Nbands, pts_flux.shape[0], t_flux.data_ptr(),
-                t_lnw.data_ptr(), t_d.data_ptr(), t_iv.data_ptr(),
-                t_cp.data_ptr(), t_ln.data_ptr(), t_n.data_ptr(),
-                1 if dim_prior else 0, ws.data_ptr(), ws.numel(), out.data_ptr(),
-                _stream_ptr(torch)))
-            lnl = out.cpu().numpy()
+                Nobjs, Nbands, t_lnw.numel(), t_flux.data_ptr(), t_lnw.data_ptr(),
+                t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
+                ds.t_n.data_ptr(), 1 if dim_prior else 0, ds.ws.data_ptr(), ds.ws.numel(),
+                ds.out.data_ptr(), _stream_ptr(torch)))
+            lnl = ds.out.cpu().numpy()
     # ---- outlier mixture (cluster.py:410-414) ---------------------------------------
     with np.errstate(all="ignore"):
-        lnl_mix = np.logaddexp(lnl + ln_fin, lnl_outlier + ln_fout)
+        lnl_mix = np.logaddexp(lnl + ln_fin, ds.lnl_outlier + ln_fout)
     lnl_tot = np.sum(lnl_mix)
     if return_lnls:
         return lnl_tot, lnl_mix
     return lnl_tot
+
+
+class _Dataset(object):
+    """What `isochrone_loglike` derives from the catalogue alone (cluster.py:292-325),
+    with the device copies the kernel reads."""
+    pass
+
+
+def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
+    from scipy.stats import chi2 as chisquare
+    from .fitting import _torch
+    key = (_fingerprint(phot), _fingerprint(err), _fingerprint(parallax),
+           _fingerprint(parallax_err), bool(dim_prior), str(device))
+    if cache:
+        ds = _lru_get(_DATA_CACHE, key)
+        if ds is not None:
+            return ds
+    Nobjs = phot.shape[0]
+    ds = _Dataset()
+    ds.phot_mask = np.isfinite(phot) & np.isfinite(err)
+    phot_n = np.sum(ds.phot_mask, axis=1)
+    if np.any(phot_n == 0):
+        raise ValueError("At least one object has no valid data entries!")
+    torch = _torch()
+    L = _lib.lib()
+    dev = ds.dev = torch.device(device if device is not None
+                                else "cuda:%d" % torch.cuda.current_device())
+    ds.lnorm_p = np.zeros(Nobjs)
+    ds.pmask = ds.par = ds.par_ivar = None
+    if parallax is not None and parallax_err is not None:
+        ds.par = np.asarray(parallax, dtype=np.float64)
+        perr = np.asarray(parallax_err, dtype=np.float64)
+        ds.pmask = np.isfinite(ds.par) & np.isfinite(perr)
+        with np.errstate(all="ignore"):
+            ds.par_ivar = 1. / perr ** 2
+            ds.lnorm_p[ds.pmask] = np.log(2. * np.pi * perr[ds.pmask] ** 2)
+        phot_n = phot_n + ds.pmask
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        if dim_prior:
+            ds.lnl_outlier = chisquare.logpdf(chisquare.ppf(1. - 1e-5, phot_n), phot_n)
+        else:
+            side = np.nanmax(phot + 3. * err, axis=0) - np.nanmin(phot - 3. * err, axis=0)
+            frac = np.where(ds.phot_mask, 6. * err / side, 1.)
+            vol = np.prod(frac, axis=1)
+            if ds.pmask is not None:
+                perr = np.asarray(parallax_err, dtype=np.float64)
+                span = (np.nanmax((ds.par + 3. * perr)[ds.pmask])
+                        - np.nanmin((ds.par - 3. * perr)[ds.pmask]))
+                vol[ds.pmask] *= 6. * perr[ds.pmask] / span
+            ds.lnl_outlier = np.log(1. / vol)
+        ivar = np.where(ds.phot_mask, 1. / err ** 2, 0.)
+        ds.lnorm0 = np.nansum(np.log(2. * np.pi * err ** 2), axis=1) + ds.lnorm_p
+    with torch.cuda.device(dev):
+        up = lambda a, dt=np.float64: torch.from_numpy(
+            np.ascontiguousarray(a, dtype=dt)).to(dev)
+        ds.t_d, ds.t_iv = up(np.where(ds.phot_mask, phot, 0.)), up(ivar)
+        ds.t_n = up(phot_n, np.int32)
+        ds.t_ln0 = up(ds.lnorm0)
+        ds.h_cp = torch.empty(Nobjs, dtype=torch.float64).pin_memory()
+        ds.t_cp = torch.empty(Nobjs, dtype=torch.float64, device=dev)
+        ds.ws = torch.empty(L.brutus_cluster_workspace_bytes(Nobjs), dtype=torch.uint8, device=dev)
+        ds.out = torch.empty(Nobjs, dtype=torch.float64, device=dev)
+    if cache:
+        _lru_put(_DATA_CACHE, key, ds, _DATA_CACHE_MAX)
+    return ds
+
+
+_STAGE = {}
+
+
+def _staging(nrow, nb, dev, torch):
+    key = (nrow, nb, str(dev))
+    st = _STAGE.get(key)
+    if st is None:
+        if len(_STAGE) > 4:
+            _STAGE.clear()
+        st = _Dataset()
+        st.h_mags = torch.empty((nrow, nb), dtype=torch.float64).pin_memory()
+        st.h_lnw = torch.empty(nrow, dtype=torch.float64).pin_memory()
+        st.d_mags = torch.empty((nrow, nb), dtype=torch.float64, device=dev)
+        st.d_lnw = torch.empty(nrow, dtype=torch.float64, device=dev)
+        st.src = st.t_src = None
+        st.hook_out = {}
+        _STAGE[key] = st
+    return st
+
+
+def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf, eep_grid,
+                 mini_bound, eep_binary_max, Nbands, dev, torch, L, up, cache):
+    """Device-resident isochrone points `(flux (Npts, Nbands), lnw (Npts))` of all
+    secondary-mass-fraction slices, or None if no slice has a usable point
+    (cluster.py:336-366).  The plug-in's magnitudes go to the device as they are;
+    `brutus_cluster_points` turns them into fluxes and drops the all-NaN points."""
+    from .fitting import _stream_ptr
+    key = (id(isochrone), feh, loga, av, rv, dist,
+           None if corr_coef is None else tuple(corr_coef), smf_grid.tobytes(),
+           eep_grid.tobytes(), mini_bound, eep_binary_max, str(dev))
+    if cache:
+        tab = _lru_get(_TABLE_CACHE, key)
+        if tab is not None:
+            return tab[0]
+    kw = dict(feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, dist=dist,
+              mini_bound=mini_bound, eep_binary_max=eep_binary_max, corr_params=corr_coef)
+    nsmf, neep = len(smf_grid), len(eep_grid)
+    with warnings.catch_warnings(), np.errstate(all="ignore"):
+        warnings.simplefilter("ignore")
+        stage = _staging(nsmf * neep, Nbands, dev, torch)
+        h_mags = stage.h_mags.numpy().reshape(nsmf, neep, Nbands)
+        if hasattr(isochrone, "get_seds_grid"):
+            if stage.hook_out.get(type(isochrone)) is None:     # does the hook take `out=`?
+                import inspect
+                stage.hook_out[type(isochrone)] = \
+                    "out" in inspect.signature(isochrone.get_seds_grid).parameters
+            if stage.hook_out[type(isochrone)]:                 # straight into pinned memory
+                mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid, out=h_mags, **kw)
+            else:
+                mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid, **kw)
+            mags = np.asarray(mags, dtype=np.float64)
+            mini = np.broadcast_to(np.asarray(mini, dtype=np.float64), (nsmf, neep))
+        else:
+            mags = h_mags
+            mini = np.empty((nsmf, neep))
+            for i, smf in enumerate(smf_grid):
+                seds, params, _ = isochrone.get_seds(smf=smf, **kw)
+                mags[i] = seds
+                mini[i] = params['mini']
+        gmini = np.gradient(mini, axis=1)
+        keep = gmini > 0.
+        keep[1:] &= (eep_grid <= eep_binary_max)[None, :]   # evolved stars: first slice only
+        lnw = np.where(keep, np.log(gmini) + np.log(grad_smf)[:, None], -np.inf)
+    tab = None
+    src = np.flatnonzero(keep).astype(np.int32)
+    if src.size:
+        # through page-locked staging buffers (kept per table shape): the magnitudes are
+        # the one sizeable host -> device copy of a call
+        if mags is not h_mags:
+            h_mags[...] = mags
+        stage.h_lnw.numpy()[...] = lnw.reshape(-1)
+        stage.d_mags.copy_(stage.h_mags, non_blocking=True)
+        stage.d_lnw.copy_(stage.h_lnw, non_blocking=True)
+        if stage.src is None or not np.array_equal(stage.src, src):
+            stage.src, stage.t_src = src, up(src, np.int32)     # the kept rows rarely change
+        t_src = stage.t_src
+        t_flux = torch.empty((src.size, Nbands), dtype=torch.float64, device=dev)
+        t_lnw = torch.empty(src.size, dtype=torch.float64, device=dev)
+        _lib.check(L.brutus_cluster_points(src.size, Nbands, t_src.data_ptr(),
+                                           stage.d_mags.data_ptr(), stage.d_lnw.data_ptr(),
+                                           t_flux.data_ptr(), t_lnw.data_ptr(),
+                                           _stream_ptr(torch)))
+        tab = (t_flux, t_lnw)
+    if cache:      # (the plug-in object is kept alive with its tables: `id` stays unique)
+        _lru_put(_TABLE_CACHE, key, (tab, isochrone), _TABLE_CACHE_MAX)
+    return tab

@@ -1198,12 +1198,12 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
     hipStream_t st = (hipStream_t)stream;
     const int ppb = (npts + CLUSTER_CHUNKS - 1) / CLUSTER_CHUNKS;
     const int nchunk = (npts + ppb - 1) / ppb;
-    const dim3 g((nobj + 63) / 64, nchunk);
+    const dim3 g((nobj + CL_T - 1) / CL_T, nchunk);
     Timer tm(st);
     tm.begin("k_cluster");
 #define BRUTUS_CL(N)                                                                              \
     case N:                                                                                       \
-        hipLaunchKernelGGL(k_cluster<N>, g, dim3(64), 0, st, nobj, nfilt, npts, d_pts_flux,       \
+        hipLaunchKernelGGL(k_cluster<N>, g, dim3(CL_T), 0, st, nobj, nfilt, npts, d_pts_flux,     \
                            d_pts_lnw, d_phot, d_ivar, d_chi2_p, d_lnorm, d_ndim, dim_prior, ppb,  \
                            pm, ps);                                                               \
         break;
@@ -1220,6 +1220,18 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        ps, d_lnl);
     HIP_TRY(hipGetLastError());
     tm.collect();
+    return 0;
+}
+
+int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const double *d_mags,
+                          const double *d_lnw_in, double *d_pts_flux, double *d_pts_lnw,
+                          void *stream) {
+    if (npts <= 0 || nfilt <= 0) return fail(BRUTUS_EINVAL, "bad point-table dimensions");
+    if (!d_mags || !d_lnw_in || !d_pts_flux || !d_pts_lnw) return fail(BRUTUS_EINVAL, "NULL device pointer");
+    hipLaunchKernelGGL(k_cluster_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, npts, nfilt, d_src, d_mags, d_lnw_in, d_pts_flux,
+                       d_pts_lnw);
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

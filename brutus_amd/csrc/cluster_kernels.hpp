@@ -13,10 +13,12 @@ namespace {
 // slices concatenated): chi2 = nansum_b (phot_ob - flux_cb)^2 / err_ob^2 + chi2_p,
 // lnl = chi2-logpdf(chi2, n_o) or -(chi2 + lnorm_o)/2, then
 // lnl_o = logsumexp_c (lnl + lnw_c).  One lane = one object (its bands in
-// VGPRs), isochrone points are wave-uniform (scalar loads); the point axis is
+// VGPRs), isochrone points are workgroup-uniform (LDS broadcasts); the point axis is
 // split over blockIdx.y and merged by k_cluster_merge (online logsumexp).
+constexpr int CL_T = 256;      // objects per workgroup: four waves share one staged sub-slice
+
 template <int NB>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(CL_T)
 k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
           const double *__restrict__ pts_lnw, const double *__restrict__ phot,
           const double *__restrict__ ivar, const double *__restrict__ chi2_p,
@@ -27,13 +29,13 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     // band"]: the loop then reads it with broadcast ds_reads instead of a chain of
     // dependent scalar loads.
     constexpr int STRIDE = NB + 2;
-    constexpr int SUB = 12288 / (STRIDE * 8);          // 12 KB per 64-lane workgroup: 3+ waves per SIMD
+    constexpr int SUB = 24576 / (STRIDE * 8);          // 24 KB per workgroup
     __shared__ double s_pts[SUB * STRIDE];
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     const int p0 = blockIdx.y * pts_per_block;
     const int p1 = min(npts, p0 + pts_per_block);
-    const int o = blockIdx.x * 64 + threadIdx.x;
+    const int o = blockIdx.x * CL_T + threadIdx.x;
     const bool live = o < nobj;
     const int oo = live ? o : 0;
     double d[NB], iv[NB];
@@ -50,7 +52,7 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     for (int q0 = p0; q0 < p1; q0 += SUB) {
         const int np = min(SUB, p1 - q0);
         __syncthreads();                                   // previous sub-slice fully consumed
-        for (int c = threadIdx.x; c < np; c += 64) {
+        for (int c = threadIdx.x; c < np; c += CL_T) {
             const double *src = pts_flux + (int64_t)(q0 + c) * nb;
             bool hole = false;
             for (int b = 0; b < NB; ++b) {
@@ -106,6 +108,27 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
         part_m[(int64_t)blockIdx.y * nobj + o] = m;
         part_s[(int64_t)blockIdx.y * nobj + o] = ssum;
     }
+}
+
+// Isochrone points from the plug-in's magnitudes (cluster.py:346-366): flux = 10^(-0.4 mag)
+// (a NaN band stays NaN), and a point none of whose bands is finite gets weight -inf,
+// as does one the host marked so.  Replaces fifteen host-side 10**x passes per call.
+// `src` (may be null = identity) lists the table rows the host kept, in order: the
+// output is the compact point list.
+__global__ void k_cluster_points(int64_t npts, int nb, const int32_t *__restrict__ src,
+                                 const double *__restrict__ mags,
+                                 const double *__restrict__ lnw_in, double *__restrict__ flux,
+                                 double *__restrict__ lnw) {
+    const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= npts) return;
+    const int64_t r = src ? (int64_t)src[c] : c;
+    bool any = false;
+    for (int b = 0; b < nb; ++b) {
+        const double m = mags[r * nb + b];
+        any = any || isfinite(m);
+        flux[c * nb + b] = exp10(-0.4 * m);
+    }
+    lnw[c] = any ? lnw_in[r] : -INFINITY;
 }
 
 __global__ void k_cluster_merge(int nobj, int nchunk, const double *__restrict__ part_m,

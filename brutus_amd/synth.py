@@ -185,6 +185,45 @@ class TableIsochrone(object):
         return mag, {"mini": mini}, {"mini": mini * smf}
 
 
+    def get_seds_grid(self, smf_grid=None, feh=0., loga=9., av=0., rv=3.3, eep=None,
+                      dist=1000., mini_bound=0.08, eep_binary_max=480., corr_params=None,
+                      out=None):
+        """All mass-fraction slices in one call (the batched hook
+        `cluster.isochrone_loglike` looks for): `(mags (Nsmf, Neep, Nbands), mini (Neep,))`,
+        slice by slice what `get_seds` returns."""
+        smf_grid = self.smf_grid if smf_grid is None else np.asarray(smf_grid, dtype=float)
+        ks = [int(np.argmin(np.abs(self.smf_grid - smf))) for smf in smf_grid]
+        if not hasattr(self, "_stack"):
+            self._stack = np.stack(self.mags)
+        eep = self.eep_grid if eep is None else np.asarray(eep, dtype=float)
+        if eep is self.eep_grid or (eep.shape == self.eep_grid.shape
+                                    and np.array_equal(eep, self.eep_grid)):
+            base = self._stack if ks == list(range(len(self.mags))) else self._stack[ks]
+            mini = self.mini
+        else:
+            base = np.empty((len(ks), eep.size, self.rvec.size))
+            for n, k in enumerate(ks):
+                for b in range(self.rvec.size):
+                    base[n, :, b] = np.interp(eep, self.eep_grid, self.mags[k][:, b])
+            mini = np.interp(eep, self.eep_grid, self.mini)
+        # same order of additions as get_seds, in place in `out` or in a buffer this object
+        # keeps (the caller uploads it before asking again)
+        if out is not None:
+            mag = out
+        else:
+            if getattr(self, "_buf", None) is None or self._buf.shape != base.shape:
+                self._buf = np.empty(base.shape)
+            mag = self._buf
+        np.add(base, 0.25 * feh, out=mag)
+        mag -= 0.15 * (loga - 9.)
+        mag += (av * (self.rvec + 0.02 * (rv - 3.3)))[None, None, :]
+        mag += 5. * np.log10(dist / 10.)
+        low = mini < mini_bound
+        if low.any():
+            mag[:, low] = np.nan
+        return mag, mini
+
+
 def make_cluster(iso, nobj, seed=11, frac_no_parallax=0.3, frac_nan_band=0.05):
     """`nobj` members of the population `iso` at 850 pc with 3 % photometry,
     a few NaN bands and NaN parallaxes (what reference cluster.py expects:

@@ -249,6 +249,16 @@ int brutus_debug_galprior(const brutus_post_params *params, int n,
  *   d_ndim (nobj,) i32            phot_n, the chi-square degrees of freedom
  * writes d_lnl (nobj,) = logsumexp over points of (lnl + lnw), i.e. the
  * `lnl` of cluster.py:407 before the outlier mixture. */
+/* Isochrone points of all secondary-mass-fraction slices from the plug-in's apparent
+ * magnitudes (reference cluster.py:346-366, the `10**(-0.4 * seds)` and the
+ * any-finite-band test of every slice): d_mags (nrow, nfilt) float64 and d_lnw_in (nrow)
+ * = ln(d mini) + ln(d smf) over the whole table, d_src (npts) int32 the rows the host
+ * kept, in order (NULL: all nrow = npts rows) -> d_pts_flux (npts, nfilt), d_pts_lnw
+ * (npts), the inputs of brutus_cluster_lnl; a kept row without a finite band gets
+ * weight -inf. */
+int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const double *d_mags,
+                          const double *d_lnw_in, double *d_pts_flux, double *d_pts_lnw,
+                          void *stream);
 size_t brutus_cluster_workspace_bytes(int nobj);
 int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        const double *d_pts_lnw, const double *d_phot,

@@ -94,3 +94,47 @@ def test_errors_match_reference_messages():
     bad[3] = np.nan
     with pytest.raises(ValueError, match="no valid data"):
         cluster.isochrone_loglike(THETA, iso, bad, err)
+
+
+@pytest.mark.gpu
+def test_batched_plugin_hook_and_caches_change_nothing():
+    """The optional `get_seds_grid` hook, the per-dataset cache and the point-table cache
+    are pure accelerations: a plug-in without the hook, `cache=False`, a first call and a
+    repeated call all give the same per-object values (<= 1e-12; the hook returns the very
+    magnitudes `get_seds` does)."""
+    from brutus_amd import cluster, synth
+
+    class NoHook(object):                      # the reference's plug-in surface only
+        def __init__(self, iso):
+            self.iso = iso
+
+        def get_seds(self, **kw):
+            return self.iso.get_seds(**kw)
+
+    iso = synth.TableIsochrone(nbands=12, neep=2000)
+    phot, err, par, perr = synth.make_cluster(iso, 700, seed=3)
+    kw = dict(parallax=par, parallax_err=perr, return_lnls=True)
+    cluster.clear_caches()
+    ref = cluster.isochrone_loglike(THETA, NoHook(iso), phot, err, cache=False, **kw)
+    first = cluster.isochrone_loglike(THETA, iso, phot, err, **kw)
+    again = cluster.isochrone_loglike(THETA, iso, phot, err, **kw)
+    th2 = THETA + np.array([0.02, -0.03, 0.05, 0., 12., 0.01])
+    moved = cluster.isochrone_loglike(th2, iso, phot, err, **kw)
+    moved_ref = cluster.isochrone_loglike(th2, NoHook(iso), phot, err, cache=False, **kw)
+    for a in (first, again):
+        assert relerr(ref[1], a[1]) < 1e-12 and abs(a[0] - ref[0]) <= 1e-12 * abs(ref[0])
+    assert relerr(moved_ref[1], moved[1]) < 1e-12
+    assert abs(moved[0] - ref[0]) > 1e-3          # a different theta is a different answer
+    # offsets: the cached device copies of the photometry are bypassed, not reused
+    nb = 12
+    theta3 = np.concatenate([THETA, np.linspace(0.97, 1.03, nb - 1)])
+    off = cluster.isochrone_loglike(theta3, iso, phot, err, offsets=[1.0] + [None] * (nb - 1), **kw)
+    off_ref = cluster.isochrone_loglike(theta3, NoHook(iso), phot, err, cache=False,
+                                        offsets=[1.0] + [None] * (nb - 1), **kw)
+    assert relerr(off_ref[1], off[1]) < 1e-12
+    # a catalogue edited in place is a new catalogue
+    phot2 = phot.copy()
+    a = cluster.isochrone_loglike(THETA, iso, phot2, err, **kw)
+    phot2[5, 3] *= 1.5
+    b = cluster.isochrone_loglike(THETA, iso, phot2, err, **kw)
+    assert a[1][5] != b[1][5] and np.array_equal(np.delete(a[1], 5), np.delete(b[1], 5))
