@@ -59,7 +59,7 @@ def parse():
     ap.add_argument("--nfilt", type=int, default=12)
     ap.add_argument("--cpu-seconds", type=float, default=20.0,
                     help="budget for the CPU baseline sample (0 = skip)")
-    ap.add_argument("--streams", type=int, default=2,
+    ap.add_argument("--streams", type=int, default=3,
                     help="host threads / HIP streams per GPU, each with its own "
                          "workspace, taking the steps round-robin (kernels of "
                          "consecutive batches overlap on the device)")

@@ -45,9 +45,9 @@ def main():
     orig = fitting._Engine.post_batch_device
 
     def counted(self, sel_idx, sel_vals, sel_off, nstar, statics, coords, parallax,
-                parallax_err, pp):
+                parallax_err, pp, **kw2):
         out = orig(self, sel_idx, sel_vals, sel_off, nstar, statics, coords, parallax,
-                   parallax_err, pp)
+                   parallax_err, pp, **kw2)
         counts["first_cut"] = int(sel_off.cpu().numpy()[nstar])
         counts["second_cut"] = int(out[4][nstar] - out[4][0]) // (3 * pp.nmc)
         return out
