@@ -1538,11 +1538,19 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             {
                 const int nitem = PCH * ng;
                 HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
-                hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
-                                   capacity, PCH * s0, PCH * s1, w.mc_counter, (const double *)zbase,
-                                   (const int64_t *)w.mt_zoff, w.mc_stage, d_sel_idx, d_sel_vals,
-                                   d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga,
-                                   w.rp, w.part_max, w.part_chi2);
+                static const int use_arr = env_int("BRUTUS_POST_MC_ARR", 1);
+                if (use_arr && pp.nmc <= MCA_NMC)
+                    hipLaunchKernelGGL(k_post_mc_arr, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0,
+                                       st, pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
+                                       (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx,
+                                       d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
+                                       d_loga, w.rp, w.part_max, w.part_chi2);
+                else
+                    hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
+                                       pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
+                                       (const double *)zbase, (const int64_t *)w.mt_zoff, w.mc_stage,
+                                       d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
+                                       w.geom, d_feh, d_loga, w.rp, w.part_max, w.part_chi2);
             }
             tm.end();
             const dim3 gg(PCH, ng);

@@ -665,6 +665,138 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     }
 }
 
+// P4 with the normals in memory (numpy's stream reproduced by mt_kernels.hpp), nmc <=
+// MCA_NMC.  The 3 nmc normals of a record are one contiguous run of the object's slice and
+// consecutive records follow each other, so a wave takes MCA_R records at a time: their
+// MCA_R * 3 nmc normals come in as ONE coalesced copy into the wave's LDS tile, and the 64
+// lanes are MCA_R records x MCA_G sample groups (group g integrates samples g, g + MCA_G,
+// ...); the partial (max, sum, count) triples of a record's lanes are merged with three
+// shuffle steps.  The lane-per-record form (k_post_mc with `zarr`) copies every run into
+// a lane-interleaved staging column first: 16-byte loads at a 1.2 KB stride, then the same
+// bytes written and read once more -- three times the HBM traffic of this kernel.
+constexpr int MCA_R = 8, MCA_G = 8, MCA_NMC = 64;
+
+__global__ void __launch_bounds__(TILE, 3)
+k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
+              const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
+              const int32_t *__restrict__ sel_idx, const double *__restrict__ sel_vals,
+              const int64_t *__restrict__ sel_off, const int64_t *__restrict__ off2,
+              const int64_t *__restrict__ nsel, const int32_t *__restrict__ flags,
+              const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+              const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
+              double *__restrict__ part_chi2) {
+    static_assert(MCA_R * MCA_G == 64, "one wave = records x sample groups");
+    __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    __shared__ unsigned int s_item;
+    __shared__ double s_z[TILE / 64][MCA_R * 3 * MCA_NMC];
+    stage_exp_table(s_tbl);
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int rec8 = lane / MCA_G, grp = lane % MCA_G;
+    const int run = 3 * pp.nmc;
+    double *const zt = s_z[w];
+    for (;;) {
+        __syncthreads();
+        if (threadIdx.x == 0) s_item = (unsigned int)item_base + atomicAdd(counter, 1u);
+        __syncthreads();
+        const unsigned int item = s_item;
+        if (item >= (unsigned int)nitem) break;
+        const int s = (int)(item / PCH), c = (int)(item % PCH);
+        int64_t a, b;
+        rec_range_n(off2[s], nsel[s], c, a, b);
+        const StarGeom g = geom[s];
+        const double *const zsrc = zarr + zoff[s];      // the object's normals, numbered from 0
+        double mx = -INFINITY, cmin = -INFINITY;        // cmin holds -min(chi2)
+        if (!flags[s]) {
+            for (int64_t ob = a + (int64_t)w * 64; ob < b; ob += TILE) {
+                for (int pass = 0; pass < 64 / MCA_R; ++pass) {
+                    const int64_t o0 = ob + pass * MCA_R;
+                    if (o0 >= b) break;                                  // wave-uniform
+                    const int nrec = (int)(b - o0 < MCA_R ? b - o0 : MCA_R);
+                    const int64_t j0 = (o0 - off2[s]) * run;
+                    for (int k = lane; k < nrec * run; k += 64) zt[k] = zsrc[j0 + k];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                    const bool live = rec8 < nrec;
+                    const int64_t o = o0 + (live ? rec8 : 0);
+                    const int64_t r = sel_off[s] + rp.src[o];
+                    const int64_t i = sel_idx[r];
+                    double Fc[3], Ac[3], L[6];
+                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+                    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
+                                 r0 = sel_vals[4 * cap + r];
+                    double M = -INFINITY, acc = 0.;
+                    int ninb = 0;
+                    const double *const zr = zt + (live ? rec8 : 0) * run;
+                    if (live) {
+                        for (int t = grp; t < pp.nmc; t += MCA_G) {
+                            double d_, a_, r_, lin, epar;
+                            bool inb;
+                            mc_sample_lin(pp, g, zr[t], zr[pp.nmc + t], zr[2 * pp.nmc + t], s0, a0, r0, L,
+                                          Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar);
+                            ninb += inb ? 1 : 0;
+                            if (g.has_par || g.dust_on) {
+                                const double dM = epar - M;
+                                const double ex = fast_exp_bf(-fabs(dM), s_tbl);
+                                const bool up = inb && dM > 0.;
+                                const double add = inb ? lin : 0.;
+                                acc = up ? fma(acc, ex, add) : (inb ? fma(add, ex, acc) : acc);
+                                M = up ? epar : M;
+                            } else {
+                                acc += inb ? lin : 0.;
+                            }
+                        }
+                    }
+                    // merge the MCA_G partial triples of a record (lanes differing in the low bits)
+#pragma unroll
+                    for (int off = 1; off < MCA_G; off <<= 1) {
+                        const double Mo = __shfl_xor(M, off, 64), acco = __shfl_xor(acc, off, 64);
+                        ninb += __shfl_xor(ninb, off, 64);
+                        if (g.has_par || g.dust_on) {
+                            if (Mo > -INFINITY) {
+                                if (M > -INFINITY) {
+                                    const double ex = fast_exp_bf(-fabs(Mo - M), s_tbl);
+                                    acc = M >= Mo ? fma(acco, ex, acc) : fma(acc, ex, acco);
+                                    M = M >= Mo ? M : Mo;
+                                } else {
+                                    acc = acco;
+                                    M = Mo;
+                                }
+                            }
+                        } else {
+                            acc += acco;
+                        }
+                    }
+                    if (live && grp == 0) {
+                        // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
+                        // sample in bounds the reference yields +inf -> not finite -> -BIG
+                        double lse = pp.lnK + log(acc);
+                        if (g.has_par || g.dust_on) lse += M - (g.has_par ? 0.5 * g.par_lnorm : 0.);
+                        double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
+                        if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
+                        rp.lnp[o] = lnp;
+                        if (lnp > mx) mx = lnp;
+                        double chi2 = sel_vals[1 * cap + r];
+                        if (g.has_par) {
+                            const double dp = sqrt(s0) - g.par;
+                            chi2 += dp * dp * g.par_ivar;
+                        }
+                        if (-chi2 > cmin) cmin = -chi2;
+                    }
+                    // the next pass overwrites the tile
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+        }
+        block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
+        block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
+    }
+}
+
 // P5: evidence and the cumulative weights of one object (fitting.py:2033-2038),
 // chunk-parallel over grid (PCH, object):
 //   k_post_evid_part : per-chunk sums of exp(lnp - max)          -> levid
