@@ -343,9 +343,14 @@ void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, 
                   const int32_t *k2, const int32_t *surv_idx, const int64_t *surv_off,
                   const int32_t *wbase, const Planes &pl, double *part, float *surv32,
                   const double *thr_cull) {
-    hipLaunchKernelGGL((k_fflux<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
-                       nmodel_pad, nstar, stars, p, k1, k2, first, surv_idx, surv_off, wbase, pl, part,
-                       surv32, thr_cull);
+    if (first)
+        hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
+                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase, pl,
+                           part, surv32, thr_cull);
+    else
+        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
+                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase, pl,
+                           part, surv32, thr_cull);
 }
 
 template <int NB, int KS, int G, bool RVF>

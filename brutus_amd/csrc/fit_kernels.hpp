@@ -663,11 +663,11 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
 // lnl_p > thr_cull[s] (fitting.py:758-759) and marks the outcome in the float32 plane
 // (survivor tag / -inf, see surv_tag); only survivors iterate, store and enter the
 // statistics, and they store at their LIST POSITION q, not at (star, model).
-template <int NB, bool RVF>
+template <int NB, bool RVF, bool FIRST>
 __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
-        const int32_t *__restrict__ k2state, int first, const int32_t *__restrict__ surv_idx,
+        const int32_t *__restrict__ k2state, const int32_t *__restrict__ surv_idx,
         const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
         double *__restrict__ part, float *__restrict__ surv32,
         const double *__restrict__ thr_cull) {
@@ -675,7 +675,9 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     stage_exp_table(s_tbl);
     __syncthreads();
     const int nitem = wbase[nstar];
-    const int niter = first ? 2 : 1;
+    // (the launch kind is a template parameter: the opening launch then carries no
+    // state-reload path and its two iterations unroll)
+    constexpr int niter = FIRST ? 2 : 1;
     // this lane's model in a work item, requested one item ahead (a dead lane reads the
     // item's last entry: no select on the loaded value, so nothing waits for it here)
     auto lane_model = [&](int item) -> int32_t {
@@ -700,7 +702,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         if (live) {
             i = i_me;
             o = (int64_t)s * pl.nmodel + i;
-            if (surv32 && !first) go = surv_is(surv32[o]);
+            if (surv32 && !FIRST) go = surv_is(surv32[o]);
         }
         const int64_t os = surv32 ? q : o;       // where this entry's state / results live
         if (go) {
@@ -712,7 +714,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             double av, rv, step, lnl_old;
             double R[RVF ? NB : 1];
             if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
-            if (first) {
+            if constexpr (FIRST) {
                 av = p.av_mean;
                 rv = p.rv_mean;
                 const int K = k1[s];
@@ -744,7 +746,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
-            if (surv32 && first) {
+            if (surv32 && FIRST) {
                 go = cull_stat(sp, m) > thr_cull[s];
                 surv32[o] = go ? surv_tag(q - surv_off[s]) : -INFINITY;
             }
