@@ -90,6 +90,9 @@ SIGNATURES = {
     "brutus_post_batch_numpy": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                           _vp, _i32, _vp, _vp, _sz, _vp]),
+    "brutus_post_batch_numpy_phase": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+                                                _vp, _vp, C.POINTER(PostParams), _vp, _sz, _vp,
+                                                _vp, _vp, _vp, _i32, _vp, _vp, _sz, _i32, _vp]),
     "brutus_debug_mt_stream": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "brutus_set_mt_jump": (C.c_int, [_vp, _i32, _i64, _i64]),
     "brutus_post_set_dust": (C.c_int, [_vp, _vp, _i32, _dbl, _dbl, _dbl, _dbl]),

@@ -1319,6 +1319,8 @@ struct MtArgs {            // numpy-stream mode of post_batch_impl
     uint32_t *h_states;    // (nstream, MT_STATE_WORDS) in / out
     double *d_zbuf;        // normals of one group of objects
     size_t zbuf_doubles;
+    int phase;             // 0: whole call; 1: up to and including the stream walk (states
+                           // advanced, normals + uniforms left in the buffers); 2: the rest
 };
 
 // Keep the nsel_max best records of object s, best first (fitting.py:1029-1036).
@@ -1418,6 +1420,8 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
     hipStream_t st = (hipStream_t)stream;
     Timer tm(st);
     const dim3 g2(PCH, nstar), blk(TILE);
+    const int phase = mt ? mt->phase : 0;
+    if (phase != 2) {
     DustCtx dc = g_dust;                 // one-shot: set by brutus_post_set_dust on this thread
     g_dust = DustCtx{};
     if (dc.d_los && (dc.nd < 2 || dc.nd > 4096)) return fail(BRUTUS_EINVAL, "bad dust table");
@@ -1452,6 +1456,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             }
         if (any) HIP_TRY(hipMemsetAsync(w.flags, 0, 4 * (size_t)nstar, st));
     }
+    }      // phase != 2
     const dim3 gdraw((pp.ndraws + 63) / 64, nstar);
     if (!mt) {
         tm.begin("k_post_mc");
@@ -1483,16 +1488,23 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         // numpy's own stream (mt_kernels.hpp): objects are served in groups whose normals fit
         // the caller's buffer; a group's stream walk, Monte Carlo integral, cdf and draws run
         // before the next group overwrites the buffer.
+        // Phases (brutus_post_batch_numpy_phase): 1 stops after the stream walk of the ONE
+        // group that must hold all objects, 2 picks up from the buffers phase 1 left --
+        // the caller runs phase 2 of batch k beside phase 1 of batch k + 1 (second
+        // workspace and buffer), since the generator state is final after the walk.
         std::vector<int64_t> hn(nstar), nnorm(nstar), zoff(nstar);
-        HIP_TRY(hipMemcpyAsync(hn.data(), w.nsel, 8 * (size_t)nstar, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(w.mt_states, mt->h_states,
-                               sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
-                               hipMemcpyHostToDevice, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        const int nuni = pp.ndraws * (pp.return_distreds ? 2 : 1);
-        for (int s = 0; s < nstar; ++s) nnorm[s] = 3 * (int64_t)pp.nmc * hn[s];
         std::vector<int> hpos(mt->nstream);
-        for (int g = 0; g < mt->nstream; ++g) hpos[g] = (int)mt->h_states[(size_t)g * MT_STATE_WORDS + MT_N];
+        const int nuni = pp.ndraws * (pp.return_distreds ? 2 : 1);
+        if (phase != 2) {
+            HIP_TRY(hipMemcpyAsync(hn.data(), w.nsel, 8 * (size_t)nstar, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(w.mt_states, mt->h_states,
+                                   sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
+                                   hipMemcpyHostToDevice, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            for (int s = 0; s < nstar; ++s) nnorm[s] = 3 * (int64_t)pp.nmc * hn[s];
+            for (int g = 0; g < mt->nstream; ++g)
+                hpos[g] = (int)mt->h_states[(size_t)g * MT_STATE_WORDS + MT_N];
+        }
         // the caller's buffer: the first eighth (at least 64 MB) is scratch of the parallel
         // stream walk (bitmap, sub-stream windows ...), the rest holds the normals
         size_t zscratch = (mt->zbuf_doubles * 8 / 8 + 255) & ~(size_t)255;
@@ -1504,16 +1516,20 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         for (int s0 = 0; s0 < nstar;) {
             int s1 = s0;
             int64_t used = 0;
-            while (s1 < nstar) {
+            while (phase != 2 && s1 < nstar) {
                 const int64_t need = ((nnorm[s1] + 1) & ~(int64_t)1) + 2;      // even, padded
                 if (used + need > (int64_t)zdoubles) break;
                 zoff[s1] = used;
                 used += need;
                 ++s1;
             }
+            if (phase == 2) s1 = nstar;
             if (s1 == s0)
                 return fail(BRUTUS_ENOMEM, "normal buffer too small: object %d needs %lld doubles, "
                             "buffer holds %zu", s0, (long long)nnorm[s0] + 3, zdoubles);
+            if (phase == 1 && s1 < nstar)
+                return fail(BRUTUS_ENOMEM, "normal buffer too small for one group (%d of %d objects "
+                            "fit): use the whole-call form", s1, nstar);
             const int ng = s1 - s0;
             int nseg;
             uint32_t *d_states;
@@ -1527,6 +1543,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                 for (int q = 0; q <= ng; ++q) seg[q] = s0 + q;
                 d_states = w.mt_states + (size_t)s0 * MT_STATE_WORDS;
             }
+            if (phase != 2) {
             HIP_TRY(hipMemcpyAsync(w.mt_nnorm, nnorm.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_seg, seg.data(), 4 * (size_t)(nseg + 1), hipMemcpyHostToDevice, st));
@@ -1538,6 +1555,15 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                                      nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm))
                     return rc;
                 for (int q = 0; q < nseg; ++q) hpos[mt->nstream == 1 ? 0 : s0 + q] = p0[q];
+            }
+            }      // phase != 2
+            if (phase == 1) {
+                HIP_TRY(hipMemcpyAsync(mt->h_states, w.mt_states,
+                                       sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
+                                       hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                tm.collect();
+                return 0;
             }
             tm.begin("k_post_mc");
             {
@@ -1577,9 +1603,10 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             HIP_TRY(hipStreamSynchronize(st));     // the host arrays of this group are reused
             s0 = s1;
         }
-        HIP_TRY(hipMemcpyAsync(mt->h_states, w.mt_states,
-                               sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
-                               hipMemcpyDeviceToHost, st));
+        if (phase == 0)
+            HIP_TRY(hipMemcpyAsync(mt->h_states, w.mt_states,
+                                   sizeof(uint32_t) * (size_t)mt->nstream * MT_STATE_WORDS,
+                                   hipMemcpyDeviceToHost, st));
     }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(h_star_out, w.star_out, 8 * 4 * (size_t)nstar, hipMemcpyDeviceToHost, st));
@@ -1618,7 +1645,25 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                             void *stream) {
     if ((nstream != 1 && nstream != nstar) || !h_states || !d_zbuf || zbuf_doubles < 1024)
         return fail(BRUTUS_EINVAL, "bad numpy-stream arguments");
-    MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles};
+    MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles, 0};
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+                           d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
+                           d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
+}
+
+int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                                  const double *d_sel_vals, const int64_t *d_sel_off,
+                                  const double *d_lnprior, const double *d_feh, const double *d_loga,
+                                  const double *d_coords, const double *d_parallax,
+                                  const double *d_parallax_err, const brutus_post_params *params,
+                                  void *d_workspace, size_t workspace_bytes, int32_t *d_out_idx,
+                                  double *d_out_vals, double *h_star_out, int32_t *h_flags,
+                                  int nstream, uint32_t *h_states, double *d_zbuf,
+                                  size_t zbuf_doubles, int phase, void *stream) {
+    if ((nstream != 1 && nstream != nstar) || !h_states || !d_zbuf || zbuf_doubles < 1024 ||
+        phase < 0 || phase > 2)
+        return fail(BRUTUS_EINVAL, "bad numpy-stream arguments");
+    MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles, phase};
     return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);

@@ -314,6 +314,60 @@ class _Engine(object):
         return (out_idx.cpu().numpy(), out_vals.cpu().numpy(), star_out, flags,
                 nbase)
 
+    # ---- brutus_post_batch_numpy in two halves (pipelined across batches) --------------
+    def post_numpy_begin(self, slot, sel_idx, sel_vals, sel_off, nstar, statics, coords,
+                         parallax, parallax_err, pp, np_states):
+        """Phase 1 of `brutus_post_batch_numpy_phase` in pipeline slot `slot` (own
+        workspace, normal buffer and outputs): cuts, covariances, stream walk; `np_states`
+        is advanced.  False if the objects do not fit the slot's buffer as one group
+        (nothing consumed: use `post_batch_device`)."""
+        import os
+        torch, L, g = self.torch, self.L, self.grid
+        ctxs = self.__dict__.setdefault("_post_slots", {})
+        ctx = ctxs.setdefault(slot, {})
+        cap = sel_idx.numel()
+        nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
+        if ctx.get("ws") is None or ctx["ws"].numel() < nbytes:
+            ctx["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        if ctx.get("zbuf") is None:
+            free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
+            gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.2 * free))))
+            ctx["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64, device=g.device)
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)
+        lnprior, feh, loga = statics
+        ctx["keep"] = (sel_idx, sel_vals, sel_off, dev(coords), dev(parallax), dev(parallax_err))
+        ctx["out"] = (torch.empty((nstar, pp.ndraws), dtype=torch.int32, device=g.device),
+                      torch.empty((nstar, pp.ndraws, 17), dtype=torch.float64, device=g.device),
+                      np.zeros((nstar, 4)), np.zeros(nstar, dtype=np.int32))
+        assert np_states.dtype == np.uint32 and np_states.flags.c_contiguous
+
+        def call(phase):
+            k, o = ctx["keep"], ctx["out"]
+            return L.brutus_post_batch_numpy_phase(
+                nstar, cap, k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
+                loga.data_ptr() if loga is not None else None, k[3].data_ptr(), k[4].data_ptr(),
+                k[5].data_ptr(), pp, ctx["ws"].data_ptr(), ctx["ws"].numel(), o[0].data_ptr(),
+                o[1].data_ptr(), o[2].ctypes.data, o[3].ctypes.data, int(np_states.shape[0]),
+                np_states.ctypes.data, ctx["zbuf"].data_ptr(), ctx["zbuf"].numel(), phase,
+                _stream_ptr(torch))
+        ctx["call"] = call
+        rc = call(1)
+        if rc == -2 and b"normal buffer too small" in L.brutus_last_error():
+            return False
+        _lib.check(rc)
+        return True
+
+    def post_numpy_end(self, slot):
+        """Phase 2 for the batch `post_numpy_begin` left in `slot` (any thread / stream)."""
+        ctx = self._post_slots[slot]
+        _lib.check(ctx["call"](2))
+        o = ctx["out"]
+        res = (o[0].cpu().numpy(), o[1].cpu().numpy(), o[2], o[3],
+               np.zeros(o[3].size + 1, dtype=np.uint64))
+        ctx["keep"] = ctx["call"] = None
+        return res
+
     @staticmethod
     def record_of(sel_idx, sel_vals, off, s, ndim, k1=0, k2=0):
         """One object's first-cut records as the host-stage dict."""
@@ -698,6 +752,7 @@ class BruteForce(object):
         #: device `lnpost` mode: scan batch k+1 on a second stream while `lnpost`
         #: of batch k runs (costs a second workspace)
         self.scan_ahead = True
+        self.post_pipeline = True      # numpy streams: phase 2 of batch k beside phase 1 of k + 1
         # `lnpost` on the device also for numpy's own random stream (RandomState / None)
         self.device_numpy_rng = True
 
@@ -1108,33 +1163,85 @@ class BruteForce(object):
         # share nothing but the read-only grid, and the random-stream positions
         # only chain the `lnpost` calls, which stay in order here.
         ahead = len(starts) > 1 and self.scan_ahead
+        # numpy streams: the generator state is final after the stream walk, so the Monte
+        # Carlo integral / evidence / draws of batch k (a second helper thread and stream)
+        # run beside the cuts + stream walk of batch k + 1 (this thread): the first is bound
+        # by float64 issue, the second by LDS and HBM.  Needs a third scan engine, because
+        # the records of batch k are still being read when batch k + 2 is scanned.
+        pipelined = ahead and np_mode is not None and getattr(self, "post_pipeline", True)
+        nE = 3 if pipelined else 2
+        finisher = None
         if ahead:
             import concurrent.futures
-            e2 = getattr(self, "_engine_obj2", None)
-            if e2 is None or e2.batch != eng.batch or e2.grid is not eng.grid:
-                self._engine_obj2 = _Engine(eng.grid, max_batch=eng.batch)
-            engines = (eng, self._engine_obj2)
-            streams = (torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev))
+            extra = getattr(self, "_engine_extra", None)
+            if (extra is None or len(extra) < nE - 1 or extra[0].batch != eng.batch
+                    or extra[0].grid is not eng.grid):
+                extra = self._engine_extra = [_Engine(eng.grid, max_batch=eng.batch)
+                                              for _ in range(nE - 1)]
+            engines = (eng,) + tuple(extra[:nE - 1])
+            streams = tuple(torch.cuda.Stream(device=dev) for _ in range(nE))
             pool = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+            if pipelined:
+                finisher = concurrent.futures.ThreadPoolExecutor(max_workers=1)
+                fin_stream = torch.cuda.Stream(device=dev)
+                walk_stream = torch.cuda.Stream(device=dev)
         else:
             engines, streams, pool = (eng, eng), (None, None), None
 
         def scan(k):
             a = starts[k]
             b = min(Ndata, a + step)
-            en = engines[k % 2]
+            en = engines[k % nE]
             with torch.cuda.device(dev):
-                if streams[k % 2] is None:
+                if streams[k % nE] is None:
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
                     return en.records_device(f, e, m, p, pe, hp, params)
-                with torch.cuda.stream(streams[k % 2]):
+                with torch.cuda.stream(streams[k % nE]):
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
                     out = en.records_device(f, e, m, p, pe, hp, params)
-                    streams[k % 2].synchronize()
+                    streams[k % nE].synchronize()
                     return out
 
+        def finish(slot):
+            with torch.cuda.device(dev), torch.cuda.stream(fin_stream):
+                return eng.post_numpy_end(slot)
+
+        def rows(a, S, sel_idx, sel_vals, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
+                 nbase, ubase0):
+            """The tuples `_fit` yields for the objects of one batch."""
+            for s in range(S):
+                i = a + s
+                if flags[s]:
+                    # more than Nsel_max models survive the second cut: the
+                    # reference re-sorts them (fitting.py:1029-1036); rare,
+                    # done by the host stage on the same stream positions
+                    rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
+                          PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
+                                            n_uniform=int(ubase0) + s * K))
+                    rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
+                    yield self._finish_star(rec, parallax[i], parallax_err[i],
+                                            data_coords[i], Nmc_prior, lnprior,
+                                            wt_thresh, cdf_thresh, lngalprior, None,
+                                            None, dlabels, avlim, rvlim, mem_lim, rs,
+                                            False, Ndraws, return_distreds)
+                    continue
+                if star_out[s, 3] < 1:
+                    raise ValueError("object %d: no model survives the prior "
+                                     "cuts (the reference fails in np.min on an "
+                                     "empty selection, fitting.py:2034)" % i)
+                v = out_vals[s]
+                nd = int(ndim[s]) + (1 if np.isfinite(parallax[i])
+                                     and np.isfinite(parallax_err[i]) else 0)
+                res = (out_idx[s].astype(np.int64), v[:, 0], v[:, 1], v[:, 2],
+                       v[:, 3:12].reshape(-1, 3, 3), nd, v[:, 12],
+                       float(star_out[s, 0]), float(star_out[s, 1]))
+                if return_distreds:
+                    res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
+                yield res
+
+        pending = None        # (future of phase 2, row arguments) of the previous batch
         try:
             fut = pool.submit(scan, 0) if ahead else None
             for kb, a in enumerate(starts):
@@ -1181,6 +1288,29 @@ class BruteForce(object):
                         t_ok = torch.from_numpy(np.ascontiguousarray(ok[a:b])).to(dev)
                         _lib.check(eng.L.brutus_post_set_dust(t_los.data_ptr(), t_ok.data_ptr(),
                                                               int(los.shape[2]), 0., 1., 1., 0.2))
+                    if pipelined:
+                        with torch.cuda.stream(walk_stream):
+                            began = eng.post_numpy_begin(
+                                kb % 2, sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
+                                parallax[a:b], parallax_err[a:b], pp, np_states)
+                        if began:
+                            if np_mode == "shared":   # final already: the walk is done
+                                rstate.set_state(words_to_state(np_states[0]))
+                            job = finisher.submit(finish, kb % 2)
+                            args = (a, S, sel_idx, sel_vals, off, ndim, k1, k2)
+                            if pending is not None:
+                                prev, pargs = pending
+                                pending = (job, args)
+                                for row in rows(*(pargs + prev.result() + (0,))):
+                                    yield row
+                            else:
+                                pending = (job, args)
+                            continue
+                        if pending is not None:      # whole-call form for this batch, in order
+                            prev, pargs = pending
+                            pending = None
+                            for row in rows(*(pargs + prev.result() + (0,))):
+                                yield row
                     out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
                         sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
                         parallax[a:b], parallax_err[a:b], pp, np_states=np_states)
@@ -1191,38 +1321,19 @@ class BruteForce(object):
                         # what the batch consumed from the shared stream
                         rstate.n_normal = int(nbase[S])
                         rstate.n_uniform = int(ubase0) + S * K
-                    for s in range(S):
-                        i = a + s
-                        if flags[s]:
-                            # more than Nsel_max models survive the second cut: the
-                            # reference re-sorts them (fitting.py:1029-1036); rare,
-                            # done by the host stage on the same stream positions
-                            rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
-                                  PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
-                                                    n_uniform=int(ubase0) + s * K))
-                            rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
-                            yield self._finish_star(rec, parallax[i], parallax_err[i],
-                                                    data_coords[i], Nmc_prior, lnprior,
-                                                    wt_thresh, cdf_thresh, lngalprior, None,
-                                                    None, dlabels, avlim, rvlim, mem_lim, rs,
-                                                    False, Ndraws, return_distreds)
-                            continue
-                        if star_out[s, 3] < 1:
-                            raise ValueError("object %d: no model survives the prior "
-                                             "cuts (the reference fails in np.min on an "
-                                             "empty selection, fitting.py:2034)" % i)
-                        v = out_vals[s]
-                        nd = int(ndim[s]) + (1 if np.isfinite(parallax[i])
-                                             and np.isfinite(parallax_err[i]) else 0)
-                        res = (out_idx[s].astype(np.int64), v[:, 0], v[:, 1], v[:, 2],
-                               v[:, 3:12].reshape(-1, 3, 3), nd, v[:, 12],
-                               float(star_out[s, 0]), float(star_out[s, 1]))
-                        if return_distreds:
-                            res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
-                        yield res
+                    for row in rows(a, S, sel_idx, sel_vals, off, ndim, k1, k2, out_idx, out_vals,
+                                    star_out, flags, nbase, ubase0):
+                        yield row
+            if pending is not None:
+                prev, pargs = pending
+                pending = None
+                for row in rows(*(pargs + prev.result() + (0,))):
+                    yield row
         finally:
             if pool is not None:      # also when the caller abandons the generator
                 pool.shutdown(wait=False)
+            if finisher is not None:
+                finisher.shutdown(wait=True)     # a running phase 2 still reads the buffers
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
                             lnprior_ext, offset, wt_thresh):

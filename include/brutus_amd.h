@@ -205,6 +205,24 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
                             int nstream, uint32_t *h_states, double *d_zbuf,
                             size_t zbuf_doubles, void *stream);
 
+/* The same call in two halves, so that a caller can overlap them across batches: the
+ * generator state of a numpy stream is final once the stream has been walked, before
+ * the Monte Carlo integral that consumes the normals.  phase 1 = first and second cut,
+ * covariances, stream walk (h_states advanced; normals and uniforms stay in d_zbuf /
+ * the workspace; fails with BRUTUS_ENOMEM if the objects do not fit d_zbuf as ONE group
+ * -- use the whole-call form then); phase 2 = Monte Carlo integral, evidence, draws,
+ * outputs, with the SAME arguments, workspace and buffer, on any stream / thread, after
+ * phase 1 returned.  phase 0 = brutus_post_batch_numpy. */
+int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+                                  const double *d_sel_vals, const int64_t *d_sel_off,
+                                  const double *d_lnprior, const double *d_feh, const double *d_loga,
+                                  const double *d_coords, const double *d_parallax,
+                                  const double *d_parallax_err, const brutus_post_params *params,
+                                  void *d_workspace, size_t workspace_bytes, int32_t *d_out_idx,
+                                  double *d_out_vals, double *h_star_out, int32_t *h_flags,
+                                  int nstream, uint32_t *h_states, double *d_zbuf,
+                                  size_t zbuf_doubles, int phase, void *stream);
+
 /* Line-of-sight dust prior for the NEXT brutus_post_batch / brutus_post_batch_numpy call
  * of the calling thread (one-shot): the reference's `dust_lnprior` (pdf.py:752-840,
  * Gaussian in Av around the profile interpolated at the distance) with the profile of every

@@ -430,6 +430,12 @@ def test_device_lnpost_with_los_dust_prior_vs_oracle():
         calls["n"] += 1
         return orig(self, *a, **k)
     fitting._Engine.post_batch_device = spy
+    orig_begin = fitting._Engine.post_numpy_begin
+
+    def spy_begin(self, *a, **k):       # the two-phase form of the numpy-stream call
+        calls["n"] += 1
+        return orig_begin(self, *a, **k)
+    fitting._Engine.post_numpy_begin = spy_begin
     try:
         for mk in (lambda: PhiloxRandomState(11), lambda: np.random.RandomState(11)):
             BF.batch_size = 5
@@ -448,3 +454,4 @@ def test_device_lnpost_with_los_dust_prior_vs_oracle():
                 _compare(dev[i], ref, ("dust", i))
     finally:
         fitting._Engine.post_batch_device = orig
+        fitting._Engine.post_numpy_begin = orig_begin

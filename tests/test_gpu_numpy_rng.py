@@ -116,23 +116,35 @@ def test_fit_with_shared_randomstate_on_device_vs_oracle(monkeypatch):
             calls["n"] += 1
         return orig(self, *a, **k)
     monkeypatch.setattr(fitting._Engine, "post_batch_device", spy)
-    rs = np.random.RandomState(2024)
-    rs.normal(size=1)               # a cached deviate is pending when the fit starts
-    ro = np.random.RandomState(2024)
-    ro.normal(size=1)
-    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
-                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
-                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60,
-                       rstate=rs))
-    assert calls["n"] == 3           # 9 objects in batches of 4: all through the device stage
-    for i in range(len(dev)):
-        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
-                         labels, st["coords"][i], st["parallax"][i],
-                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60)
-        assert np.array_equal(dev[i][0], ref[0]), i
-        for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
-            assert relerr(a, b) < 1e-8, (i, n, relerr(a, b))
-    assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
+    # ... or through its two-phase form (phase 2 of a batch beside phase 1 of the next)
+    orig_begin = fitting._Engine.post_numpy_begin
+
+    def spy_begin(self, *a, **k):
+        ok = orig_begin(self, *a, **k)
+        calls["n"] += 1 if ok else 0
+        return ok
+    monkeypatch.setattr(fitting._Engine, "post_numpy_begin", spy_begin)
+    for pipeline in (True, False):
+        BF.post_pipeline = pipeline
+        calls["n"] = 0
+        rs = np.random.RandomState(2024)
+        rs.normal(size=1)               # a cached deviate is pending when the fit starts
+        ro = np.random.RandomState(2024)
+        ro.normal(size=1)
+        dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                           parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                           lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60,
+                           rstate=rs))
+        assert calls["n"] == 3       # 9 objects in batches of 4: all through the device stage
+        for i in range(len(dev)):
+            ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                             labels, st["coords"][i], st["parallax"][i],
+                             st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60)
+            assert np.array_equal(dev[i][0], ref[0]), (pipeline, i)
+            for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
+                assert relerr(a, b) < 1e-8, (pipeline, i, n, relerr(a, b))
+        assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
+    BF.post_pipeline = True
     assert relerr(ro.normal(size=3), rs.normal(size=3)) < 1e-15
 
 
