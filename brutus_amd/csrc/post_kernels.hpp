@@ -689,13 +689,15 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
     __shared__ unsigned int s_item;
-    __shared__ double s_z[TILE / 64][MCA_R * 3 * MCA_NMC];
+    extern __shared__ double s_z[];       // (TILE / 64) tiles of MCA_R * 3 * nmc normals: as
+                                          // little LDS as the call needs, so that the stream
+                                          // walkers of the next batch fit beside this kernel
     stage_exp_table(s_tbl);
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rec8 = lane / MCA_G, grp = lane % MCA_G;
     const int run = 3 * pp.nmc;
-    double *const zt = s_z[w];
+    double *const zt = s_z + (size_t)w * MCA_R * run;
     for (;;) {
         __syncthreads();
         if (threadIdx.x == 0) s_item = (unsigned int)item_base + atomicAdd(counter, 1u);

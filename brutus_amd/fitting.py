@@ -1184,7 +1184,9 @@ class BruteForce(object):
             if pipelined:
                 finisher = concurrent.futures.ThreadPoolExecutor(max_workers=1)
                 fin_stream = torch.cuda.Stream(device=dev)
-                walk_stream = torch.cuda.Stream(device=dev)
+                # phase 1 is a chain of short kernels, small copies and host decisions:
+                # high priority, or each of them queues behind the long phase-2 kernels
+                walk_stream = torch.cuda.Stream(device=dev, priority=-1)
         else:
             engines, streams, pool = (eng, eng), (None, None), None
 
