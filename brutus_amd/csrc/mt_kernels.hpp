@@ -318,49 +318,48 @@ struct MtSub {           // one sub-stream
 };
 
 constexpr int MT_PT = 256;                    // threads of the parallel walkers
-constexpr int MT_PB = 4;                      // blocks per refill
-constexpr int MT_PW = MT_PB * MT_N + 4 * MT_PT;
+constexpr int MT_RB = 4;                      // raw state blocks kept (a ring)
 
-// Sequential word source of a sub-stream for the parallel walkers: `ensure(need)` makes
-// `need` (<= 4 * MT_PT) unread words available at wbuf[rp ..].
+// Sequential word source of a sub-stream for the parallel walkers: a ring of the last
+// MT_RB raw state blocks in LDS; block b (624 words) sits in blk[b % MT_RB], words are
+// tempered when they are consumed.  `rd` = index of the first unread word (counted from
+// the window's first word), `gen` = blocks generated so far: both are uniform values
+// every thread carries in registers -- no cursor in LDS, no copy of the words into a
+// staging buffer, no barrier besides the three of a block step and one in front of it.
 struct MtWalk {
     uint32_t (*blk)[MT_N];
-    uint32_t *wbuf;
-    int *s_nw, *s_rp;
+    int64_t rd;
+    int gen;
     __device__ __forceinline__ void init(const uint32_t *__restrict__ window, int skip) {
-        const int t = threadIdx.x;
-        for (int k = t; k < MT_N; k += MT_PT) blk[MT_PB - 1][k] = window[k];
-        lds_barrier();
-        for (int k = t; k < MT_N - skip; k += MT_PT) wbuf[k] = mt_temper(blk[MT_PB - 1][skip + k]);
-        if (t == 0) {
-            *s_nw = MT_N - skip;
-            *s_rp = 0;
-        }
+        for (int k = threadIdx.x; k < MT_N; k += MT_PT) blk[0][k] = window[k];
+        rd = skip;
+        gen = 1;
         lds_barrier();
     }
+    // make `need` (<= 4 * MT_PT) unread words available
     __device__ __forceinline__ void ensure(int need) {
-        const int t = threadIdx.x;
-        while (*s_nw - *s_rp < need) {
-            const int left = *s_nw - *s_rp, rp = *s_rp;
-            uint32_t keep[4];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) keep[r] = (t + r * MT_PT < left) ? wbuf[rp + t + r * MT_PT] : 0u;
-            lds_barrier();
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                if (t + r * MT_PT < left) wbuf[t + r * MT_PT] = keep[r];
-            mt_next_block(blk[MT_PB - 1], blk[1]);
-            for (int k = t; k < MT_N; k += MT_PT) blk[0][k] = blk[1][k];
-            lds_barrier();
-            for (int b = 1; b < MT_PB; ++b) mt_next_block(blk[b - 1], blk[b]);
-            for (int k = t; k < MT_PB * MT_N; k += MT_PT) wbuf[left + k] = mt_temper(blk[k / MT_N][k % MT_N]);
-            if (t == 0) {
-                *s_nw = left + MT_PB * MT_N;
-                *s_rp = 0;
-            }
-            lds_barrier();
+        while ((int64_t)gen * MT_N - rd < need) {
+            lds_barrier();      // every wave is done with the block this step overwrites
+            mt_next_block(blk[(gen - 1) % MT_RB], blk[gen % MT_RB]);
+            ++gen;
         }
     }
+    // the four words of slot `k` slots after the cursor (k < MT_PT), tempered
+    __device__ __forceinline__ void slot_words(int k, uint32_t (&w)[4]) const {
+        const int64_t w0 = rd + 4 * k;
+        int b = (int)(w0 / MT_N);
+        int off = (int)(w0 - (int64_t)b * MT_N);
+        b %= MT_RB;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            w[q] = mt_temper(blk[b][off]);
+            if (++off == MT_N) {
+                off = 0;
+                b = b + 1 == MT_RB ? 0 : b + 1;
+            }
+        }
+    }
+    __device__ __forceinline__ void consume(int nslot) { rd += 4 * nslot; }
 };
 
 __device__ __forceinline__ double mt_u53(uint32_t a, uint32_t b) {
@@ -372,22 +371,20 @@ __global__ void __launch_bounds__(MT_PT)
 k_mt_bits(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__ windows,
           unsigned long long *__restrict__ bitmap) {
 #pragma clang fp contract(off)
-    __shared__ uint32_t blk[MT_PB][MT_N];
-    __shared__ uint32_t wbuf[MT_PW];
-    __shared__ int s_nw, s_rp;
+    __shared__ uint32_t blk[MT_RB][MT_N];
     const int g = blockIdx.x;
     if (g >= nsub) return;
     const MtSub sb = subs[g];
-    MtWalk wk{blk, wbuf, &s_nw, &s_rp};
+    MtWalk wk{blk, 0, 0};
     wk.init(windows + (int64_t)g * MT_N, sb.skip);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     for (int64_t q = sb.q0; q < sb.q1; q += MT_PT) {
         const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
         wk.ensure(4 * ns);
-        const int rp = s_rp;
         bool acc = false;
         if (t < ns) {
-            const uint32_t *w = wbuf + rp + 4 * t;
+            uint32_t w[4];
+            wk.slot_words(t, w);
             const double x1 = 2.0 * mt_u53(w[0], w[1]) - 1.0, x2 = 2.0 * mt_u53(w[2], w[3]) - 1.0;
             const double r2 = x1 * x1 + x2 * x2;
             acc = r2 < 1.0 && r2 != 0.0;
@@ -395,9 +392,7 @@ k_mt_bits(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
         const unsigned long long bal = __ballot(acc);
         if (lane == 0 && (q - sb.q0) + 64 * wv < sb.q1 - sb.q0)      // words of this sub-stream only
             bitmap[((sb.bit0 + (q - sb.q0)) >> 6) + wv] = bal;
-        lds_barrier();
-        if (t == 0) s_rp = rp + 4 * ns;
-        lds_barrier();
+        wk.consume(ns);
     }
 }
 
@@ -572,10 +567,8 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
           const int64_t *__restrict__ nnorm, const int64_t *__restrict__ zoff,
           double *__restrict__ Z, int nuni, double *__restrict__ U, double *__restrict__ end_gauss) {
 #pragma clang fp contract(off)
-    __shared__ uint32_t blk[MT_PB][MT_N];
-    __shared__ uint32_t wbuf[MT_PW];
-    __shared__ int s_nw, s_rp;
-    __shared__ int wcnt[MT_PT / 64];
+    __shared__ uint32_t blk[MT_RB][MT_N];
+    __shared__ int wcnt[2][MT_PT / 64];
     __shared__ int64_t s_bound[2 * BRUTUS_MAX_BATCH + 1];
     const int g = blockIdx.x;
     if (g >= nsub) return;
@@ -589,7 +582,7 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
         s_bound[2 * k + 1] = objs[o0 + k].y;
     }
     if (t == 0) s_bound[2 * no] = no > 0 ? objs[o0 + no - 1].y + nuni / 2 : 0;
-    MtWalk wk{blk, wbuf, &s_nw, &s_rp};
+    MtWalk wk{blk, 0, 0};
     wk.init(windows + (int64_t)g * MT_N, sb.skip);
     if (sb.q0 >= s_bound[2 * no]) return;              // nothing of this sub-stream is consumed
     // accepted candidates of the stream before slot q0 (q0 is a multiple of 64)
@@ -601,22 +594,23 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
         int cnt = (t < w) ? __popcll(bm[b * 64 + t]) : 0;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
-        if (lane == 0) wcnt[wv] = cnt;
+        if (lane == 0) wcnt[0][wv] = cnt;
         lds_barrier();
-        pcount = pre[sb_lo[st] + st + b] + wcnt[0];     // w < 64: only wave 0 holds counts
+        pcount = pre[sb_lo[st] + st + b] + wcnt[0][0];  // w < 64: only wave 0 holds counts
         lds_barrier();
     }
+    int par = 0;        // wcnt is double-buffered: one barrier per step
     const int64_t qend = sb.q1 < s_bound[2 * no] ? sb.q1 : s_bound[2 * no];
     for (int64_t q = sb.q0; q < qend; q += MT_PT) {
         const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
         wk.ensure(4 * ns);
-        const int rp = s_rp;
         const int64_t myq = q + t;
         bool acc = false, accbit = false;
         double x1 = 0., x2 = 0., r2 = 1., u1 = 0., u2 = 0.;
         int reg = -1;
         if (t < ns) {
-            const uint32_t *w = wbuf + rp + 4 * t;
+            uint32_t w[4];
+            wk.slot_words(t, w);
             u1 = mt_u53(w[0], w[1]);
             u2 = mt_u53(w[2], w[3]);
             x1 = 2.0 * u1 - 1.0;
@@ -634,14 +628,15 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
             }
         }
         const unsigned long long bal = __ballot(accbit);
-        if (lane == 0) wcnt[wv] = __popcll(bal);
+        if (lane == 0) wcnt[par][wv] = __popcll(bal);
         lds_barrier();
         int bef = __popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
 #pragma unroll
         for (int w2 = 0; w2 < MT_PT / 64; ++w2) {
-            bef += w2 < wv ? wcnt[w2] : 0;
-            tot += wcnt[w2];
+            bef += w2 < wv ? wcnt[par][w2] : 0;
+            tot += wcnt[par][w2];
         }
+        par ^= 1;
         if (reg >= 0) {
             const int o = o0 + (reg >> 1);
             if (reg & 1) {
@@ -663,9 +658,7 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
             }
         }
         pcount += tot;
-        lds_barrier();
-        if (t == 0) s_rp = rp + 4 * ns;
-        lds_barrier();
+        wk.consume(ns);
     }
 }
 
