@@ -240,6 +240,22 @@ def phot_loglike(data, data_err, data_mask, models, dim_prior=True):
     return -0.5 * chi2 - 0.5 * (ndim * np.log(2. * np.pi) + np.sum(np.log(var)))
 
 
+def _phot_loglike_many(data, data_err, band_mask, models, dim_prior):
+    """`phot_loglike` for many objects sharing one band mask: `data`, `data_err` (G, Nfilt),
+    `models` (G, Nmodel, Nfilt) -> (G, Nmodel); row g equals
+    `phot_loglike(data[g], data_err[g], band_mask, models[g])` bit for bit."""
+    from scipy.special import gammaln, xlogy
+    m = np.asarray(band_mask, dtype=bool)
+    flux, var = data[:, m], np.square(data_err[:, m])
+    ndim = int(m.sum())
+    resid = flux[:, None, :] - models[:, :, m]
+    chi2 = np.sum(np.square(resid) / var[:, None, :], axis=2)
+    if dim_prior:
+        a = 0.5 * (ndim - 3)
+        return xlogy(a - 1., chi2) - chi2 / 2. - gammaln(a) - np.log(2.) * a
+    return -0.5 * chi2 - 0.5 * (ndim * np.log(2. * np.pi) + np.sum(np.log(var), axis=1)[:, None])
+
+
 def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
                         sel=None, weights=None, mask_fit=None, Nmc=150,
                         old_offsets=None, dim_prior=True, prior_mean=None,
@@ -283,9 +299,15 @@ def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
         if mask_fit[b]:
             others = mask[s].copy()
             others[:, b] = False
-            lnl = np.array([phot_loglike(p * old_offsets, e * old_offsets, m, sd,
-                                         dim_prior=dim_prior)
-                            for p, e, m, sd in zip(phot[s], err[s], others, seds[s])])
+            # the reference evaluates phot_loglike object by object; objects with the same
+            # band pattern are evaluated together here (same sums in the same order)
+            lnl = np.empty((n, Nsamps))
+            pat, inv = np.unique(others, axis=0, return_inverse=True)
+            inv = np.asarray(inv).reshape(-1)
+            for k, m in enumerate(pat):
+                g = np.where(inv == k)[0]
+                lnl[g] = _phot_loglike_many(phot[s[g]] * old_offsets, err[s[g]] * old_offsets,
+                                            m, seds[s[g]], dim_prior)
             wt = np.exp(lnl - logsumexp(lnl, axis=1)[:, None])
         else:
             wt = np.ones((n, Nsamps))
@@ -293,13 +315,27 @@ def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
         wt /= wt.sum(axis=1)[:, None]
         wt_obj = np.array(weights[s].sum(axis=1) > 0, dtype=float)
         wt_obj /= wt_obj.sum()
+        # The reference draws `ridx = choice(n, size=n, p=wt_obj)` and then one
+        # `choice(Nsamps, p=wt[i])` per drawn object: 2 n `random_sample` values in that
+        # order, each turned into an index by `searchsorted(cumsum(p) / cumsum(p)[-1], u,
+        # 'right')` (numpy's legacy `choice`).  Same stream, same indices, without the n
+        # Python-level calls per bootstrap round.
+        cdf_obj = wt_obj.cumsum()
+        cdf_obj /= cdf_obj[-1]
+        cdf = wt.cumsum(axis=1)
+        cdf /= cdf[:, -1:]
+        sample = getattr(rstate, "random_sample", None) or rstate.random
         meds = np.empty(Nmc)
         for j in range(Nmc):
             if verbose:
                 sys.stderr.write('\rBand {0} ({1}/{2})     '.format(b + 1, j + 1, Nmc))
                 sys.stderr.flush()
-            ridx = rstate.choice(n, size=n, p=wt_obj)
-            midx = [rstate.choice(Nsamps, p=w) for w in wt[ridx]]
+            ridx = cdf_obj.searchsorted(sample(n), side='right')
+            u = sample(n)
+            midx = np.empty(n, dtype=np.intp)
+            for lo in range(0, n, 4096):              # bounded temporaries
+                hi = min(n, lo + 4096)
+                midx[lo:hi] = np.sum(cdf[ridx[lo:hi]] <= u[lo:hi, None], axis=1)
             meds[j] = np.median(ratio[ridx, midx])
         ratios[b], ratios_err[b] = np.median(meds), np.std(meds)
     if verbose:

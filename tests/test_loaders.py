@@ -154,3 +154,70 @@ def test_results_file_resume(tmp_path):
     assert list(h5io.read_dataset(path, "samps_logp")[:, 0]) == [10., 11., 22., 23., 24.]
     with pytest.raises(ValueError):
         h5io.ResultsFile.resume(path, 6, 3, True)
+
+
+def test_photometric_offsets_vectorised_equals_call_by_call_form():
+    """The bootstrap of `photometric_offsets` is vectorised (one `random_sample(n)` and a
+    row-wise searchsorted instead of n `RandomState.choice` calls per round, objects with
+    the same band pattern through one `phot_loglike` evaluation): bit-identical to the
+    reference's call-by-call form (utils.py:1330-1385) on a case with mixed band masks,
+    zero-weight objects, a band outside the fit and both likelihood forms."""
+    from scipy.special import logsumexp
+    rng = np.random.RandomState(0)
+    Nobj, Ns, Nf, Nm = 300, 40, 6, 200
+    models = np.zeros((Nm, Nf, 3))
+    models[:, :, 0] = rng.uniform(10, 20, (Nm, Nf))
+    models[:, :, 1] = rng.uniform(0.5, 3, (Nm, Nf))
+    models[:, :, 2] = rng.uniform(0, 0.3, (Nm, Nf))
+    idxs = rng.randint(0, Nm, (Nobj, Ns))
+    reds, dreds = rng.uniform(0, 1, (Nobj, Ns)), rng.uniform(3, 3.6, (Nobj, Ns))
+    dists = rng.uniform(0.5, 3, (Nobj, Ns))
+    seds0 = utils.get_seds(models[idxs[:, 0]], av=reds[:, 0], rv=dreds[:, 0],
+                           return_flux=True) / dists[:, 0, None] ** 2
+    phot = seds0 * (1 + 0.05 * rng.normal(size=seds0.shape))
+    err = 0.05 * phot
+    mask = rng.uniform(size=phot.shape) > 0.15
+    w = rng.uniform(size=(Nobj, Ns))
+    w[5] = 0
+    mask_fit = np.array([1, 1, 0, 1, 1, 1], bool)
+    old = np.linspace(0.98, 1.02, Nf)
+
+    def call_by_call(dim_prior, rstate, Nmc):
+        seds = utils.get_seds(models[idxs.ravel()], av=reds.ravel(), rv=dreds.ravel(),
+                              return_flux=True)
+        seds = (seds / dists.ravel()[:, None] ** 2).reshape(Nobj, Ns, Nf)
+        ratios, errs, nr = np.ones(Nf), np.zeros(Nf), np.zeros(Nf, dtype=int)
+        nbands = mask.sum(axis=1)
+        usable = w.sum(axis=1) > 0
+        for b in range(Nf):
+            s = np.where(mask[:, b] & usable & (nbands > 3 + (1 if mask_fit[b] else 0)))[0]
+            n = nr[b] = len(s)
+            ratio = seds[s, :, b] / phot[s, None, b]
+            if mask_fit[b]:
+                others = mask[s].copy()
+                others[:, b] = False
+                lnl = np.array([utils.phot_loglike(p * old, e * old, m, sd, dim_prior=dim_prior)
+                                for p, e, m, sd in zip(phot[s], err[s], others, seds[s])])
+                wt = np.exp(lnl - logsumexp(lnl, axis=1)[:, None])
+            else:
+                wt = np.ones((n, Ns))
+            wt = wt * w[s]
+            wt /= wt.sum(axis=1)[:, None]
+            wo = np.array(w[s].sum(axis=1) > 0, dtype=float)
+            wo /= wo.sum()
+            meds = np.empty(Nmc)
+            for j in range(Nmc):
+                ridx = rstate.choice(n, size=n, p=wo)
+                midx = [rstate.choice(Ns, p=x) for x in wt[ridx]]
+                meds[j] = np.median(ratio[ridx, midx])
+            ratios[b], errs[b] = np.median(meds), np.std(meds)
+        return ratios, errs, nr
+
+    for dp in (True, False):
+        a = call_by_call(dp, np.random.RandomState(3), 8)
+        b = utils.photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
+                                      weights=w, mask_fit=mask_fit, Nmc=8, old_offsets=old,
+                                      dim_prior=dp, verbose=False,
+                                      rstate=np.random.RandomState(3))
+        for x, y in zip(a, b):
+            assert np.array_equal(x, y), dp
