@@ -1169,6 +1169,13 @@ class BruteForce(object):
         # by float64 issue, the second by LDS and HBM.  Needs a third scan engine, because
         # the records of batch k are still being read when batch k + 2 is scanned.
         pipelined = ahead and np_mode is not None and getattr(self, "post_pipeline", True)
+        if pipelined:
+            # the pipeline holds a third scan workspace and a second post workspace + normal
+            # buffer: only where that clearly fits (a quarter of the device free per slot)
+            free = torch.cuda.mem_get_info(dev)[0]
+            per_engine = eng.L.brutus_workspace_bytes(eng.grid.nmodel, eng.grid.nfilt,
+                                                      eng.batch) + eng.batch * 600000 * 92
+            pipelined = free > 4 * per_engine + (16 << 30)
         nE = 3 if pipelined else 2
         finisher = None
         if ahead:
