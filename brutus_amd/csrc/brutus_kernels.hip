@@ -728,11 +728,37 @@ size_t mt_scratch_bytes(const std::vector<MtPlanStream> &ps, int nobj_total) {
 // Walk the streams of one group with many workgroups.  Returns 0, a negative error, or 1
 // if the generated slots did not suffice / the shape is not supported (caller then uses
 // the sequential k_mt_stream; nothing has been modified).
+// k_mt_emit of a walk whose caller asked for it to be deferred (phase 1 of
+// brutus_post_batch_numpy_phase): everything it reads stays in the caller's buffers.
+struct MtEmitLaunch {
+    int Ktot;
+    const MtSub *subs;
+    const uint32_t *win;
+    const unsigned long long *bits;
+    const int64_t *bitbase, *sblo, *pre;
+    const int32_t *seg;
+    const MtObj *objs;
+    const int64_t *nnorm, *zoff;
+    double *Z;
+    int nuni;
+    double *U, *endgauss;
+};
+std::mutex g_emit_mu;
+std::map<const void *, MtEmitLaunch> g_emit;      // key: the scratch base
+
+void launch_mt_emit(const MtEmitLaunch &e, hipStream_t st, Timer &tm) {
+    tm.begin("k_mt_emit");
+    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)e.Ktot), dim3(MT_PT), 0, st, e.Ktot, e.subs, e.win,
+                       e.bits, e.bitbase, e.sblo, e.pre, e.seg, e.objs, e.nnorm, e.zoff, e.Z, e.nuni,
+                       e.U, e.endgauss);
+    tm.end();
+}
+
 int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states,
                      const std::vector<int> &pos0, const std::vector<int64_t> &nnorm,
                      const int32_t *d_seg, const int64_t *d_nnorm, const int64_t *d_zoff, double *d_Z,
                      int nuni, double *d_U, char *scratch, size_t scratch_bytes, int nobj_total,
-                     hipStream_t st, Timer &tm) {
+                     hipStream_t st, Timer &tm, bool defer_emit) {
     if (nuni & 1) return 1;                      // slot grid needs an even number of uniforms
     std::vector<uint32_t> polys;
     {
@@ -783,6 +809,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     double *d_endgauss = (double *)take(8 * (size_t)nstream);
     int64_t *d_widx = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_skip = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_skipc = (int64_t *)take(8 * (size_t)nstream);
     int32_t *d_fail = (int32_t *)take(256);
     MtObj *d_objs = (MtObj *)take((size_t)nobj_total * sizeof(MtObj));
     // chains
@@ -912,25 +939,34 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     HIP_TRY(hipStreamSynchronize(st));
     if (hfail) return 1;        // not enough slots generated (the resolve wrote only scratch and
                                 // possibly a cached deviate the sequential walk rewrites)
-    // ---- pass 2 -----------------------------------------------------------------------------
-    tm.begin("k_mt_emit");
-    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs, d_win, d_bits,
-                       d_bitbase, d_sblo, d_pre, d_seg, d_objs, d_nnorm, d_zoff, d_Z, nuni, d_U,
-                       d_endgauss);
-    tm.end();
     // ---- states after the last consumed word ---------------------------------------------------
-    std::vector<int64_t> hw(nstream), hs(nstream);
+    // (before pass 2: the boundaries fix the state; a new cached deviate is the f * x1 of the
+    // candidate slot that ends 2 nuni words before the end, which k_mt_advance meets on its
+    // way when it starts from the window holding that slot)
+    std::vector<int64_t> hw(nstream), hs(nstream), hc(nstream);
     for (int g = 0; g < nstream; ++g) {
         const int64_t e = ps[g].pos0 + 4 * hend[g];
-        int64_t k = e / MT_J;
+        const int64_t ec = e - 2 * (int64_t)nuni;
+        int64_t k = (ec - 4 >= 0 ? ec - 4 : 0) / MT_J;
         if (k >= ps[g].K) k = ps[g].K - 1;
         hw[g] = ps[g].base + k;
         hs[g] = e - k * MT_J;
+        hc[g] = ec - k * MT_J;
     }
     HIP_TRY(upv(d_widx, hw.data(), 8 * (size_t)nstream));
     HIP_TRY(upv(d_skip, hs.data(), 8 * (size_t)nstream));
+    HIP_TRY(upv(d_skipc, hc.data(), 8 * (size_t)nstream));
     hipLaunchKernelGGL(k_mt_advance, dim3(nstream), dim3(MT_PT), 0, st, nstream, d_win, d_widx, d_skip,
-                       d_endhasg, d_endgauss, d_endnew, d_states);
+                       d_skipc, d_endhasg, d_endnew, d_endgauss, d_states);
+    // ---- pass 2 -----------------------------------------------------------------------------
+    const MtEmitLaunch el{(int)Ktot, d_subs, d_win, d_bits, d_bitbase, d_sblo, d_pre, d_seg, d_objs,
+                          d_nnorm, d_zoff, d_Z, nuni, d_U, d_endgauss};
+    if (defer_emit) {
+        std::lock_guard<std::mutex> lk(g_emit_mu);
+        g_emit[(const void *)scratch] = el;
+    } else {
+        launch_mt_emit(el, st, tm);
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));        // host vectors go out of scope
     return 0;
@@ -942,11 +978,15 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
 int mt_walk(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states, std::vector<int> &pos0,
             const std::vector<int64_t> &nnorm, const int32_t *d_seg, const int64_t *d_nnorm,
             const int64_t *d_zoff, double *d_Z, int nuni, double *d_U, char *scratch,
-            size_t scratch_bytes, int nobj_total, hipStream_t st, Timer &tm) {
+            size_t scratch_bytes, int nobj_total, hipStream_t st, Timer &tm, bool defer_emit = false) {
     int rc = 1;
+    if (scratch) {
+        std::lock_guard<std::mutex> lk(g_emit_mu);
+        g_emit.erase((const void *)scratch);
+    }
     if (env_int("BRUTUS_MT_PARALLEL", 1) && scratch)
         rc = mt_walk_parallel(nstream, seg, d_states, pos0, nnorm, d_seg, d_nnorm, d_zoff, d_Z, nuni,
-                              d_U, scratch, scratch_bytes, nobj_total, st, tm);
+                              d_U, scratch, scratch_bytes, nobj_total, st, tm, defer_emit);
     if (rc < 0) return rc;
     if (rc == 1) {
         tm.begin("k_mt_stream");
@@ -1552,7 +1592,8 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                 std::vector<int> p0(nseg);
                 for (int q = 0; q < nseg; ++q) p0[q] = hpos[mt->nstream == 1 ? 0 : s0 + q];
                 if (int rc = mt_walk(nseg, segv, d_states, p0, nnorm, w.mt_seg, w.mt_nnorm, w.mt_zoff, zbase,
-                                     nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm))
+                                     nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm,
+                                     phase == 1))
                     return rc;
                 for (int q = 0; q < nseg; ++q) hpos[mt->nstream == 1 ? 0 : s0 + q] = p0[q];
             }
@@ -1564,6 +1605,20 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                 HIP_TRY(hipStreamSynchronize(st));
                 tm.collect();
                 return 0;
+            }
+            if (phase == 2) {       // the pass phase 1 left for us: normals / uniforms to their places
+                MtEmitLaunch el;
+                bool have = false;
+                {
+                    std::lock_guard<std::mutex> lk(g_emit_mu);
+                    auto it = g_emit.find((const void *)mt->d_zbuf);
+                    if (it != g_emit.end()) {
+                        el = it->second;
+                        g_emit.erase(it);
+                        have = true;
+                    }
+                }
+                if (have) launch_mt_emit(el, st, tm);
             }
             tm.begin("k_post_mc");
             {

@@ -662,25 +662,45 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
     }
 }
 
-// state of a stream `skip` words into the given window (pos = 0), in numpy's form
+// State of a stream `skip` words into the given window, in numpy's form.  When the walk
+// leaves a NEW cached deviate behind (gauss_is_new), it is the f * x1 of the candidate slot
+// that ends `skipc` words into the window (the stream's last accepted candidate; the
+// uniforms of the last object follow it): its four words are met on the way and the value
+// is computed here with the expression k_mt_emit uses -- so the state is complete before
+// k_mt_emit runs (which lets a caller start the next batch's walk beside it).
 __global__ void __launch_bounds__(MT_PT)
 k_mt_advance(int nstream, const uint32_t *__restrict__ windows, const int64_t *__restrict__ widx,
-             const int64_t *__restrict__ skip, const int32_t *__restrict__ hasg,
-             const double *__restrict__ gauss_new, const int32_t *__restrict__ gauss_is_new,
-             uint32_t *__restrict__ states) {
+             const int64_t *__restrict__ skip, const int64_t *__restrict__ skipc,
+             const int32_t *__restrict__ hasg, const int32_t *__restrict__ gauss_is_new,
+             double *__restrict__ gauss_new, uint32_t *__restrict__ states) {
+#pragma clang fp contract(off)
     __shared__ uint32_t a[MT_N], b[MT_N];
+    __shared__ uint32_t s_w[4];
     const int st = blockIdx.x, t = threadIdx.x;
     if (st >= nstream) return;
     uint32_t *cur = a, *nxt = b;
     for (int k = t; k < MT_N; k += MT_PT) cur[k] = windows[widx[st] * MT_N + k];
     lds_barrier();
     int64_t r = skip[st];
-    while (r >= MT_N) {
+    const bool want = gauss_is_new[st] != 0;
+    const int64_t c1 = skipc[st];                   // words [c1 - 4, c1) of the window's stream
+    int64_t base = 0;                               // index of cur[0]
+    bool have_prev = false;
+    for (;;) {
+        // the candidate's words: the last one lies in this block, the first possibly in the
+        // previous one (`nxt` after the swap below)
+        if (want && c1 - 1 >= base && c1 - 1 < base + MT_N && t < 4) {
+            const int64_t idx = c1 - 4 + t;
+            s_w[t] = mt_temper(idx >= base ? cur[idx - base] : (have_prev ? nxt[idx - base + MT_N] : 0u));
+        }
+        if (r < MT_N) break;
         mt_next_block(cur, nxt);
         uint32_t *sw = cur;
         cur = nxt;
         nxt = sw;
         r -= MT_N;
+        base += MT_N;
+        have_prev = true;
     }
     uint32_t *stt = states + (int64_t)st * MT_STATE_WORDS;
     double g = __hiloint2double((int)stt[MT_N + 3], (int)stt[MT_N + 2]);
@@ -689,7 +709,13 @@ k_mt_advance(int nstream, const uint32_t *__restrict__ windows, const int64_t *_
     if (t == 0) {
         stt[MT_N] = (uint32_t)r;
         stt[MT_N + 1] = (uint32_t)hasg[st];
-        if (gauss_is_new[st]) g = gauss_new[st];
+        if (want) {
+            const double x1 = 2.0 * mt_u53(s_w[0], s_w[1]) - 1.0, x2 = 2.0 * mt_u53(s_w[2], s_w[3]) - 1.0;
+            const double r2 = x1 * x1 + x2 * x2;
+            const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
+            g = f * x1;
+            gauss_new[st] = g;
+        }
         stt[MT_N + 2] = (uint32_t)__double2loint(g);
         stt[MT_N + 3] = (uint32_t)__double2hiint(g);
     }
