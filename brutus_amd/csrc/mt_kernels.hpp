@@ -328,7 +328,7 @@ constexpr int MT_RB = 4;                      // raw state blocks kept (a ring)
 // staging buffer, no barrier besides the three of a block step and one in front of it.
 struct MtWalk {
     uint32_t (*blk)[MT_N];
-    int64_t rd;
+    int rd;                 // (a sub-stream is 2.1e6 words: 32-bit index arithmetic)
     int gen;
     __device__ __forceinline__ void init(const uint32_t *__restrict__ window, int skip) {
         for (int k = threadIdx.x; k < MT_N; k += MT_PT) blk[0][k] = window[k];
@@ -338,7 +338,7 @@ struct MtWalk {
     }
     // make `need` (<= 4 * MT_PT) unread words available
     __device__ __forceinline__ void ensure(int need) {
-        while ((int64_t)gen * MT_N - rd < need) {
+        while (gen * MT_N - rd < need) {
             lds_barrier();      // every wave is done with the block this step overwrites
             mt_next_block(blk[(gen - 1) % MT_RB], blk[gen % MT_RB]);
             ++gen;
@@ -346,10 +346,10 @@ struct MtWalk {
     }
     // the four words of slot `k` slots after the cursor (k < MT_PT), tempered
     __device__ __forceinline__ void slot_words(int k, uint32_t (&w)[4]) const {
-        const int64_t w0 = rd + 4 * k;
-        int b = (int)(w0 / MT_N);
-        int off = (int)(w0 - (int64_t)b * MT_N);
-        b %= MT_RB;
+        const unsigned w0 = (unsigned)(rd + 4 * k);
+        unsigned bq = w0 / (unsigned)MT_N;
+        int off = (int)(w0 - bq * (unsigned)MT_N);
+        int b = (int)(bq % (unsigned)MT_RB);
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             w[q] = mt_temper(blk[b][off]);
@@ -601,9 +601,23 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
     }
     int par = 0;        // wcnt is double-buffered: one barrier per step
     const int64_t qend = sb.q1 < s_bound[2 * no] ? sb.q1 : s_bound[2 * no];
+    // region of the step's first slot, carried along (regions are millions of slots long:
+    // nearly every step lies inside one, and then region, object and its constants are
+    // uniform instead of a binary search and three loads per lane)
+    int ureg = 0;
+    {
+        int lo = 0, hi = 2 * no;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_bound[mid] <= sb.q0) lo = mid; else hi = mid;
+        }
+        ureg = lo;
+    }
     for (int64_t q = sb.q0; q < qend; q += MT_PT) {
         const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
         wk.ensure(4 * ns);
+        while (ureg + 1 < 2 * no && s_bound[ureg + 1] <= q) ++ureg;
+        const bool one = q + ns <= s_bound[ureg + 1];        // the whole step in region ureg
         const int64_t myq = q + t;
         bool acc = false, accbit = false;
         double x1 = 0., x2 = 0., r2 = 1., u1 = 0., u2 = 0.;
@@ -617,15 +631,17 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
             x2 = 2.0 * u2 - 1.0;
             r2 = x1 * x1 + x2 * x2;
             accbit = r2 < 1.0 && r2 != 0.0;        // the bitmap's bit: every slot counts in the prefix
-            if (myq < s_bound[2 * no]) {
+            if (one) {
+                reg = ureg;
+            } else if (myq < s_bound[2 * no]) {
                 int lo = 0, hi = 2 * no;           // region: largest r with bound[r] <= myq
                 while (hi - lo > 1) {
                     const int mid = (lo + hi) >> 1;
                     if (s_bound[mid] <= myq) lo = mid; else hi = mid;
                 }
                 reg = lo;
-                acc = accbit && !(reg & 1);
             }
+            acc = reg >= 0 && accbit && !(reg & 1);
         }
         const unsigned long long bal = __ballot(accbit);
         if (lane == 0) wcnt[par][wv] = __popcll(bal);
@@ -644,7 +660,7 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
                 if (ui < nuni) U[(int64_t)o * nuni + ui] = u1;
                 if (ui + 1 < nuni) U[(int64_t)o * nuni + ui + 1] = u2;
             } else if (acc) {
-                const MtObj ob = objs[o];
+                const MtObj ob = objs[o];            // (uniform address when `one`: scalar loads)
                 const int64_t m = (pcount + bef) - ob.px;            // pair index in the object
                 const int64_t j = ob.c + 2 * m, n = nnorm[o];
                 const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
