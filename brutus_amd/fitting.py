@@ -261,8 +261,11 @@ class _Engine(object):
         torch, L, g = self.torch, self.L, self.grid
         cap = sel_idx.numel()
         nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
-        if getattr(self, "_post_ws", None) is None or self._post_ws.numel() < nbytes:
-            self._post_ws = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        slot0 = self.__dict__.setdefault("_post_slots", {}).setdefault(0, {})
+        # (one set of buffers with pipeline slot 0: the two forms never run at the same time)
+        if slot0.get("ws") is None or slot0["ws"].numel() < nbytes:
+            slot0["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
+        self._post_ws = slot0["ws"]
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)
         t_coords, t_par, t_perr = dev(coords), dev(parallax), dev(parallax_err)
         out_idx = torch.empty((nstar, pp.ndraws), dtype=torch.int32, device=g.device)
@@ -275,15 +278,15 @@ class _Engine(object):
         if np_states is not None:
             assert np_states.dtype == np.uint32 and np_states.flags.c_contiguous
             while True:
-                zb = getattr(self, "_zbuf", None)
+                zb = slot0.get("zbuf")
                 if zb is None:
                     import os
                     # normals of one group of objects; a 128-object batch of the bench
                     # workload (1.4e5 kept models x 150 normals each) needs ~22 GB + 1/8 scratch
                     free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
                     gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.25 * free))))
-                    zb = self._zbuf = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
-                                                  device=g.device)
+                    zb = slot0["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
+                                                     device=g.device)
                 rc = L.brutus_post_batch_numpy(
                     nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
                     lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
@@ -296,9 +299,9 @@ class _Engine(object):
                         and zb.numel() * 8 < 96 * 2 ** 30:
                     # one object alone exceeds the buffer (the states were not touched): grow
                     n = zb.numel() * 2
-                    self._zbuf = zb = None
+                    slot0["zbuf"] = zb = None
                     torch.cuda.empty_cache()
-                    self._zbuf = torch.empty(n, dtype=torch.float64, device=g.device)
+                    slot0["zbuf"] = torch.empty(n, dtype=torch.float64, device=g.device)
                     continue
                 _lib.check(rc)
                 break
@@ -1172,10 +1175,12 @@ class BruteForce(object):
         if pipelined:
             # the pipeline holds a third scan workspace and a second post workspace + normal
             # buffer: only where that clearly fits (a quarter of the device free per slot)
+            have = (len(getattr(self, "_engine_extra", None) or ()) >= 2
+                    and len(getattr(eng, "_post_slots", None) or ()) >= 2)
             free = torch.cuda.mem_get_info(dev)[0]
             per_engine = eng.L.brutus_workspace_bytes(eng.grid.nmodel, eng.grid.nfilt,
                                                       eng.batch) + eng.batch * 600000 * 92
-            pipelined = free > 4 * per_engine + (16 << 30)
+            pipelined = have or free > 4 * per_engine + (16 << 30)
         nE = 3 if pipelined else 2
         finisher = None
         if ahead:
