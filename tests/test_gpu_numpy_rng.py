@@ -235,3 +235,44 @@ def test_mt_stream_many_workgroups_equals_one_and_numpy():
                 assert np.array_equal(outs["1"][1][o], ur), (nnorm, o)
                 if n:
                     assert relerr(zr, outs["1"][0][o]) < 1e-15
+
+
+def test_small_normal_buffer_falls_back_to_groups(monkeypatch):
+    """A normal buffer that cannot hold a batch as ONE group: phase 1 of the two-phase call
+    declines (nothing consumed), the whole-call form serves the objects in groups -- and,
+    with no room for the parallel walk's scratch, through the one-workgroup stream walker;
+    results and the generator's end state still equal the oracle's."""
+    from brutus_amd import fitting
+    from brutus_amd.galprior import gal_lnprior
+    from oracle import brutus_oracle as O
+    monkeypatch.setenv("BRUTUS_AMD_ZBUF_GB", "0.003")          # ~4e5 doubles
+    BF, models, labels, st, lnprior = _bf(seed=57)
+    BF.batch_size = 5
+    seen = {"begin": [], "whole": 0}
+    ob, ow = fitting._Engine.post_numpy_begin, fitting._Engine.post_batch_device
+
+    def spy_begin(self, *a, **k):
+        ok = ob(self, *a, **k)
+        seen["begin"].append(ok)
+        return ok
+
+    def spy_whole(self, *a, **k):
+        seen["whole"] += 1
+        return ow(self, *a, **k)
+    monkeypatch.setattr(fitting._Engine, "post_numpy_begin", spy_begin)
+    monkeypatch.setattr(fitting._Engine, "post_batch_device", spy_whole)
+    rs, ro = np.random.RandomState(5), np.random.RandomState(5)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60, rstate=rs))
+    # (the first batch of five does not fit; the last four objects do and take the
+    # two-phase form: both forms in one run, in stream order)
+    assert seen["begin"] and seen["begin"][0] is False and seen["whole"] >= 1
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior, labels,
+                         st["coords"][i], st["parallax"][i], st["parallax_err"][i], ro,
+                         gal_lnprior, Nmc_prior=20, Ndraws=60)
+        assert np.array_equal(dev[i][0], ref[0]), i
+        for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
+            assert relerr(a, b) < 1e-8, (i, n, relerr(a, b))
+    assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
