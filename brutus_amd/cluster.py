@@ -190,7 +190,9 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
                 t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
                 ds.t_n.data_ptr(), 1 if dim_prior else 0, ds.ws.data_ptr(), ds.ws.numel(),
                 ds.out.data_ptr(), _stream_ptr(torch)))
-            lnl = ds.out.cpu().numpy()
+            ds.h_out.copy_(ds.out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            lnl = ds.h_out.numpy()
     # ---- outlier mixture (cluster.py:410-414) ---------------------------------------
     with np.errstate(all="ignore"):
         lnl_mix = np.logaddexp(lnl + ln_fin, ds.lnl_outlier + ln_fout)
@@ -261,6 +263,7 @@ def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
         ds.t_cp = torch.empty(Nobjs, dtype=torch.float64, device=dev)
         ds.ws = torch.empty(L.brutus_cluster_workspace_bytes(Nobjs), dtype=torch.uint8, device=dev)
         ds.out = torch.empty(Nobjs, dtype=torch.float64, device=dev)
+        ds.h_out = torch.empty(Nobjs, dtype=torch.float64).pin_memory()
     if cache:
         _lru_put(_DATA_CACHE, key, ds, _DATA_CACHE_MAX)
     return ds
@@ -317,7 +320,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
             else:
                 mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid, **kw)
             mags = np.asarray(mags, dtype=np.float64)
-            mini = np.broadcast_to(np.asarray(mini, dtype=np.float64), (nsmf, neep))
+            mini = np.asarray(mini, dtype=np.float64)
         else:
             mags = h_mags
             mini = np.empty((nsmf, neep))
@@ -325,10 +328,18 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                 seds, params, _ = isochrone.get_seds(smf=smf, **kw)
                 mags[i] = seds
                 mini[i] = params['mini']
-        gmini = np.gradient(mini, axis=1)
-        keep = gmini > 0.
-        keep[1:] &= (eep_grid <= eep_binary_max)[None, :]   # evolved stars: first slice only
-        lnw = np.where(keep, np.log(gmini) + np.log(grad_smf)[:, None], -np.inf)
+        if mini.ndim == 1:      # one mass grid for all slices: 2 000 logarithms, not 30 000
+            gmini = np.gradient(mini)
+            lng = np.where(gmini > 0., np.log(gmini), -np.inf)
+            keep = np.repeat((gmini > 0.)[None, :], nsmf, axis=0)
+            lnw = lng[None, :] + np.log(grad_smf)[:, None]
+        else:
+            gmini = np.gradient(mini, axis=1)
+            keep = gmini > 0.
+            lnw = np.where(keep, np.log(gmini) + np.log(grad_smf)[:, None], -np.inf)
+        late = eep_grid > eep_binary_max                    # evolved stars: first slice only
+        keep[1:, late] = False
+        lnw[1:, late] = -np.inf
     tab = None
     src = np.flatnonzero(keep).astype(np.int32)
     if src.size:

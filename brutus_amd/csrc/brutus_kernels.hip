@@ -1217,7 +1217,7 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
     return 0;
 }
 
-constexpr int CLUSTER_CHUNKS = 64;
+constexpr int CLUSTER_CHUNKS = 256;
 
 size_t brutus_cluster_workspace_bytes(int nobj) {
     if (nobj <= 0) return 0;
@@ -1241,7 +1241,9 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
     double *pm = (double *)d_workspace;
     double *ps = (double *)((char *)d_workspace + align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS));
     hipStream_t st = (hipStream_t)stream;
-    const int ppb = (npts + CLUSTER_CHUNKS - 1) / CLUSTER_CHUNKS;
+    static const int want_chunks = env_int("BRUTUS_CLUSTER_CHUNKS", CLUSTER_CHUNKS);
+    const int use_chunks = want_chunks < 1 ? 1 : (want_chunks > CLUSTER_CHUNKS ? CLUSTER_CHUNKS : want_chunks);
+    const int ppb = (npts + use_chunks - 1) / use_chunks;
     const int nchunk = (npts + ppb - 1) / ppb;
     const dim3 g((nobj + CL_T - 1) / CL_T, nchunk);
     Timer tm(st);
