@@ -328,6 +328,11 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                 seds, params, _ = isochrone.get_seds(smf=smf, **kw)
                 mags[i] = seds
                 mini[i] = params['mini']
+        # the one sizeable host -> device copy of a call starts now, from page-locked
+        # memory, and runs under the host arithmetic below
+        if mags is not h_mags:
+            h_mags[...] = mags
+        stage.d_mags.copy_(stage.h_mags, non_blocking=True)
         if mini.ndim == 1:      # one mass grid for all slices: 2 000 logarithms, not 30 000
             gmini = np.gradient(mini)
             lng = np.where(gmini > 0., np.log(gmini), -np.inf)
@@ -343,12 +348,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     tab = None
     src = np.flatnonzero(keep).astype(np.int32)
     if src.size:
-        # through page-locked staging buffers (kept per table shape): the magnitudes are
-        # the one sizeable host -> device copy of a call
-        if mags is not h_mags:
-            h_mags[...] = mags
         stage.h_lnw.numpy()[...] = lnw.reshape(-1)
-        stage.d_mags.copy_(stage.h_mags, non_blocking=True)
         stage.d_lnw.copy_(stage.h_lnw, non_blocking=True)
         if stage.src is None or not np.array_equal(stage.src, src):
             stage.src, stage.t_src = src, up(src, np.int32)     # the kept rows rarely change
