@@ -728,6 +728,27 @@ size_t mt_scratch_bytes(const std::vector<MtPlanStream> &ps, int nobj_total) {
 // Walk the streams of one group with many workgroups.  Returns 0, a negative error, or 1
 // if the generated slots did not suffice / the shape is not supported (caller then uses
 // the sequential k_mt_stream; nothing has been modified).
+// Page-locked staging for the plan arrays of a walk: one host -> device copy instead of a
+// dozen small ones from pageable vectors (each of which queues behind whatever long kernel
+// another stream has on the device when the phases of two batches overlap).
+struct PinnedBuf {
+    char *p = nullptr;
+    size_t cap = 0;
+    char *get(size_t n) {
+        if (n > cap) {
+            if (p) (void)hipHostFree(p);
+            p = nullptr;
+            cap = 0;
+            const size_t want = (n + ((size_t)1 << 20)) & ~(((size_t)1 << 20) - 1);
+            if (hipHostMalloc((void **)&p, want, hipHostMallocDefault) != hipSuccess) return nullptr;
+            cap = want;
+        }
+        return p;
+    }
+    // (never freed at thread / process exit: the HIP runtime may be gone by then)
+};
+thread_local PinnedBuf g_plan_pin;
+
 // k_mt_emit of a walk whose caller asked for it to be deferred (phase 1 of
 // brutus_post_batch_numpy_phase): everything it reads stays in the caller's buffers.
 struct MtEmitLaunch {
@@ -792,25 +813,22 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         off += (n + 255) & ~(size_t)255;
         return q;
     };
-    uint32_t *d_polys = (uint32_t *)take(polys.size() * 4);
     uint32_t *d_win = (uint32_t *)take((size_t)Ktot * MT_N * 4);
-    MtSub *d_subs = (MtSub *)take((size_t)Ktot * sizeof(MtSub));
     unsigned long long *d_bits = (unsigned long long *)take((size_t)Ttot / 8);
     const int64_t nsb = Ttot / MT_SB;
     uint32_t *d_cnt = (uint32_t *)take((size_t)nsb * 4);
     int64_t *d_pre = (int64_t *)take((size_t)(nsb + nstream + 1) * 8);
-    int64_t *d_base = (int64_t *)take(8 * (size_t)nstream);
-    int64_t *d_bitbase = (int64_t *)take(8 * (size_t)nstream);
-    int64_t *d_sblo = (int64_t *)take(8 * ((size_t)nstream + 1));
-    int64_t *d_tslots = (int64_t *)take(8 * (size_t)nstream);
+    // read back together after k_mt_resolve: [fail | end slots]
+    int32_t *d_fail = (int32_t *)take(256);
     int64_t *d_endslot = (int64_t *)take(8 * (size_t)nstream);
     int32_t *d_endhasg = (int32_t *)take(4 * (size_t)nstream);
     int32_t *d_endnew = (int32_t *)take(4 * (size_t)nstream);
     double *d_endgauss = (double *)take(8 * (size_t)nstream);
+    // uploaded together before k_mt_advance: [window index | skip | skipc]
+    const size_t adv_stride = (8 * (size_t)nstream + 255) & ~(size_t)255;
     int64_t *d_widx = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_skip = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_skipc = (int64_t *)take(8 * (size_t)nstream);
-    int32_t *d_fail = (int32_t *)take(256);
     MtObj *d_objs = (MtObj *)take((size_t)nobj_total * sizeof(MtObj));
     // chains
     std::vector<int64_t> c2s, c2d;
@@ -861,40 +879,49 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         }
     }
     hsblo[nstream] = Ttot / MT_SB;
-    auto upv = [&](void *d, const void *h, size_t n) { return hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, st); };
     const size_t n2 = c2s.size();
     size_t n1tot = 0;
     for (int r = 0; r < 16; ++r) n1tot += r1s[r].size();
+    // ---- the plan block: one contiguous device region, one page-locked mirror, one copy --------
+    const size_t plan0 = off;
+    uint32_t *d_polys = (uint32_t *)take(polys.size() * 4);
+    MtSub *d_subs = (MtSub *)take((size_t)Ktot * sizeof(MtSub));
+    int64_t *d_base = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_bitbase = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_sblo = (int64_t *)take(8 * ((size_t)nstream + 1));
+    int64_t *d_tslots = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_c1s = (int64_t *)take(8 * (n1tot + 1)), *d_c1d = (int64_t *)take(8 * (n1tot + 1));
     int32_t *d_c1n = (int32_t *)take(4 * (n1tot + 1));
     int64_t *d_c2s = (int64_t *)take(8 * (n2 + 1)), *d_c2d = (int64_t *)take(8 * (n2 + 1));
     int32_t *d_c2n = (int32_t *)take(4 * (n2 + 1));
+    const size_t plan_bytes = off - plan0;
     if (off > scratch_bytes) return 1;
-    HIP_TRY(upv(d_polys, polys.data(), polys.size() * 4));
-    HIP_TRY(upv(d_subs, subs.data(), sizeof(MtSub) * (size_t)Ktot));
-    HIP_TRY(upv(d_base, hbase.data(), 8 * (size_t)nstream));
-    HIP_TRY(upv(d_bitbase, hbit.data(), 8 * (size_t)nstream));
-    HIP_TRY(upv(d_sblo, hsblo.data(), 8 * ((size_t)nstream + 1)));
-    HIP_TRY(upv(d_tslots, hT.data(), 8 * (size_t)nstream));
+    char *hp = g_plan_pin.get(plan_bytes);
+    if (!hp) return fail(BRUTUS_ENOMEM, "page-locked staging for the stream plan (%zu bytes)", plan_bytes);
+    auto at = [&](const void *d) { return hp + ((const char *)d - (scratch + plan0)); };
+    memcpy(at(d_polys), polys.data(), polys.size() * 4);
+    memcpy(at(d_subs), subs.data(), sizeof(MtSub) * (size_t)Ktot);
+    memcpy(at(d_base), hbase.data(), 8 * (size_t)nstream);
+    memcpy(at(d_bitbase), hbit.data(), 8 * (size_t)nstream);
+    memcpy(at(d_sblo), hsblo.data(), 8 * ((size_t)nstream + 1));
+    memcpy(at(d_tslots), hT.data(), 8 * (size_t)nstream);
     {
-        std::vector<int64_t> fs, fd;
-        for (int r = 0; r < 16; ++r) {
-            fs.insert(fs.end(), r1s[r].begin(), r1s[r].end());
-            fd.insert(fd.end(), r1d[r].begin(), r1d[r].end());
-        }
-        std::vector<int32_t> ones(n1tot + 1, 1);
-        if (n1tot) {
-            HIP_TRY(upv(d_c1s, fs.data(), 8 * n1tot));
-            HIP_TRY(upv(d_c1d, fd.data(), 8 * n1tot));
-            HIP_TRY(upv(d_c1n, ones.data(), 4 * n1tot));
-            HIP_TRY(hipStreamSynchronize(st));       // fs / fd / ones are locals
-        }
+        int64_t *fs = (int64_t *)at(d_c1s), *fd = (int64_t *)at(d_c1d);
+        int32_t *fn = (int32_t *)at(d_c1n);
+        size_t k = 0;
+        for (int r = 0; r < 16; ++r)
+            for (size_t q = 0; q < r1s[r].size(); ++q, ++k) {
+                fs[k] = r1s[r][q];
+                fd[k] = r1d[r][q];
+                fn[k] = 1;
+            }
     }
     if (n2) {
-        HIP_TRY(upv(d_c2s, c2s.data(), 8 * n2));
-        HIP_TRY(upv(d_c2d, c2d.data(), 8 * n2));
-        HIP_TRY(upv(d_c2n, c2n.data(), 4 * n2));
+        memcpy(at(d_c2s), c2s.data(), 8 * n2);
+        memcpy(at(d_c2d), c2d.data(), 8 * n2);
+        memcpy(at(d_c2n), c2n.data(), 4 * n2);
     }
+    HIP_TRY(hipMemcpyAsync(scratch + plan0, hp, plan_bytes, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemsetAsync(d_fail, 0, 4, st));
     // ---- sub-stream windows by jump-ahead ------------------------------------------------
     tm.begin("k_mt_jump");
@@ -931,19 +958,25 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
                        d_bitbase, d_sblo, d_tslots, d_bits, d_pre, d_zoff, d_Z, d_objs, d_endslot,
                        d_endhasg, d_endnew, d_fail);
     tm.end();
-    int32_t hfail = 0;
-    std::vector<int64_t> hend(nstream);
-    std::vector<int32_t> hhasg(nstream);
-    HIP_TRY(hipMemcpyAsync(&hfail, d_fail, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(hend.data(), d_endslot, 8 * (size_t)nstream, hipMemcpyDeviceToHost, st));
+    // (the plan's page-locked mirror is free again once the stream has passed the copy; it
+    // doubles as the landing zone of [fail | end slots], which are adjacent on the device)
+    const size_t back_bytes = 256 + 8 * (size_t)nstream;
+    char *hb = g_plan_pin.get(back_bytes > plan_bytes ? back_bytes : plan_bytes);
+    if (!hb) return fail(BRUTUS_ENOMEM, "page-locked staging");
+    HIP_TRY(hipMemcpyAsync(hb, d_fail, back_bytes, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
+    const int32_t hfail = *(const int32_t *)hb;
+    std::vector<int64_t> hend(nstream);
+    memcpy(hend.data(), hb + 256, 8 * (size_t)nstream);
     if (hfail) return 1;        // not enough slots generated (the resolve wrote only scratch and
                                 // possibly a cached deviate the sequential walk rewrites)
     // ---- states after the last consumed word ---------------------------------------------------
     // (before pass 2: the boundaries fix the state; a new cached deviate is the f * x1 of the
     // candidate slot that ends 2 nuni words before the end, which k_mt_advance meets on its
     // way when it starts from the window holding that slot)
-    std::vector<int64_t> hw(nstream), hs(nstream), hc(nstream);
+    char *ha = g_plan_pin.get(3 * adv_stride);
+    if (!ha) return fail(BRUTUS_ENOMEM, "page-locked staging");
+    int64_t *hw = (int64_t *)ha, *hs = (int64_t *)(ha + adv_stride), *hc = (int64_t *)(ha + 2 * adv_stride);
     for (int g = 0; g < nstream; ++g) {
         const int64_t e = ps[g].pos0 + 4 * hend[g];
         const int64_t ec = e - 2 * (int64_t)nuni;
@@ -953,9 +986,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         hs[g] = e - k * MT_J;
         hc[g] = ec - k * MT_J;
     }
-    HIP_TRY(upv(d_widx, hw.data(), 8 * (size_t)nstream));
-    HIP_TRY(upv(d_skip, hs.data(), 8 * (size_t)nstream));
-    HIP_TRY(upv(d_skipc, hc.data(), 8 * (size_t)nstream));
+    HIP_TRY(hipMemcpyAsync(d_widx, ha, 3 * adv_stride, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_mt_advance, dim3(nstream), dim3(MT_PT), 0, st, nstream, d_win, d_widx, d_skip,
                        d_skipc, d_endhasg, d_endnew, d_endgauss, d_states);
     // ---- pass 2 -----------------------------------------------------------------------------
