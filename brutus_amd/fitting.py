@@ -24,6 +24,8 @@ import sys
 import time
 import warnings
 
+import os
+
 import numpy as np
 
 from . import _lib
@@ -755,7 +757,8 @@ class BruteForce(object):
         #: device `lnpost` mode: scan batch k+1 on a second stream while `lnpost`
         #: of batch k runs (costs a second workspace)
         self.scan_ahead = True
-        self.post_pipeline = True      # numpy streams: phase 2 of batch k beside phase 1 of k + 1
+        # numpy streams: phase 2 of batch k beside phase 1 of k + 1 (BRUTUS_POST_PIPELINE=0: off)
+        self.post_pipeline = os.environ.get("BRUTUS_POST_PIPELINE", "1") != "0"
         # `lnpost` on the device also for numpy's own random stream (RandomState / None)
         self.device_numpy_rng = True
 
