@@ -276,3 +276,38 @@ def test_small_normal_buffer_falls_back_to_groups(monkeypatch):
         for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
             assert relerr(a, b) < 1e-8, (i, n, relerr(a, b))
     assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
+
+
+def test_full_size_fit_with_numpy_stream_vs_oracle():
+    """The bench's size and fit()'s defaults (750k x 12, Nmc_prior=50, Ndraws=250: ~10^5
+    kept models and ~2 10^7 normals per object, i.e. many jump-ahead sub-streams) with ONE
+    numpy RandomState over three objects in batches of two (two-phase form, a stream that
+    continues across batches): resampled indices bit-exact against the oracle -- C `loglike`
+    followed by the numpy `lnpost` drawing from numpy itself -- and the same end state."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from oracle import brutus_oracle as O
+    from oracle import c_oracle
+    models, labels, lmask = synth.make_mist_like_grid(750000, 12)
+    st = synth.make_stars(models, 3, seed=2)
+    lnprior = O.static_lnprior(labels, lmask)
+    BF = fitting.BruteForce(models, labels, lmask)
+    BF.batch_size = 2
+    rs, ro = np.random.RandomState(99), np.random.RandomState(99)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], rstate=rs,
+                       Nmc_prior=50, Ndraws=250))
+    py_loglike = O.loglike
+    O.loglike = lambda *a, return_vals=True, **k: c_oracle.loglike(*a, **k)
+    try:
+        for i in range(3):
+            ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                             labels, st["coords"][i], st["parallax"][i],
+                             st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=50, Ndraws=250)
+            assert np.array_equal(dev[i][0], ref[0]), "resampled indices, object %d" % i
+            for n, a, b in zip(NAMES[1:], ref[1:], dev[i][1:]):
+                assert relerr(a, b) < 1e-6, (i, n, relerr(a, b))
+    finally:
+        O.loglike = py_loglike
+    assert np.array_equal(rs.random_sample(5), ro.random_sample(5))
