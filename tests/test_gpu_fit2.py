@@ -185,3 +185,30 @@ def test_many_sweeps_star_is_not_an_error():
             assert np.max(np.abs(lnl[sel] - rec["lnlike"])) < 1e-7
             k1s.append(tr["K1"])
     assert max(k1s) > 8, k1s      # the case the old 8-sweep cap rejected
+
+
+def test_record_buffer_regrowth_replays_select_and_emit():
+    """Record buffers too small for a batch: `records_device` grows them and
+    `brutus_fit_gather` replays selection + emit from the workspace (survivor tags in the
+    float32 plane, staged flux-phase results, candidate offsets) without redoing the scan;
+    the records equal those of a run whose buffers were large enough from the start."""
+    import torch
+    from brutus_amd import fitting, synth
+    models, _, _ = synth.make_mist_like_grid(60000, 12, seed=4)
+    st = synth.make_stars(models, 12, seed=5)
+    grid = fitting.DeviceGrid(models)
+    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18),
+                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    ref = fitting._Engine(grid, max_batch=12).fit_batch(
+        st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"], params)
+    eng = fitting._Engine(grid, max_batch=12)
+    up = eng._upload(st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"])
+    eng._sel_bufs = (torch.empty(1000, dtype=torch.int32, device=grid.device),
+                     torch.empty((11, 1000), dtype=torch.float64, device=grid.device))
+    sel_idx, sel_vals, sel_off, off, ndim, k1, k2 = eng.records_device(*up, params)
+    assert sel_idx.numel() > 1000 and int(off[-1]) == sum(len(r["sel"]) for r in ref)
+    for s, r in enumerate(ref):
+        got = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
+        assert np.array_equal(got["sel"], r["sel"]), s
+        for k in ("lnlike", "chi2", "scale", "av", "rv", "icov"):
+            assert np.array_equal(got[k], r[k]), (s, k)
