@@ -63,7 +63,7 @@ def parse():
                     help="host threads / HIP streams per GPU, each with its own "
                          "workspace, taking the steps round-robin (kernels of "
                          "consecutive batches overlap on the device)")
-    ap.add_argument("--e2e-stars", type=int, default=1024,
+    ap.add_argument("--e2e-stars", type=int, default=2048,
                     help="stars of the sequential-RandomState end-to-end BruteForce.fit() "
                          "leg reported beside the metric (0 = skip all end-to-end legs); "
                          "rank 0, N=1 only")
