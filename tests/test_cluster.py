@@ -138,3 +138,26 @@ def test_batched_plugin_hook_and_caches_change_nothing():
     phot2[5, 3] *= 1.5
     b = cluster.isochrone_loglike(THETA, iso, phot2, err, **kw)
     assert a[1][5] != b[1][5] and np.array_equal(np.delete(a[1], 5), np.delete(b[1], 5))
+
+
+def test_cache_keys_follow_content_not_identity():
+    """The cluster caches are keyed by address, layout and a digest of the CONTENT of the
+    catalogue arrays (CPU-only check of the helpers): an in-place edit, a copy, a view with
+    other strides and None all give distinct / equal keys as they should; the LRU keeps the
+    most recently used entries."""
+    import collections
+    from brutus_amd import cluster
+    a = np.arange(60, dtype=float).reshape(5, 12)
+    k0 = cluster._fingerprint(a)
+    assert cluster._fingerprint(a) == k0 and cluster._fingerprint(None) is None
+    b = a.copy()
+    assert cluster._fingerprint(b) != k0 and cluster._fingerprint(b)[3] == k0[3]   # other address, same digest
+    a[2, 3] += 1.
+    assert cluster._fingerprint(a) != k0                                           # same address, new content
+    assert cluster._fingerprint(a[:, ::2])[2] != cluster._fingerprint(a)[2]
+    lru = collections.OrderedDict()
+    for k in range(4):
+        cluster._lru_put(lru, k, str(k), 3)
+    assert list(lru) == [1, 2, 3] and cluster._lru_get(lru, 1) == "1" and list(lru) == [2, 3, 1]
+    cluster._lru_put(lru, 9, "9", 3)
+    assert list(lru) == [3, 1, 9] and cluster._lru_get(lru, 2) is None
