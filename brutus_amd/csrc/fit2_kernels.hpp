@@ -154,14 +154,18 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     __shared__ float slot[4][G * NV32];
     const float C10 = -1.32877123795494494f;     // -0.4 log2(10)
     const float NINF = -INFINITY;
-    const int g0 = blockIdx.y * G;
+    // star group = the FAST block index: consecutive workgroups take the same eight tiles
+    // for different star groups, so a tile is fetched from the fabric once per XCD instead
+    // of once per star group (the grid is read by nrun / G groups)
+    const int bx = blockIdx.y;                 // tile chunk
+    const int g0 = blockIdx.x * G;
     const int ng = min(G, nrun - g0);
     float mx[G][NV32];
 #pragma unroll
     for (int g = 0; g < G; ++g)
 #pragma unroll
         for (int v = 0; v < NV32; ++v) mx[g][v] = NINF;
-    const int t0 = blockIdx.x * F2_T;
+    const int t0 = bx * F2_T;
     const int t1 = min(ntile, t0 + F2_T);
     const float inv_nf = 1.f / (float)p.nfilt;
     for (int t = t0; t < t1; ++t) {
@@ -383,7 +387,7 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             const int s = star_ids[g0 + g];
             const float x = fmaxf(fmaxf(slot[0][threadIdx.x], slot[1][threadIdx.x]),
                                   fmaxf(slot[2][threadIdx.x], slot[3][threadIdx.x]));
-            part[((int64_t)blockIdx.x * nstar + s) * NV32 + v] = x;
+            part[((int64_t)bx * nstar + s) * NV32 + v] = x;
         }
     }
 }
