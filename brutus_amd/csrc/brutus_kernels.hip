@@ -86,7 +86,8 @@ struct Workspace {
     double *thr_cull, *maxns, *maxns_part, *maxsurv, *thr_sel;
     int32_t *surv_idx;  // (S * nmodel,) worst case
     int64_t *surv_off;  // (S + 1,)
-    int32_t *wbase_surv, *wbase_sel;   // (S + 1,)
+    int32_t *wbase_surv, *wbase_sel;   // (NCHUNK * S + 1,): chunk-major work items
+    ItemGeom *items_surv, *items_sel;  // one record per work item
     int32_t *bandn;                    // (S * NCHUNK,) band-queue fill of k_sel_classify
     unsigned long long *mask;          // (S, nmodel_pad / 64) membership words
     // second-generation path (fit2_kernels.hpp)
@@ -149,8 +150,13 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         w.thr_sel = (double *)take(sizeof(double) * nstar);
         w.surv_idx = (int32_t *)take(sizeof(int32_t) * (size_t)nstar * (size_t)nmodel);
         w.surv_off = (int64_t *)take(sizeof(int64_t) * (nstar + 1));
-        w.wbase_surv = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
-        w.wbase_sel = (int32_t *)take(sizeof(int32_t) * (nstar + 1));
+        w.wbase_surv = (int32_t *)take(sizeof(int32_t) * ((size_t)NCHUNK * nstar + 1));
+        w.wbase_sel = (int32_t *)take(sizeof(int32_t) * ((size_t)NCHUNK * nstar + 1));
+        {
+            const size_t nit = (size_t)nstar * ((size_t)(pad_models(nmodel) / TILE) + NCHUNK);
+            w.items_surv = (ItemGeom *)take(sizeof(ItemGeom) * nit);
+            w.items_sel = (ItemGeom *)take(sizeof(ItemGeom) * nit);
+        }
         w.bandn = (int32_t *)take(sizeof(int32_t) * (size_t)NCHUNK * nstar);
         w.mask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
                                             (size_t)(pad_models(nmodel) / 64));
@@ -341,16 +347,16 @@ template <int NB, bool RVF>
 void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, int64_t nmodel_pad,
                   int nstar, const StarPrep *stars, const DevParams &p, const int32_t *k1,
                   const int32_t *k2, const int32_t *surv_idx, const int64_t *surv_off,
-                  const int32_t *wbase, const Planes &pl, double *part, float *surv32,
-                  const double *thr_cull) {
+                  const int32_t *wbase, const ItemGeom *items, const Planes &pl, double *part,
+                  float *surv32, const double *thr_cull) {
     if (first)
         hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
-                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase, pl,
-                           part, surv32, thr_cull);
+                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase,
+                           items, pl, part, surv32, thr_cull);
     else
         hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
-                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase, pl,
-                           part, surv32, thr_cull);
+                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase,
+                           items, pl, part, surv32, thr_cull);
 }
 
 template <int NB, int KS, int G, bool RVF>
@@ -390,13 +396,15 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     // path 2: k_sel_classify / k_sel_band have left the membership words and the chunk counts
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts,
                        w.offsets, d_sel_off, w.wbase_sel);
+    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_sel,
+                       w.offsets, d_sel_off, w.items_sel);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
                        w.mask, w.offsets, capacity, d_sel_idx);
     tm.end();
     tm.begin("k_emit");
     hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                        nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
-                       w.wbase_sel, w.pl, capacity, d_sel_vals,
+                       w.wbase_sel, w.items_sel, w.pl, capacity, d_sel_vals,
                        path == 2 ? (const float *)w.lnlp32 : (const float *)nullptr, w.surv_off);
     tm.end();
     HIP_TRY(hipGetLastError());
@@ -452,6 +460,8 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
                        w.thr_cull, w.pl.lnprob, w.counts, w.maxns_part, w.mask);
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
                        w.surv_off, w.wbase_surv);
+    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_surv,
+                       w.offsets, w.surv_off, w.items_surv);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
                        w.mask, w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
     tm.end();
@@ -464,7 +474,7 @@ int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, i
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
         launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
-                              w.surv_idx, w.surv_off, w.wbase_surv, w.pl, w.part, (float *)nullptr,
+                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, (float *)nullptr,
                               (const double *)nullptr);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
@@ -627,6 +637,8 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
                        w.counts, w.smask);
     hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
                        w.surv_off, w.wbase_surv);
+    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_surv,
+                       w.offsets, w.surv_off, w.items_surv);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.smask,
                        w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
     tm.end();
@@ -639,7 +651,8 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
         launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
-                              w.surv_idx, w.surv_off, w.wbase_surv, w.pl, w.part, w.lnlp32, w.thr_cull);
+                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, w.lnlp32,
+                              w.thr_cull);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);

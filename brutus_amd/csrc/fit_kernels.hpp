@@ -542,31 +542,48 @@ k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
 }
 
 // Exclusive scan of counts[(s, c)] in (s, c) order; one workgroup, thread s owns star s.
-//   offsets[(s, c)], star_off[s] (star_off[nstar] = total), wbase[s] = first work
-//   item of star s when its list is cut into TILE-sized work items (wbase[nstar] = #items).
+//   offsets[(s, c)], star_off[s] (star_off[nstar] = total).
+// Work items of the list kernels (k_fflux, k_emit): the segment of star s in model chunk c,
+// cut into pieces of TILE entries, numbered CHUNK-MAJOR: wbase[c * nstar + s] = first item
+// of that segment, wbase[NCHUNK * nstar] = #items.  Workgroups that run at the same time
+// then work on the same 1/NCHUNK of the grid for different stars, and the coefficient rows
+// they gather are L2 hits instead of one fabric read per star.
 __global__ void k_offsets(int nstar, const int64_t *__restrict__ counts,
                           int64_t *__restrict__ offsets, int64_t *__restrict__ star_off,
                           int32_t *__restrict__ wbase) {
     __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
+    __shared__ int32_t crow[NCHUNK + 1];
     const int s = threadIdx.x;
     int64_t n = 0;
     if (s < nstar)
         for (int c = 0; c < NCHUNK; ++c) n += counts[(int64_t)s * NCHUNK + c];
     if (s < nstar) tot[s] = n;
+    // items of chunk row c over all stars (thread c)
+    if (wbase && s < NCHUNK) {
+        int32_t m = 0;
+        for (int q = 0; q < nstar; ++q) m += (int32_t)((counts[(int64_t)q * NCHUNK + s] + TILE - 1) / TILE);
+        crow[s] = m;
+    }
     __syncthreads();
     if (s == 0) {
         int64_t run = 0;
-        int32_t w = 0;
         for (int q = 0; q < nstar; ++q) {
             const int64_t m = tot[q];
             tot[q] = run;
             star_off[q] = run;
-            if (wbase) wbase[q] = w;
             run += m;
-            w += (int32_t)((m + TILE - 1) / TILE);
         }
         star_off[nstar] = run;
-        if (wbase) wbase[nstar] = w;
+        if (wbase) {
+            int32_t w = 0;
+            for (int c = 0; c < NCHUNK; ++c) {
+                const int32_t m = crow[c];
+                crow[c] = w;
+                w += m;
+            }
+            crow[NCHUNK] = w;
+            wbase[NCHUNK * nstar] = w;
+        }
     }
     __syncthreads();
     if (s < nstar) {
@@ -574,6 +591,13 @@ __global__ void k_offsets(int nstar, const int64_t *__restrict__ counts,
         for (int c = 0; c < NCHUNK; ++c) {
             offsets[(int64_t)s * NCHUNK + c] = run;
             run += counts[(int64_t)s * NCHUNK + c];
+        }
+    }
+    if (wbase && s < NCHUNK) {
+        int32_t w = crow[s];
+        for (int q = 0; q < nstar; ++q) {
+            wbase[s * nstar + q] = w;
+            w += (int32_t)((counts[(int64_t)q * NCHUNK + s] + TILE - 1) / TILE);
         }
     }
 }
@@ -619,14 +643,30 @@ __device__ __forceinline__ bool surv_is(float x) {
 }
 __device__ __forceinline__ int surv_slot(float x) { return __float_as_int(x) - 1; }
 
-// Map a work item (TILE consecutive entries of one star's compact list) to its star.
-__device__ __forceinline__ int star_of_item(const int32_t *__restrict__ wbase, int nstar, int item) {
-    int lo = 0, hi = nstar;   // largest s with wbase[s] <= item
-    while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (wbase[mid] <= item) lo = mid; else hi = mid;
+// A work item -> its star and the list positions [q0, q0 + n) it covers (k_offsets: items
+// are pieces of (star, chunk) segments, numbered chunk-major).
+struct ItemGeom {
+    int64_t q0;
+    int32_t s, n;
+};
+// one record per work item, written by the segments' owners (a 13-step search over the
+// segment table per item costs the list kernels 10 %)
+__global__ void k_items(int nstar, const int32_t *__restrict__ wbase,
+                        const int64_t *__restrict__ offsets, const int64_t *__restrict__ star_off,
+                        ItemGeom *__restrict__ items) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= NCHUNK * nstar) return;
+    const int c = e / nstar, s = e - c * nstar;
+    const int64_t start = offsets[(int64_t)s * NCHUNK + c];
+    const int64_t end = c + 1 < NCHUNK ? offsets[(int64_t)s * NCHUNK + c + 1] : star_off[s + 1];
+    const int first = wbase[e], np = wbase[e + 1] - first;
+    for (int k = 0; k < np; ++k) {
+        ItemGeom g;
+        g.q0 = start + (int64_t)k * TILE;
+        g.s = s;
+        g.n = (int)(end - g.q0 < TILE ? end - g.q0 : TILE);
+        items[first + k] = g;
     }
-    return lo;
 }
 
 // Coefficients of ONE model from the model-major copy: 3*NB/4 16-byte loads.
@@ -668,13 +708,13 @@ __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
         const int32_t *__restrict__ k2state, const int32_t *__restrict__ surv_idx,
-        const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase, Planes pl,
-        double *__restrict__ part, float *__restrict__ surv32,
-        const double *__restrict__ thr_cull) {
+        const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase,
+        const ItemGeom *__restrict__ items, Planes pl, double *__restrict__ part,
+        float *__restrict__ surv32, const double *__restrict__ thr_cull) {
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
-    const int nitem = wbase[nstar];
+    const int nitem = wbase[NCHUNK * nstar];
     // (the launch kind is a template parameter: the opening launch then carries no
     // state-reload path and its two iterations unroll)
     constexpr int niter = FIRST ? 2 : 1;
@@ -682,20 +722,21 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     // item's last entry: no select on the loaded value, so nothing waits for it here)
     auto lane_model = [&](int item) -> int32_t {
         if (item >= nitem) return 0;
-        const int s = star_of_item(wbase, nstar, item);
-        const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
-        const int64_t last = surv_off[s + 1] - 1;
+        const ItemGeom ig = items[item];
+        const int64_t q = ig.q0 + threadIdx.x;
+        const int64_t last = ig.q0 + ig.n - 1;
         return surv_idx[q < last ? q : last];
     };
     int32_t i_nxt = lane_model(blockIdx.x);
     for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
-        const int s = star_of_item(wbase, nstar, item);
+        const ItemGeom ig = items[item];
+        const int s = ig.s;
         const int32_t i_me = i_nxt;
         i_nxt = lane_model(item + gridDim.x);
         if (k2state[s] < 0) continue;
         const StarPrep &sp = stars[s];
-        const int64_t q = surv_off[s] + (int64_t)(item - wbase[s]) * TILE + threadIdx.x;
-        const bool live = q < surv_off[s + 1];
+        const int64_t q = ig.q0 + threadIdx.x;
+        const bool live = (int)threadIdx.x < ig.n;
         double L = -INFINITY, T = -INFINITY, M = -INFINITY;
         bool go = live;
         int64_t i = 0, o = 0;
@@ -812,11 +853,14 @@ __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
     if (k2state[s] < 0) return;
     double v[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int per = TILE / 64;       // k_fflux leaves one partial per wave
-    for (int it = wbase[s] * per + threadIdx.x; it < wbase[s + 1] * per; it += blockDim.x)
-        for (int q = 0; q < 3; ++q) {
-            const double x = part[(int64_t)it * 3 + q];
-            v[q] = x > v[q] ? x : v[q];
-        }
+    for (int c = 0; c < NCHUNK; ++c) {      // the star's items: one run per model chunk
+        const int e = c * nstar + s;
+        for (int it = wbase[e] * per + threadIdx.x; it < wbase[e + 1] * per; it += blockDim.x)
+            for (int q = 0; q < 3; ++q) {
+                const double x = part[(int64_t)it * 3 + q];
+                v[q] = x > v[q] ? x : v[q];
+            }
+    }
     for (int q = 0; q < 3; ++q) {
         const double m = wave_max(v[q]);
         if ((threadIdx.x & 63) == 0) sm[q][threadIdx.x >> 6] = m;
@@ -867,8 +911,9 @@ __global__ void __launch_bounds__(TILE, 2)
 k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
        const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
        const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
-       const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase, Planes pl,
-       int64_t capacity, double *__restrict__ sel_vals, const float *__restrict__ surv32,
+       const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase,
+       const ItemGeom *__restrict__ items, Planes pl, int64_t capacity,
+       double *__restrict__ sel_vals, const float *__restrict__ surv32,
        const int64_t *__restrict__ cand_off) {
     constexpr int NW = TILE / 64;
     __shared__ double s_tbl[64];
@@ -878,7 +923,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
     __shared__ int16_t s_pd[NW][TILE];      // ... of the re-derived entries
     stage_exp_table(s_tbl);
     __syncthreads();
-    const int nitem = wbase[nstar];
+    const int nitem = wbase[NCHUNK * nstar];
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const uint64_t below = (1ull << lane) - 1ull;
@@ -888,10 +933,11 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
         q0 = 0;
         n = 0;
         if (item >= nitem) return;
-        s = star_of_item(wbase, nstar, item);
-        q0 = sel_off[s] + (int64_t)(item - wbase[s]) * TILE;
-        const int64_t lim = sel_off[s + 1] < capacity ? sel_off[s + 1] : capacity;
-        n = (int)(lim - q0 < TILE ? lim - q0 : TILE);
+        const ItemGeom ig = items[item];
+        s = ig.s;
+        q0 = ig.q0;
+        const int64_t room = capacity - q0;          // a record buffer too small: drop the rest
+        n = (int)(room < ig.n ? room : ig.n);
         n = n > 0 ? n : 0;
     };
     // the entries' models / their kind words (survivor tag, see surv_tag; path 1: 1 or -0.)
