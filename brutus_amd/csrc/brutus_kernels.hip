@@ -405,7 +405,7 @@ int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParam
     hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
                        nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
                        w.wbase_sel, w.items_sel, w.pl, capacity, d_sel_vals,
-                       path == 2 ? (const float *)w.lnlp32 : (const float *)nullptr, w.surv_off);
+                       path == 2 ? (const float *)w.lnpr32 : (const float *)nullptr, w.surv_off);
     tm.end();
     HIP_TRY(hipGetLastError());
     return 0;
@@ -651,7 +651,7 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
         launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
-                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, w.lnlp32,
+                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, w.lnpr32,
                               w.thr_cull);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
@@ -670,12 +670,12 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
     tm.begin("k_top");
     hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
                        nmodel_pad, nstar, nstar, w.ids_all, w.stars, p, w.k1, ntile, 1, w.lnpr32,
-                       w.nomB, w.lnlp32, w.part32, w.part, aud ? aud + nstar : nullptr);
+                       w.nomB, w.lnpr32, w.part32, w.part, aud ? aud + nstar : nullptr);
     tm.end();
     hipLaunchKernelGGL(k_top_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids_all, 1, w.part,
                        w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
     tm.begin("k_sel_classify");
-    hipLaunchKernelGGL(k_sel_classify, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.s32, w.lnlp32,
+    hipLaunchKernelGGL(k_sel_classify, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.s32,
                        w.lnpr32, w.pl.lnprob, w.surv_off, w.thr_sel, w.counts, w.mask, w.surv_idx,
                        w.bandn);
     tm.end();

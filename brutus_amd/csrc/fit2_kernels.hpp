@@ -21,7 +21,7 @@
 //   k_fflux    (fit_kernels.hpp, second-generation mode) exact cull test in float64, flux
 //              iterations for the survivors; results staged in candidate-list order
 //              (full-line writes, dense read-back), the survivor's list position left as
-//              a tag in the lnl_p~ plane (surv_tag), -inf for a failed candidate.
+//              a tag in the lnprob~ plane (surv_tag).
 //   k_top (B)  exact maximum of lnprob over the non-survivors that could exceed the
 //              survivors' maximum  ->  EXACT first-cut threshold.
 //   k_sel_classify + k_sel_band
@@ -520,7 +520,7 @@ __device__ __forceinline__ int64_t mword(int s, int ntile, int t, int w) {
 // ---------------------------------------------------------------------------
 // mode 0: nominees = !(lnlp32 < nom[s])                          -> max lnl_p
 // mode 1: nominees = non-survivors with !(lnpr32 < nom[s])       -> max lnprob (mag-phase value)
-//         (survivors carry a tag in the lnl_p~ plane, see surv_tag)
+//         (survivors carry a tag in that plane, see surv_tag)
 // A (block, star) whose float32 block maximum (part32 column 6 + mode) is below nom[s]
 // and that holds no NaN lane is skipped outright.
 // part[(bx * nstar + s)] = block maximum (-inf if no nominee)
@@ -671,7 +671,7 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 // ---------------------------------------------------------------------------
 // k_sel_classify + k_sel_band: the first cut of lnpost as a bit-mask (fitting.py:976-991)
 // ---------------------------------------------------------------------------
-// grid = (NCHUNK, nstar), one star per workgroup.  Survivors (tagged in the lnl_p~ plane)
+// grid = (NCHUNK, nstar), one star per workgroup.  Survivors (tagged in the lnprob~ plane)
 // are tested on their final float64 lnprob (staged in candidate order); the rest on
 // lnprob~ with the margin eps.
 // Models inside the band |lnprob~ - thr| <= eps (or NaN) go to the block's region of
@@ -680,7 +680,7 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 // the membership words.  Outputs as k_cmp_count: membership words + per-chunk counts.
 __global__ void __launch_bounds__(TILE)
 k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
-               const float *__restrict__ lnlp32, const float *__restrict__ lnpr32,
+               const float *__restrict__ lnpr32,
                const double *__restrict__ lnprob_st, const int64_t *__restrict__ cand_off,
                const double *__restrict__ thr_sel,
                int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
@@ -698,12 +698,11 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
     int n = 0;
     constexpr int U = 4;      // tiles in flight per lane
     for (int tb = t0; tb < t1; tb += U) {
-        float a[U], v32[U];
+        float v32[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t i = (int64_t)(tb + u) * TILE + threadIdx.x;
             const bool in = tb + u < t1 && i < nmodel;
-            a[u] = in ? lnlp32[(int64_t)s * nmodel + i] : -INFINITY;
             v32[u] = in ? lnpr32[(int64_t)s * nmodel + i] : -INFINITY;
         }
 #pragma unroll
@@ -713,8 +712,8 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
             const int64_t i = (int64_t)t * TILE + threadIdx.x;
             bool yes = false, bd = false;
             if (i < nmodel) {
-                if (surv_is(a[u])) {
-                    yes = lnprob_st[cbase + surv_slot(a[u])] > th;
+                if (surv_is(v32[u])) {
+                    yes = lnprob_st[cbase + surv_slot(v32[u])] > th;
                 } else {
                     const double v = (double)v32[u];
                     yes = v >= th + e;

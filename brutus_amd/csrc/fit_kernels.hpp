@@ -630,10 +630,12 @@ k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ 
     }
 }
 
-// Second generation (fit2_kernels.hpp): the float32 lnl_p~ plane doubles as the survivor
-// map.  Its genuine entries are negative, -inf or NaN; k_fflux overwrites a candidate's
-// entry with -inf (failed the exact cull test) or with the bit pattern 1 + (position in
-// the star's candidate list), a positive finite word.  The flux-phase results live in
+// Second generation (fit2_kernels.hpp): the float32 lnprob~ plane doubles as the survivor
+// map.  Its genuine entries are negative, -inf or NaN (the value of a survivor is not
+// needed again: survivors are judged by their final float64 lnprob); k_fflux overwrites a
+// survivor's entry with the bit pattern 1 + (position in the star's candidate list), a
+// positive finite word, and leaves a candidate that failed the exact cull test alone.
+// Every later pass (exact first-cut threshold, classification, emit) then reads ONE plane.  The flux-phase results live in
 // candidate-list order ("staging": the Planes arrays indexed by list position), so they
 // are written as full lines and read back densely.
 __device__ __forceinline__ float surv_tag(int64_t slot) { return __int_as_float((int)slot + 1); }
@@ -789,7 +791,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
             if (surv32 && FIRST) {
                 go = cull_stat(sp, m) > thr_cull[s];
-                surv32[o] = go ? surv_tag(q - surv_off[s]) : -INFINITY;
+                if (go) surv32[o] = surv_tag(q - surv_off[s]);     // a failed candidate keeps its lnprob~
             }
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; go && it < niter; ++it) {
