@@ -16,8 +16,9 @@
 //   k_top      float64 re-evaluation of the models within 2 eps of the float32 maximum
 //              (only the blocks whose float32 maximum is that high are touched)
 //              ->  EXACT max lnl_p, i.e. the exact cull threshold.
-//   k_cmp_count32 + k_offsets + k_cmp_scatter
-//              ordered list of the models with lnl_p~ >= threshold - eps.
+//   k_cmp_count32 + k_offsets + k_items + k_cmp_scatter
+//              ordered list of the models with lnl_p~ >= threshold - eps, cut into work
+//              items by (star, model chunk) segment and numbered chunk-major.
 //   k_fflux    (fit_kernels.hpp, second-generation mode) exact cull test in float64, flux
 //              iterations for the survivors; results staged in candidate-list order
 //              (full-line writes, dense read-back), the survivor's list position left as
