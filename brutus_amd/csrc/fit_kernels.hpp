@@ -782,7 +782,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = -BIG;
             } else {
                 av = pl.av[os];
-                rv = pl.rv[os];
+                rv = RVF ? p.rv_mean : pl.rv[os];     // pinned Rv is not staged
                 step = pl.step[os];
                 lnl_old = -0.5 * pl.chi2[os];
             }
@@ -818,7 +818,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             if (go) {
                 store_mle(pl, os, m);
                 pl.av[os] = av;
-                pl.rv[os] = rv;
+                if constexpr (!RVF) pl.rv[os] = rv;
                 pl.step[os] = step;
                 const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
                 const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
@@ -1006,7 +1006,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             rec[1] = pl.chi2[o];
             rec[2] = pl.scale[o];
             rec[3] = pl.av[o];
-            rec[4] = pl.rv[o];
+            rec[4] = RVF ? p.rv_mean : pl.rv[o];
 #pragma unroll
             for (int v = 0; v < 6; ++v) rec[5 + v] = pl.icov[v][o];
 #pragma unroll
