@@ -671,6 +671,40 @@ __global__ void k_items(int nstar, const int32_t *__restrict__ wbase,
     }
 }
 
+// Walk of the work items that gives every XCD whole model chunks: workgroups are dispatched
+// round-robin over the 8 XCDs, so workgroup b runs on XCD b % 8 and takes the chunks
+// c = b % 8, b % 8 + 8, ...; inside a chunk the XCD's workers (`nw` of them, this one is
+// number `me`) take the items in turn.  A chunk's coefficient rows then cross the fabric
+// once, into ONE L2, and serve all stars from there (chunk-major numbering alone still
+// fetched them into all eight).
+struct ItemWalk {
+    const int32_t *wbase;
+    int nstar, c, item, me, nw;
+    __device__ __forceinline__ void seek() {      // first chunk from c on with an item for `me`
+        for (; c < NCHUNK; c += 8) {
+            item = wbase[c * nstar] + me;
+            if (item < wbase[(c + 1) * nstar]) return;
+        }
+        item = -1;
+    }
+    __device__ __forceinline__ void init(const int32_t *wb, int ns, int xcd, int me_, int nw_) {
+        wbase = wb;
+        nstar = ns;
+        me = me_;
+        nw = nw_;
+        c = xcd;
+        seek();
+    }
+    __device__ __forceinline__ bool done() const { return item < 0; }
+    __device__ __forceinline__ void next() {
+        item += nw;
+        if (item >= wbase[(c + 1) * nstar]) {
+            c += 8;
+            seek();
+        }
+    }
+};
+
 // Coefficients of ONE model from the model-major copy: 3*NB/4 16-byte loads.
 template <int NB>
 __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int64_t nmodel_pad,
@@ -716,25 +750,28 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
-    const int nitem = wbase[NCHUNK * nstar];
     // (the launch kind is a template parameter: the opening launch then carries no
     // state-reload path and its two iterations unroll)
     constexpr int niter = FIRST ? 2 : 1;
     // this lane's model in a work item, requested one item ahead (a dead lane reads the
     // item's last entry: no select on the loaded value, so nothing waits for it here)
     auto lane_model = [&](int item) -> int32_t {
-        if (item >= nitem) return 0;
+        if (item < 0) return 0;
         const ItemGeom ig = items[item];
         const int64_t q = ig.q0 + threadIdx.x;
         const int64_t last = ig.q0 + ig.n - 1;
         return surv_idx[q < last ? q : last];
     };
-    int32_t i_nxt = lane_model(blockIdx.x);
-    for (int item = blockIdx.x; item < nitem; item += gridDim.x) {
+    ItemWalk wk;
+    wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
+    int32_t i_nxt = lane_model(wk.item);
+    while (!wk.done()) {
+        const int item = wk.item;
+        wk.next();
         const ItemGeom ig = items[item];
         const int s = ig.s;
         const int32_t i_me = i_nxt;
-        i_nxt = lane_model(item + gridDim.x);
+        i_nxt = lane_model(wk.item);
         if (k2state[s] < 0) continue;
         const StarPrep &sp = stars[s];
         const int64_t q = ig.q0 + threadIdx.x;
@@ -934,7 +971,7 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
         s = 0;
         q0 = 0;
         n = 0;
-        if (item >= nitem) return;
+        if (item < 0) return;
         const ItemGeom ig = items[item];
         s = ig.s;
         q0 = ig.q0;
@@ -958,8 +995,10 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             }
         }
     };
-    const int stride = gridDim.x * NW;
-    int item = blockIdx.x * NW + w;
+    ItemWalk wk;
+    wk.init(wbase, nstar, blockIdx.x & 7, (blockIdx.x >> 3) * NW + w,
+            ((gridDim.x + 7 - (blockIdx.x & 7)) >> 3) * NW);
+    int item = wk.item;
     int s, n, s_n, n_n;
     int64_t q0, q0_n;
     int32_t iv[NW], iv_n[NW];
@@ -967,10 +1006,11 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
     geom(item, s, q0, n);
     load_idx(q0, n, iv);
     load_kind(s, n, iv, kd);
-    for (; item < nitem; item += stride) {
+    for (; item >= 0; item = wk.item) {
         // the next item's models are requested now, its kind words once those have
         // arrived (after the copy rounds): both latencies run under this item's work
-        geom(item + stride, s_n, q0_n, n_n);
+        wk.next();
+        geom(wk.item, s_n, q0_n, n_n);
         load_idx(q0_n, n_n, iv_n);
         const StarPrep &sp = stars[s];
         const int64_t sbase = (int64_t)s * pl.nmodel;
