@@ -564,7 +564,8 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     q.dim_prior = p.dim_prior;
     q.nfilt = nfilt;
     tm.begin("k_pre32");
-    hipLaunchKernelGGL((k_pre32<NB, RVF, G>), dim3((nrun + G - 1) / G, nblkx), dim3(TILE), 0, st, grid,
+    hipLaunchKernelGGL((k_pre32<NB, RVF, G>), dim3(8 * ((nblkx + 7) / 8) * ((nrun + G - 1) / G)),
+                       dim3(TILE), 0, st, grid,
                        nmodel, nmodel_pad, nstar, nrun, w.ids, w.s32, q, w.kfix, ntile, w.lnlp32,
                        w.lnpr32, w.part32);
     tm.end();

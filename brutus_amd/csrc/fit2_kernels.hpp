@@ -155,11 +155,14 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     __shared__ float slot[4][G * NV32];
     const float C10 = -1.32877123795494494f;     // -0.4 log2(10)
     const float NINF = -INFINITY;
-    // star group = the FAST block index: consecutive workgroups take the same eight tiles
-    // for different star groups, so a tile is fetched from the fabric once per XCD instead
-    // of once per star group (the grid is read by nrun / G groups)
-    const int bx = blockIdx.y;                 // tile chunk
-    const int g0 = blockIdx.x * G;
+    // 1-D launch of 8 * ceil(nchunk / 8) * ngroup workgroups.  Workgroup L runs on XCD L % 8
+    // (round-robin dispatch) and takes, in turn, the star groups of the tile chunks
+    // L % 8, L % 8 + 8, ...: a tile chunk is fetched from the fabric ONCE, into one L2, and
+    // serves all nrun / G star groups from there (108 MB per call instead of 108 MB per group)
+    const int ngroup = (nrun + G - 1) / G;
+    const int bx = ((int)(blockIdx.x >> 3) / ngroup) * 8 + (int)(blockIdx.x & 7);     // tile chunk
+    if (bx * F2_T >= ntile) return;
+    const int g0 = ((int)(blockIdx.x >> 3) % ngroup) * G;
     const int ng = min(G, nrun - g0);
     float mx[G][NV32];
 #pragma unroll
