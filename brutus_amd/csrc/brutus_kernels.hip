@@ -54,6 +54,7 @@
 #include "cluster_kernels.hpp"
 #include "mt_kernels.hpp"
 #include "post_kernels.hpp"
+#include "offsets_kernels.hpp"
 
 namespace {
 
@@ -1323,6 +1324,95 @@ int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const d
     hipLaunchKernelGGL(k_cluster_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, npts, nfilt, d_src, d_mags, d_lnw_in, d_pts_flux,
                        d_pts_lnw);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- utils.photometric_offsets on the device (offsets_kernels.hpp) ----------
+int brutus_offsets_weights(int nobj, int nsamps, int nfilt, int64_t nmodel, const float *d_models,
+                           const int64_t *d_idxs, const double *d_reds, const double *d_dreds,
+                           const double *d_dists, const double *d_phot, const double *d_err,
+                           const uint8_t *d_mask, const double *d_weights,
+                           const double *d_old_offsets, const uint8_t *d_use,
+                           const uint8_t *d_mask_fit, int dim_prior, double *d_flux, double *d_cdf,
+                           void *stream) {
+    if (nobj <= 0 || nsamps <= 0 || nfilt <= 0 || nfilt > NBMAX || nmodel <= 0)
+        return fail(BRUTUS_EINVAL, "bad photometric-offset dimensions (nobj=%d, nsamps=%d, nfilt=%d)",
+                    nobj, nsamps, nfilt);
+    if (!d_models || !d_idxs || !d_reds || !d_dreds || !d_dists || !d_phot || !d_err || !d_mask ||
+        !d_weights || !d_old_offsets || !d_use || !d_mask_fit || !d_flux || !d_cdf)
+        return fail(BRUTUS_EINVAL, "NULL device pointer");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nt = (int64_t)nobj * nsamps;
+    hipLaunchKernelGGL(k_po_flux, dim3((unsigned)((nt + PO_T - 1) / PO_T)), dim3(PO_T), 0, st, nobj,
+                       nsamps, nfilt, nmodel, d_models, d_idxs, d_reds, d_dreds, d_dists, d_phot,
+                       d_err, d_mask, d_old_offsets, d_use, d_mask_fit, dim_prior, d_flux, d_cdf);
+    hipLaunchKernelGGL(k_po_cdf, dim3(nobj, nfilt), dim3(PO_T), 0, st, nobj, nsamps, d_weights,
+                       d_use, d_mask_fit, d_cdf);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+namespace {
+// [vals | sorted | segment offsets | hipCUB scratch]
+struct OffsetsWs {
+    double *vals, *sorted;
+    int32_t *seg;
+    void *tmp;
+    size_t tmp_bytes, bytes;
+};
+int carve_offsets(char *base, int n, int nmc, OffsetsWs &w) {
+    const size_t nv = (size_t)n * nmc;
+    size_t off = 0;
+    w.vals = (double *)(base + off);
+    off += align_up(sizeof(double) * nv);
+    w.sorted = (double *)(base + off);
+    off += align_up(sizeof(double) * nv);
+    w.seg = (int32_t *)(base + off);
+    off += align_up(sizeof(int32_t) * ((size_t)nmc + 1));
+    w.tmp = base + off;
+    w.tmp_bytes = 0;
+    hipError_t e = hipcub::DeviceSegmentedRadixSort::SortKeys(
+        nullptr, w.tmp_bytes, (const double *)nullptr, (double *)nullptr, (int)nv, nmc,
+        (const int32_t *)nullptr, (const int32_t *)nullptr);
+    if (e != hipSuccess) return -1;
+    off += align_up(w.tmp_bytes);
+    w.bytes = off;
+    return 0;
+}
+}  // namespace
+
+size_t brutus_offsets_workspace_bytes(int n, int nmc) {
+    if (n <= 0 || nmc <= 0 || (int64_t)n * nmc >= (int64_t)1 << 31) return 0;
+    OffsetsWs w;
+    if (carve_offsets(nullptr, n, nmc, w)) return 0;
+    return w.bytes;
+}
+
+int brutus_offsets_bootstrap(int band, int nobj, int nsamps, int nfilt, int n, int nmc,
+                             const int32_t *d_subset, const double *d_cdf_obj, const double *d_u,
+                             const double *d_flux, const double *d_cdf, const double *d_phot,
+                             void *d_workspace, size_t workspace_bytes, double *d_meds,
+                             void *stream) {
+    if (band < 0 || band >= nfilt || nobj <= 0 || nsamps <= 0 || n <= 0 || n > nobj || nmc <= 0 ||
+        (int64_t)n * nmc >= (int64_t)1 << 31)
+        return fail(BRUTUS_EINVAL, "bad bootstrap dimensions (band=%d, n=%d, nmc=%d)", band, n, nmc);
+    if (!d_subset || !d_cdf_obj || !d_u || !d_flux || !d_cdf || !d_phot || !d_workspace || !d_meds)
+        return fail(BRUTUS_EINVAL, "NULL device pointer");
+    OffsetsWs w;
+    if (carve_offsets((char *)d_workspace, n, nmc, w)) return fail(BRUTUS_EHIP, "hipCUB sizing failed");
+    if (workspace_bytes < w.bytes) return fail(BRUTUS_ENOMEM, "photometric-offset workspace too small");
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nv = (int64_t)n * nmc;
+    hipLaunchKernelGGL(k_po_segments, dim3((nmc + 1 + 255) / 256), dim3(256), 0, st, n, nmc, w.seg);
+    hipLaunchKernelGGL(k_po_boot, dim3((unsigned)((nv + PO_T - 1) / PO_T)), dim3(PO_T), 0, st, band,
+                       nobj, nsamps, nfilt, n, nmc, d_subset, d_cdf_obj, d_u, d_flux, d_cdf, d_phot,
+                       w.vals);
+    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(w.tmp, w.tmp_bytes, (const double *)w.vals,
+                                                       w.sorted, (int)nv, nmc, w.seg, w.seg + 1, 0,
+                                                       64, st));
+    hipLaunchKernelGGL(k_po_median, dim3((nmc + 255) / 256), dim3(256), 0, st, n, nmc, w.sorted,
+                       d_meds);
     HIP_TRY(hipGetLastError());
     return 0;
 }

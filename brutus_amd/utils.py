@@ -259,7 +259,7 @@ def _phot_loglike_many(data, data_err, band_mask, models, dim_prior):
 def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
                         sel=None, weights=None, mask_fit=None, Nmc=150,
                         old_offsets=None, dim_prior=True, prior_mean=None,
-                        prior_std=None, verbose=True, rstate=None):
+                        prior_std=None, verbose=True, rstate=None, device=None):
     """Multiplicative photometric offsets (model / data) per band from the
     resampled fits of many objects, with bootstrap errors; same arguments,
     RNG call order and returns `(ratios, ratios_err, nratio)` as reference
@@ -267,8 +267,17 @@ def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
 
     For a band that took part in the fit the model draws of every object are
     re-weighted by the likelihood of the *other* bands (leave-one-band-out),
-    so that the band does not calibrate itself."""
+    so that the band does not calibrate itself.
+
+    `device` (not in the reference): a torch device (`"cuda"`, `"cuda:0"`) runs
+    the SEDs, the leave-one-out weights and the bootstrap rounds in the HIP
+    library (`brutus_offsets_weights`, `brutus_offsets_bootstrap`); `rstate` is
+    consumed exactly as on the host, so the same draws are made."""
     import sys
+    if device is not None:
+        return _photometric_offsets_device(
+            phot, err, mask, models, idxs, reds, dreds, dists, sel, weights, mask_fit, Nmc,
+            old_offsets, dim_prior, prior_mean, prior_std, verbose, rstate, device)
     from scipy.special import logsumexp
     phot, err = np.asarray(phot, float), np.asarray(err, float)
     mask = np.asarray(mask, dtype=bool)
@@ -338,6 +347,111 @@ def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
                 midx[lo:hi] = np.sum(cdf[ridx[lo:hi]] <= u[lo:hi, None], axis=1)
             meds[j] = np.median(ratio[ridx, midx])
         ratios[b], ratios_err[b] = np.median(meds), np.std(meds)
+    if verbose:
+        sys.stderr.write('\n')
+    if prior_mean is not None and prior_std is not None:
+        var = ratios_err ** 2 + prior_std ** 2
+        ratios = (ratios * prior_std ** 2 + prior_mean * ratios_err ** 2) / var
+        ratios_err = ratios_err * prior_std / np.sqrt(var)
+    return ratios, ratios_err, nratio
+
+
+def _offsets_subsets(mask, sel, weights, mask_fit):
+    """Objects that enter each band (reference utils.py:1337-1350)."""
+    nbands = mask.sum(axis=1)
+    usable = sel & (weights.sum(axis=1) > 0)
+    return [np.where(mask[:, b] & usable & (nbands > 3 + (1 if mask_fit[b] else 0)))[0]
+            for b in range(mask.shape[1])]
+
+
+def _photometric_offsets_device(phot, err, mask, models, idxs, reds, dreds, dists, sel, weights,
+                                mask_fit, Nmc, old_offsets, dim_prior, prior_mean, prior_std,
+                                verbose, rstate, device):
+    """`photometric_offsets` with the arithmetic on the GPU (csrc/offsets_kernels.hpp).
+    The host draws the uniforms (2 n per bootstrap round, the order of the reference's
+    `choice` calls, utils.py:1381-1385) and takes median / std of the Nmc medians."""
+    import sys
+    from . import _lib
+    from .fitting import _torch, _stream_ptr
+    phot, err = np.asarray(phot, float), np.asarray(err, float)
+    mask = np.asarray(mask, dtype=bool)
+    Nobj, Nfilt = phot.shape
+    idxs = np.asarray(idxs)
+    Nsamps = idxs.shape[1]
+    sel = np.ones(Nobj, dtype=bool) if sel is None else np.asarray(sel, bool)
+    weights = np.ones((Nobj, Nsamps)) if weights is None else np.asarray(weights, float)
+    mask_fit = np.ones(Nfilt, dtype=bool) if mask_fit is None else np.asarray(mask_fit, bool)
+    old_offsets = np.ones(Nfilt) if old_offsets is None else np.asarray(old_offsets, float)
+    if rstate is None:
+        rstate = getattr(np, "random_intel", np.random)
+    models = np.asarray(models)
+    if models.ndim != 3 or models.shape[1] != Nfilt or models.shape[2] != 3:
+        raise ValueError("models must have shape (Nmodel, Nfilt, 3)")
+    if models.dtype != np.float32:
+        # the kernels read the float32 coefficients of `load_models` (utils.py:588-591)
+        m32 = models.astype(np.float32)
+        if not np.array_equal(m32.astype(models.dtype), models):
+            raise ValueError("the device path needs float32 magnitude coefficients "
+                             "(as `load_models` returns them)")
+        models = m32
+    torch = _torch()
+    L = _lib.lib()
+    dev = torch.device("cuda:%d" % torch.cuda.current_device() if device in (True, "cuda")
+                       else device)
+
+    def up(a, dt):
+        return torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+
+    subsets = _offsets_subsets(mask, sel, weights, mask_fit)
+    use = np.zeros((Nfilt, Nobj), dtype=np.uint8)
+    for b, s in enumerate(subsets):
+        use[b, s] = 1
+    with torch.cuda.device(dev):
+        sp = _stream_ptr(torch)
+        t_models = up(models, np.float32)
+        t_phot, t_err = up(phot, np.float64), up(err, np.float64)
+        t_w = up(weights, np.float64)
+        t_flux = torch.empty((Nfilt, Nobj, Nsamps), dtype=torch.float64, device=dev)
+        t_cdf = torch.empty((Nfilt, Nobj, Nsamps), dtype=torch.float64, device=dev)
+        keep = [up(idxs, np.int64), up(reds, np.float64), up(dreds, np.float64),
+                up(dists, np.float64), up(mask, np.uint8), up(old_offsets, np.float64),
+                up(use, np.uint8), up(mask_fit, np.uint8)]
+        _lib.check(L.brutus_offsets_weights(
+            Nobj, Nsamps, Nfilt, models.shape[0], t_models.data_ptr(), keep[0].data_ptr(),
+            keep[1].data_ptr(), keep[2].data_ptr(), keep[3].data_ptr(), t_phot.data_ptr(),
+            t_err.data_ptr(), keep[4].data_ptr(), t_w.data_ptr(), keep[5].data_ptr(),
+            keep[6].data_ptr(), keep[7].data_ptr(), int(bool(dim_prior)), t_flux.data_ptr(),
+            t_cdf.data_ptr(), sp))
+        ratios, ratios_err = np.ones(Nfilt), np.zeros(Nfilt)
+        nratio = np.zeros(Nfilt, dtype=int)
+        sample = getattr(rstate, "random_sample", None) or rstate.random
+        nmax = max(len(s) for s in subsets)
+        t_ws = None
+        if nmax:
+            nbytes = int(L.brutus_offsets_workspace_bytes(nmax, Nmc))
+            if nbytes == 0:
+                raise ValueError("Nmc x objects per band is too large for one bootstrap call")
+            t_ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            t_meds = torch.empty(Nmc, dtype=torch.float64, device=dev)
+        for b, s in enumerate(subsets):
+            n = nratio[b] = len(s)
+            if n == 0:
+                continue
+            if verbose:
+                sys.stderr.write('\rBand {0} ({1}/{1})     '.format(b + 1, Nmc))
+                sys.stderr.flush()
+            wt_obj = np.array(weights[s].sum(axis=1) > 0, dtype=float)
+            wt_obj /= wt_obj.sum()
+            cdf_obj = wt_obj.cumsum()
+            cdf_obj /= cdf_obj[-1]
+            u = sample(2 * n * Nmc)         # round j: n object draws, then n model draws
+            t_u, t_s, t_co = up(u, np.float64), up(s, np.int32), up(cdf_obj, np.float64)
+            _lib.check(L.brutus_offsets_bootstrap(
+                b, Nobj, Nsamps, Nfilt, n, Nmc, t_s.data_ptr(), t_co.data_ptr(), t_u.data_ptr(),
+                t_flux.data_ptr(), t_cdf.data_ptr(), t_phot.data_ptr(), t_ws.data_ptr(),
+                t_ws.numel(), t_meds.data_ptr(), sp))
+            meds = t_meds.cpu().numpy()
+            ratios[b], ratios_err[b] = np.median(meds), np.std(meds)
     if verbose:
         sys.stderr.write('\n')
     if prior_mean is not None and prior_std is not None:

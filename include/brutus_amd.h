@@ -285,6 +285,43 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        int dim_prior, void *d_workspace, size_t workspace_bytes,
                        double *d_lnl, void *stream);
 
+/* ---- utils.photometric_offsets (reference utils.py:1218-1400) ------------------------
+ * The per-band bootstrap of model / data flux ratios over the resampled fits of many
+ * objects.  The caller keeps numpy's random stream and the final median / std over the
+ * rounds; these two calls replace the reference's get_seds + phot_loglike + per-object
+ * `choice` loop.
+ *
+ * brutus_offsets_weights: for every object o and resampled draw k
+ *   d_models (nmodel, nfilt, 3) f32   the grid as utils.load_models returns it
+ *   d_idxs, d_reds, d_dreds, d_dists (nobj, nsamps)   the fit's draws (negative idx wraps)
+ *   d_phot, d_err (nobj, nfilt) f64, d_mask (nobj, nfilt) u8, d_weights (nobj, nsamps)
+ *   d_old_offsets (nfilt), d_mask_fit (nfilt) u8
+ *   d_use (nfilt, nobj) u8            the objects that enter band b (utils.py:1337-1350)
+ * writes d_flux (nfilt, nobj, nsamps) = 10^(-0.4 sed) / dist^2 (utils.py:1327-1331) and
+ * d_cdf (nfilt, nobj, nsamps) = cumulative normalised weights of the draws: leave-one-band-
+ * out likelihood x weights where mask_fit[b], plain weights otherwise (utils.py:1355-1372);
+ * rows with d_use == 0 are left untouched. */
+int brutus_offsets_weights(int nobj, int nsamps, int nfilt, int64_t nmodel, const float *d_models,
+                           const int64_t *d_idxs, const double *d_reds, const double *d_dreds,
+                           const double *d_dists, const double *d_phot, const double *d_err,
+                           const uint8_t *d_mask, const double *d_weights,
+                           const double *d_old_offsets, const uint8_t *d_use,
+                           const uint8_t *d_mask_fit, int dim_prior, double *d_flux, double *d_cdf,
+                           void *stream);
+/* brutus_offsets_bootstrap: the nmc bootstrap rounds of ONE band (utils.py:1374-1387):
+ *   d_subset (n) i32   the objects of this band, d_cdf_obj (n) their cumulative weights
+ *   d_u (nmc, 2, n)    the 2 n uniforms of every round in numpy's order: the n of
+ *                      `choice(n, size=n, p=wt_obj)`, then one per `choice(Nsamps, p=wt[i])`
+ * both `choice`s are numpy's legacy searchsorted(cdf, u, 'right'); writes d_meds (nmc) =
+ * np.median of the round's model / data ratios.  0 bytes from the size query = bad sizes. */
+size_t brutus_offsets_workspace_bytes(int n, int nmc);
+int brutus_offsets_bootstrap(int band, int nobj, int nsamps, int nfilt, int n, int nmc,
+                             const int32_t *d_subset, const double *d_cdf_obj, const double *d_u,
+                             const double *d_flux, const double *d_cdf, const double *d_phot,
+                             void *d_workspace, size_t workspace_bytes, double *d_meds,
+                             void *stream);
+
+
 /* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
  * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
  * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated
