@@ -656,14 +656,27 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
     const double th = thr[s];
     int n = 0;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        bool hit = false;
-        if (i < nmodel) hit = !((double)plane[(int64_t)s * nmodel + i] < th);
-        n += hit ? 1 : 0;
-        const unsigned long long b = __ballot(hit);
-        if ((threadIdx.x & 63) == 0)
-            mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
+    constexpr int U = 8;      // tiles in flight per lane (one 4-byte load each: latency-bound otherwise)
+    for (int tb = t0; tb < t1; tb += U) {
+        float v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            // (clamped address + select: a guarded load compiles to a branch and a full
+            // wait per load, which serialises the batch)
+            const int64_t i = (int64_t)(tb + u) * TILE + threadIdx.x;
+            const bool in = tb + u < t1 && i < nmodel;
+            const float x = plane[(int64_t)s * nmodel + (in ? i : nmodel - 1)];
+            v[u] = in ? x : -INFINITY;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            if (tb + u >= t1) break;
+            const bool hit = !((double)v[u] < th);
+            n += hit ? 1 : 0;
+            const unsigned long long b = __ballot(hit);
+            if ((threadIdx.x & 63) == 0)
+                mask[(int64_t)s * (4 * ntile) + (int64_t)(tb + u) * 4 + (threadIdx.x >> 6)] = b;
+        }
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
@@ -707,8 +720,14 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
         for (int u = 0; u < U; ++u) {
             const int64_t i = (int64_t)(tb + u) * TILE + threadIdx.x;
             const bool in = tb + u < t1 && i < nmodel;
-            v32[u] = in ? lnpr32[(int64_t)s * nmodel + i] : -INFINITY;
+            const float x = lnpr32[(int64_t)s * nmodel + (in ? i : nmodel - 1)];   // see k_cmp_count32
+            v32[u] = in ? x : -INFINITY;
         }
+        // (the survivors' staged values: second round of loads, again all in flight)
+        double vst[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+            vst[u] = surv_is(v32[u]) ? lnprob_st[cbase + surv_slot(v32[u])] : 0.;
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int t = tb + u;
@@ -717,7 +736,7 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
             bool yes = false, bd = false;
             if (i < nmodel) {
                 if (surv_is(v32[u])) {
-                    yes = lnprob_st[cbase + surv_slot(v32[u])] > th;
+                    yes = vst[u] > th;
                 } else {
                     const double v = (double)v32[u];
                     yes = v >= th + e;

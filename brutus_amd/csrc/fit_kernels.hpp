@@ -541,89 +541,107 @@ k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
     if (other) block_max_store(om, slot, other_max + (int64_t)s * NCHUNK + c);
 }
 
-// Exclusive scan of counts[(s, c)] in (s, c) order; one workgroup, thread s owns star s.
+// Exclusive scan of counts[(s, c)] in (s, c) order:
 //   offsets[(s, c)], star_off[s] (star_off[nstar] = total).
 // Work items of the list kernels (k_fflux, k_emit): the segment of star s in model chunk c,
 // cut into pieces of TILE entries, numbered CHUNK-MAJOR: wbase[c * nstar + s] = first item
 // of that segment, wbase[NCHUNK * nstar] = #items.  Workgroups that run at the same time
 // then work on the same 1/NCHUNK of the grid for different stars, and the coefficient rows
 // they gather are L2 hits instead of one fabric read per star.
-__global__ void k_offsets(int nstar, const int64_t *__restrict__ counts,
-                          int64_t *__restrict__ offsets, int64_t *__restrict__ star_off,
-                          int32_t *__restrict__ wbase) {
-    __shared__ int64_t tot[BRUTUS_MAX_BATCH + 1];
-    __shared__ int32_t crow[NCHUNK + 1];
-    const int s = threadIdx.x;
-    int64_t n = 0;
-    if (s < nstar)
-        for (int c = 0; c < NCHUNK; ++c) n += counts[(int64_t)s * NCHUNK + c];
-    if (s < nstar) tot[s] = n;
-    // items of chunk row c over all stars (thread c)
-    if (wbase && s < NCHUNK) {
-        int32_t m = 0;
-        for (int q = 0; q < nstar; ++q) m += (int32_t)((counts[(int64_t)q * NCHUNK + s] + TILE - 1) / TILE);
-        crow[s] = m;
-    }
-    __syncthreads();
-    if (s == 0) {
-        int64_t run = 0;
-        for (int q = 0; q < nstar; ++q) {
-            const int64_t m = tot[q];
-            tot[q] = run;
-            star_off[q] = run;
-            run += m;
+// One workgroup of BRUTUS_MAX_BATCH threads, two exclusive scans over the nstar x NCHUNK
+// counts -- star-major for the list offsets, chunk-major for the work items -- each lane
+// taking a run of consecutive entries whose loads are all in flight at once (the serial
+// per-star / per-chunk loops this replaces paid one memory round trip per entry).
+__global__ void __launch_bounds__(BRUTUS_MAX_BATCH)
+k_offsets(int nstar, const int64_t *__restrict__ counts, int64_t *__restrict__ offsets,
+          int64_t *__restrict__ star_off, int32_t *__restrict__ wbase) {
+    constexpr int NT = BRUTUS_MAX_BATCH;
+    constexpr int EPT = NCHUNK;                       // entries per lane at the full batch
+    typedef hipcub::BlockScan<int64_t, NT> Scan64;
+    typedef hipcub::BlockScan<int32_t, NT> Scan32;
+    __shared__ union {
+        typename Scan64::TempStorage a;
+        typename Scan32::TempStorage b;
+    } tmp;
+    const int total = nstar * NCHUNK;
+    const int ept = (total + NT - 1) / NT;
+    const int e0 = threadIdx.x * ept;
+    {
+        int64_t r[EPT];
+        int64_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            r[k] = k < ept && e0 + k < total ? counts[e0 + k] : 0;
+            sum += r[k];
         }
-        star_off[nstar] = run;
-        if (wbase) {
-            int32_t w = 0;
-            for (int c = 0; c < NCHUNK; ++c) {
-                const int32_t m = crow[c];
-                crow[c] = w;
-                w += m;
+        int64_t pre, all;
+        Scan64(tmp.a).ExclusiveSum(sum, pre, all);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            if (k < ept && e0 + k < total) {
+                offsets[e0 + k] = pre;
+                if ((e0 + k) % NCHUNK == 0) star_off[(e0 + k) / NCHUNK] = pre;
             }
-            crow[NCHUNK] = w;
-            wbase[NCHUNK * nstar] = w;
+            pre += r[k];
         }
+        if (threadIdx.x == 0) star_off[nstar] = all;
     }
+    if (!wbase) return;
     __syncthreads();
-    if (s < nstar) {
-        int64_t run = tot[s];
-        for (int c = 0; c < NCHUNK; ++c) {
-            offsets[(int64_t)s * NCHUNK + c] = run;
-            run += counts[(int64_t)s * NCHUNK + c];
+    {
+        int32_t r[EPT];
+        int32_t sum = 0;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            const int e = e0 + k;                     // = c * nstar + q
+            const int c = e / nstar, q = e - c * nstar;
+            r[k] = k < ept && e < total ? (int32_t)((counts[(int64_t)q * NCHUNK + c] + TILE - 1) / TILE) : 0;
+            sum += r[k];
         }
-    }
-    if (wbase && s < NCHUNK) {
-        int32_t w = crow[s];
-        for (int q = 0; q < nstar; ++q) {
-            wbase[s * nstar + q] = w;
-            w += (int32_t)((counts[(int64_t)q * NCHUNK + s] + TILE - 1) / TILE);
+        int32_t pre, all;
+        Scan32(tmp.b).ExclusiveSum(sum, pre, all);
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) {
+            if (k < ept && e0 + k < total) wbase[e0 + k] = pre;
+            pre += r[k];
         }
+        if (threadIdx.x == 0) wbase[total] = all;
     }
 }
 
+// A chunk's membership words are fetched 64 tiles (256 words, one per lane) at a time and
+// prefix-summed once; the per-tile loop then runs out of LDS.  (One dependent global load
+// per tile made this kernel latency-bound: 46 round trips per workgroup.)
 __global__ void __launch_bounds__(TILE)
 k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ mask,
               const int64_t *__restrict__ offsets, int64_t capacity,
               int32_t *__restrict__ out_idx) {
-    __shared__ int wsum[4];
+    typedef hipcub::BlockScan<int, TILE> Scan;
+    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ unsigned long long s_word[TILE];
+    __shared__ int s_pre[TILE];
     const int s = blockIdx.y, c = blockIdx.x;
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
     int64_t base = offsets[(int64_t)s * NCHUNK + c];
     const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        const unsigned long long b = mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + w];
-        const bool sel = (b >> lane) & 1ull;
-        const int rank = __popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[w] = __popcll(b);
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long *__restrict__ row = mask + (int64_t)s * (4 * ntile);
+    for (int tb = t0; tb < t1; tb += TILE / 4) {
+        const int nt = min(TILE / 4, t1 - tb);
+        const unsigned long long word =
+            (int)threadIdx.x < 4 * nt ? row[(int64_t)tb * 4 + threadIdx.x] : 0ull;
+        int pre, tot;
+        Scan(s_scan).ExclusiveSum(__popcll(word), pre, tot);
+        s_word[threadIdx.x] = word;
+        s_pre[threadIdx.x] = pre;
         __syncthreads();
-        int woff = 0;
-        for (int q = 0; q < w; ++q) woff += wsum[q];
-        const int tot = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        if (sel) {
-            const int64_t r = base + woff + rank;
-            if (r < capacity) out_idx[r] = (int32_t)i;
+#pragma unroll 4
+        for (int k = 0; k < nt; ++k) {
+            const unsigned long long b = s_word[4 * k + w];
+            if ((b >> lane) & 1ull) {
+                const int64_t r = base + s_pre[4 * k + w] + __popcll(b & below);
+                if (r < capacity) out_idx[r] = (int32_t)((int64_t)(tb + k) * TILE + threadIdx.x);
+            }
         }
         base += tot;
         __syncthreads();
