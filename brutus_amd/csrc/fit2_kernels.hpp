@@ -558,24 +558,49 @@ k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ns
             anyhot = anyhot || hot[g];
         }
     }
+    // nominee masks of the block's tiles for its hot stars: all float32 values are requested
+    // first (clamped addresses, no guards: every load of the batch is in flight at once;
+    // one guarded load per (tile, star) made each a round trip of its own), the masks wait
+    // in a wave-private LDS row
+    __shared__ unsigned long long s_need[4][G][F2_T];
+    const float *__restrict__ tagp = mode == 1 ? surv32 : plane32;     // (mode 0: value unused)
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g < ng && hot[g]) {
+            const int s = star_ids[g0 + g];
+            const double nm_s = nom[s];
+            float v[F2_T], tg[F2_T];
+#pragma unroll
+            for (int u = 0; u < F2_T; ++u) {
+                const int64_t i = (int64_t)(t0 + u) * TILE + threadIdx.x;
+                const int64_t ic = i < nmodel ? i : nmodel - 1;
+                v[u] = plane32[(int64_t)s * nmodel + ic];
+                tg[u] = tagp[(int64_t)s * nmodel + ic];
+            }
+#pragma unroll
+            for (int u = 0; u < F2_T; ++u) {
+                const int64_t i = (int64_t)(t0 + u) * TILE + threadIdx.x;
+                bool nm = t0 + u < t1 && i < nmodel && !(v[u] < nm_s);
+                if (mode == 1 && nm) nm = !surv_is(tg[u]);
+                const unsigned long long b = __ballot(nm);
+                if (lane == 0) s_need[wv][g][u] = b;
+            }
+        } else if (lane < F2_T) {
+            s_need[wv][g][lane] = 0ull;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     for (int t = t0; anyhot && t < t1; ++t) {
         const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        const bool live = i < nmodel;
         unsigned long long need[G];
         bool any = false;
 #pragma unroll
         for (int g = 0; g < G; ++g) {
-            need[g] = 0ull;
-            if (g < ng && hot[g]) {
-                const int s = star_ids[g0 + g];
-                bool nm = false;
-                if (live) {
-                    nm = !(plane32[(int64_t)s * nmodel + i] < nom[s]);
-                    if (mode == 1 && nm) nm = !surv_is(surv32[(int64_t)s * nmodel + i]);
-                }
-                need[g] = __ballot(nm);
-                any = any || need[g] != 0ull;
-            }
+            const unsigned long long b = s_need[wv][g][t - t0];
+            need[g] = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) |
+                      (unsigned int)__builtin_amdgcn_readfirstlane((int)b);
+            any = any || need[g] != 0ull;
         }
         if (!any) continue;
         Tile64<NB, RVF> tl;
