@@ -682,7 +682,7 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
                        w.bandn);
     tm.end();
     tm.begin("k_sel_band");      // (the candidate lists in surv_idx are no longer needed)
-    hipLaunchKernelGGL((k_sel_band<NB, RVF>), dim3(NCHUNK, nstar), blk, 0, st, grid, nmodel, nmodel_pad,
+    hipLaunchKernelGGL((k_sel_band<NB, RVF>), dim3(NCHUNK / SB_C, nstar, SB_Z), blk, 0, st, grid, nmodel, nmodel_pad,
                        ntile, w.stars, p, w.k1, w.lnpr32, w.thr_sel, w.surv_idx, w.bandn, w.counts,
                        w.mask, aud ? aud + 2 * nstar : nullptr);
     tm.end();

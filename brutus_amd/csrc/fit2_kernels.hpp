@@ -785,6 +785,11 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
     }
 }
 
+// grid = (NCHUNK / SB_C, nstar, SB_Z): the queues of SB_C neighbouring chunks form one list
+// (a single chunk queues ~50 models on the Av-only bench: a quarter of the lanes, and 8 192
+// workgroups that each pay the full index -> row -> MLE latency chain); a list longer than a
+// workgroup is shared in turns by the SB_Z workgroups of its column.
+constexpr int SB_C = 8, SB_Z = 8;
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
 k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ntile,
@@ -793,21 +798,29 @@ k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, i
            const int32_t *__restrict__ bandq, const int32_t *__restrict__ bandn,
            int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
            float *__restrict__ aud) {
-    const int s = blockIdx.y, c = blockIdx.x;
-    const int n = bandn[s * NCHUNK + c];
-    if (n == 0) return;
+    const int s = blockIdx.y, c0 = blockIdx.x * SB_C;
+    int pre[SB_C + 1];
+    pre[0] = 0;
+#pragma unroll
+    for (int k = 0; k < SB_C; ++k) pre[k + 1] = pre[k] + bandn[s * NCHUNK + c0 + k];
+    const int n = pre[SB_C];
+    if ((int)(blockIdx.z * TILE) >= n) return;      // (long lists are shared by gridDim.z workgroups)
     __shared__ double s_tbl[64];
-    __shared__ int added;
     stage_exp_table(s_tbl);
-    if (threadIdx.x == 0) added = 0;
     __syncthreads();
-    const int t0 = (int)((int64_t)ntile * c / NCHUNK);
-    const int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
     const StarPrep &sp = stars[s];
     const double th = thr_sel[s];
     const int K = k1[s];
-    for (int q = threadIdx.x; q < n; q += TILE) {
-        const int64_t i = queue[q];
+    for (int q = blockIdx.z * TILE + threadIdx.x; q < n; q += TILE * gridDim.z) {
+        int k = 0;
+#pragma unroll
+        for (int j = 1; j < SB_C; ++j) k += q >= pre[j] ? 1 : 0;
+        int qk = q;
+#pragma unroll
+        for (int j = 1; j < SB_C; ++j) qk = k == j ? q - pre[j] : qk;
+        const int c = c0 + k;
+        const int t0 = (int)((int64_t)ntile * c / NCHUNK);
+        const int64_t i = bandq[(int64_t)s * nmodel + (int64_t)t0 * TILE + qk];
         Tile64<NB, RVF> tl;
         gather_coef<NB>(grid, nmodel_pad, i, tl.c);
         compute_F0_tbl<NB>(tl.c, s_tbl, tl.F0);
@@ -821,11 +834,9 @@ k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, i
         audit(aud, s, lnpr32[(int64_t)s * nmodel + i], lnprob, th);
         if (lnprob > th) {
             atomicOr(mask + (int64_t)s * (4 * ntile) + (i >> 6), 1ull << (i & 63));
-            atomicAdd(&added, 1);
+            atomicAdd(reinterpret_cast<unsigned long long *>(counts + (int64_t)s * NCHUNK + c), 1ull);
         }
     }
-    __syncthreads();
-    if (threadIdx.x == 0 && added) counts[(int64_t)s * NCHUNK + c] += added;   // this block owns the entry
 }
 
 
