@@ -910,13 +910,28 @@ __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
     if (k2state[s] < 0) return;
     double v[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int per = TILE / 64;       // k_fflux leaves one partial per wave
-    for (int c = 0; c < NCHUNK; ++c) {      // the star's items: one run per model chunk
+    // the star's items: one run per model chunk.  blockDim.x / NCHUNK lanes share a run and
+    // take its partials four at a time (clamped addresses: all twelve loads in flight; a
+    // chunk-by-chunk loop paid two dependent round trips per chunk)
+    {
+        const int lpc = blockDim.x / NCHUNK;
+        const int c = threadIdx.x / lpc, j = threadIdx.x - c * lpc;
         const int e = c * nstar + s;
-        for (int it = wbase[e] * per + threadIdx.x; it < wbase[e + 1] * per; it += blockDim.x)
-            for (int q = 0; q < 3; ++q) {
-                const double x = part[(int64_t)it * 3 + q];
-                v[q] = x > v[q] ? x : v[q];
+        const int lo = wbase[e] * per, hi = wbase[e + 1] * per;
+        constexpr int U = 4;
+        for (int it = lo + j; it < hi; it += U * lpc) {
+            double x[U][3];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int a = it + u * lpc < hi ? it + u * lpc : it;
+#pragma unroll
+                for (int q = 0; q < 3; ++q) x[u][q] = part[(int64_t)a * 3 + q];
             }
+#pragma unroll
+            for (int u = 0; u < U; ++u)
+#pragma unroll
+                for (int q = 0; q < 3; ++q) v[q] = x[u][q] > v[q] ? x[u][q] : v[q];
+        }
     }
     for (int q = 0; q < 3; ++q) {
         const double m = wave_max(v[q]);
