@@ -269,6 +269,40 @@ def test_full_size_fit_records_vs_c_oracle(config):
         assert np.max(np.abs(rec["icov"] - icov[sel]) / (d[:, :, None] * d[:, None, :])) < RTOL
 
 
+def test_grid_larger_than_one_scan_window_vs_c_oracle():
+    """1.35 M models x 5 bands: 83 tiles per model chunk, so the ordered compaction
+    (`k_cmp_scatter`) walks more than one 64-tile window of membership words per chunk and
+    `k_offsets` / `k_items` number > 2^15 work items; selected sets against the C
+    restatement, full batch (3 stars) and a second call with a single star."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.pdf import scale_parallax_lnprior
+    from oracle import c_oracle
+    models, _, _ = synth.make_mist_like_grid(1350000, 5, seed=3)
+    st = synth.make_stars(models, 3, seed=8)
+    grid = fitting.DeviceGrid(models)
+    eng = fitting._Engine(grid, max_batch=3)
+    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18),
+                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
+                         st["parallax_err"], params)
+    one = eng.fit_batch(st["flux"][1:2], st["err"][1:2], st["mask"][1:2], st["parallax"][1:2],
+                        st["parallax_err"][1:2], params)
+    assert np.array_equal(one[0]["sel"], recs[1]["sel"])
+    for i, rec in enumerate(recs):
+        lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+            st["flux"][i], st["err"][i], st["mask"][i], models, parallax=st["parallax"][i],
+            parallax_err=st["parallax_err"][i])
+        with np.errstate(all="ignore"):
+            lnprob = lnl + scale_parallax_lnprior(
+                sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), st["parallax"][i],
+                st["parallax_err"][i])
+        lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+        sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
+        assert np.array_equal(sel, rec["sel"]), i
+        assert relerr(lnl[sel], rec["lnlike"]) < RTOL
+        assert relerr(sc[sel], rec["scale"]) < RTOL
+
+
 def test_fit_records_vs_oracle_all_cases():
     """The fast fit path (fused scan + compact flux phase) against the oracle's
     loglike + first cut, on stars that need K1 = 1, 2 and > 2 sweeps and
@@ -392,11 +426,13 @@ def test_device_exp10_accuracy():
 
 
 @pytest.mark.parametrize("nmodel,nfilt,nstar", [(1, 4, 1), (257, 5, 3), (1000, 20, 2),
-                                                (513, 32, 2), (4096, 12, 70)])
+                                                (513, 32, 2), (4096, 12, 70),
+                                                (20000, 8, 256)])
 def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
     """Ragged / extreme shapes: a single model, model counts that are not a
     multiple of the 256-model tile, band counts that need padding (5 -> 8,
-    20 -> 24), the maximum 32 bands, more stars than one scan group.  Both entry
+    20 -> 24), the maximum 32 bands, more stars than one scan group, the largest batch
+    (BRUTUS_MAX_BATCH = 256 stars; first three and last star checked).  Both entry
     points against the C oracle."""
     from brutus_amd import fitting, synth
     from brutus_amd.pdf import scale_parallax_lnprior
@@ -419,7 +455,7 @@ def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
                                3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
     rpin = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
                          st["parallax_err"], pin)
-    for i in range(min(nstar, 3)):
+    for i in list(range(min(nstar, 3))) + ([nstar - 1] if nstar > 3 else []):
         par, pe = st["parallax"][i], st["parallax_err"][i]
         tr = {}
         lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
@@ -437,7 +473,7 @@ def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
         d = np.sqrt(np.abs(np.einsum('nii->ni', icov[sel])))
         assert np.max(np.abs(rpin[i]["icov"] - icov[sel])
                       / (d[:, :, None] * d[:, None, :])) < RTOL
-    for i in range(min(nstar, 6)):
+    for i in list(range(min(nstar, 6))) + ([nstar - 1] if nstar > 6 else []):
         par, pe = st["parallax"][i], st["parallax_err"][i]
         ref = c_oracle.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
                                parallax=par, parallax_err=pe)
