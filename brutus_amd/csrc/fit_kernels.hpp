@@ -1070,8 +1070,14 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        // Survivors and re-derived entries take turns, 64 of each (both lists are in position
+        // order): the two kinds of stores into a stretch of the record planes then follow
+        // each other closely and the half-written lines are still in L2 when their other
+        // half arrives.
+        const int nmax = nS > nD ? nS : nD;
+        for (int k0 = 0; k0 < nmax; k0 += 64) {
         // ---- survivors: copy ---------------------------------------------------------
-        for (int k = lane; k < nS; k += 64) {
+        if (const int k = k0 + lane; k < nS) {
             const int mp = s_ps[w][k];
             const int64_t o = surv32 ? cand_off[s] + s_slot[w][mp] : sbase + s_idx[w][mp];
             double rec[BRUTUS_NVALS];
@@ -1085,9 +1091,9 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
 #pragma unroll
             for (int v = 0; v < BRUTUS_NVALS; ++v) sel_vals[(int64_t)v * capacity + q0 + mp] = rec[v];
         }
-        load_kind(s_n, n_n, iv_n, kd_n);
+        if (k0 == 0) load_kind(s_n, n_n, iv_n, kd_n);
         // ---- the rest: K1 sweeps + full MLE from the model's row -----------------------
-        for (int k = lane; k < nD; k += 64) {
+        if (const int k = k0 + lane; k < nD) {
             const int mp = s_pd[w][k];
             const int64_t i = s_idx[w][mp];
             Coef<NB> c;
@@ -1127,6 +1133,8 @@ k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int n
             out[(int64_t)9 * capacity] = m.i12;
             out[(int64_t)10 * capacity] = m.i22;
         }
+        }
+        if (nmax == 0) load_kind(s_n, n_n, iv_n, kd_n);
         // the next item's LDS writes must not pass this item's reads
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
