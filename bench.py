@@ -333,15 +333,16 @@ WORKLOADS = {
 
 # algorithmic bytes of one kernel launch: what the kernel has to
 # move at the very least for the work it is given.  g = grid bytes per star (108 MB at
-# 750k x 12), pairs = stars x models, nsel = selected records of the batch.
+# 750k x 12), pairs = stars x models, c = (nsel, ncand, nder) of the batch: selected
+# records, candidates of the cull, selected models whose values are derived.
 KERNEL_ALG_BYTES = {
-    "k_pre32": lambda B, g, pairs, nsel: B * g,                  # the SURVEY 8(d) unit: one grid read per star
-    "k_fscan": lambda B, g, pairs, nsel: B * g,
-    "k_top": lambda B, g, pairs, nsel: 8. * pairs / 2048.,       # block partials only
-    "k_surv_compact": lambda B, g, pairs, nsel: 4. * pairs,      # the float32 statistic once
-    "k_sel_classify": lambda B, g, pairs, nsel: 8. * pairs,      # two float32 statistics
-    "k_select": lambda B, g, pairs, nsel: 4. * nsel,             # the index list
-    "k_emit": lambda B, g, pairs, nsel: 92. * nsel,              # the records (i32 + 11 f64)
+    "k_pre32": lambda B, g, pairs, c: B * g,                     # the SURVEY 8(d) unit: one grid read per star
+    "k_top": lambda B, g, pairs, c: 8. * pairs / 2048.,          # block partials only
+    "k_surv_compact": lambda B, g, pairs, c: 4. * pairs,         # the float32 statistic once
+    "k_fflux": lambda B, g, pairs, c: 104. * c[1],               # candidates: index in, 11 values + step + lnprob out
+    "k_sel_classify": lambda B, g, pairs, c: 4. * pairs,         # one float32 plane
+    "k_select": lambda B, g, pairs, c: 8. * c[0] + 4. * c[2],    # (model, slot) per record + derived list
+    "k_derive": lambda B, g, pairs, c: 92. * c[2],               # derived records: index in, 11 values out
 }
 
 
@@ -383,16 +384,16 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         subs.append(eng._upload(stars["flux"][sl], stars["err"][sl], stars["mask"][sl],
                                 stars["parallax"][sl] if with_par else None,
                                 stars["parallax_err"][sl] if with_par else None))
-    cap = max(32 << 20, SB * 600000)
-    sel_bufs = [(torch.empty(cap, dtype=torch.int32, device=dev),
-                 torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
-                for _ in range(NS)]
+    # record buffers sized once, before the clock starts (grow=False: a batch that does not
+    # fit fails the run instead of silently repeating work inside the timed region)
+    cap = max(32 << 20, int(SB * nmodel * 0.62))
+    rec_bufs = [engines[j]._record_buffers(cap) for j in range(NS)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
-    nsel_seen = []
 
     def one(i, j=0):
         f, e, m, p, pe, hp = subs[i % len(subs)]
-        out = engines[j].fit_batch_device(f, e, m, p, pe, hp, params, sel_buffers=sel_bufs[j])
+        out = engines[j].fit_batch_device(f, e, m, p, pe, hp, params, buffers=rec_bufs[j],
+                                          grow=False)
         return out
 
     def run(n_sub, first=0):
@@ -431,10 +432,7 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
     out = run(len(subs))              # exactly `steps` steps (this rank's share of them)
     fence()
     dt = time.perf_counter() - t0
-    nsel_total = int(out[2][-1].item())
-    if nsel_total > cap:
-        raise SystemExit("record buffer overflow (%d > %d): timing would be invalid"
-                         % (nsel_total, cap))
+    nsel_total = int(out[0].counts[0])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -455,7 +453,8 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         for i in range(reps):
             o = one(i)
             torch.cuda.synchronize()
-            nsel_k.append(int(o[2][-1].item()))
+            c = o[0].counts
+            nsel_k.append((int(c[0]), int(c[1]), int(c[2] - c[1])))
             n = C.c_int(0)
             names = (C.c_char_p * 24)()
             ms = (C.c_float * 24)()
@@ -465,8 +464,8 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         L.brutus_enable_timing(0)
         res["kernels_ms"] = {k: float(np.mean(v)) for k, v in ktimes.items()}
         res["kernel_sub_batch"] = int(subs[0][0].shape[0])
-        res["kernel_nsel"] = float(np.mean(nsel_k))
-    del engines, sel_bufs, subs
+        res["kernel_counts"] = [float(x) for x in np.mean(nsel_k, axis=0)]
+    del engines, rec_bufs, subs
     torch.cuda.empty_cache()
     return res
 
@@ -490,11 +489,10 @@ def roofline_of(res, args, config, world):
         for name, ms in sorted(res["kernels_ms"].items(), key=lambda kv: -kv[1]):
             alg = KERNEL_ALG_BYTES.get(name.replace("_cont", ""), None)
             e = {"avg_launch_ms": ms}
-            if name.startswith("k_fflux"):
-                e["bound"] = "f64 VALU issue"
-            elif alg is not None:
-                ab = alg(SB, g, pairs, res["kernel_nsel"])
-                e.update(bound="hbm", algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
+            if alg is not None:
+                ab = alg(SB, g, pairs, res["kernel_counts"])
+                e.update(bound="f64 VALU issue" if name.startswith("k_fflux") else "hbm",
+                         algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
             e["traffic"] = measured_traffic(name, SB, config)    # None for grouped timer entries
             kern[name] = e
         rl["kernels"] = kern
@@ -588,7 +586,6 @@ def main():
                                 "device-resident compact survivor records",
                 "selected_models_last_sub_batch": r["selected_models_last_sub_batch"],
                 "streams_per_gpu": max(1, args.streams),
-                "fit_path": int(os.environ.get("BRUTUS_FIT_PATH", "2")),
                 "parallelism": "stars sharded, %d rank(s), no data-path collective" % world}
 
     line = {

@@ -14,6 +14,7 @@ __all__ = ["lib", "Params", "PostParams", "check", "LIB_PATH", "BrutusError", "N
 LIB_PATH = os.environ.get("BRUTUS_AMD_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libbrutus_amd.so")
 NVALS = 11
+ABI_VERSION = 2
 MAX_BATCH = 256
 MAX_FILT = 32
 
@@ -59,7 +60,9 @@ class PostParams(C.Structure):
                 ("min_age", C.c_double), ("max_age", C.c_double)]
 
 
-# name -> (restype, argtypes); mirrors include/brutus_amd.h one to one
+# name -> (restype, argtypes); mirrors include/brutus_amd.h (product ABI) and
+# include/brutus_amd_debug.h (test hooks / measurement aids, see DEBUG_NAMES) one to one
+DEBUG_NAMES = ("brutus_calibrate_traffic", "brutus_calibrate_copy16", "brutus_debug_exp10", "brutus_debug_math", "brutus_debug_mt_stream", "brutus_debug_rng", "brutus_debug_galprior", "brutus_debug_copy", "brutus_debug_sizeof_star32")
 SIGNATURES = {
     "brutus_abi_version": (C.c_int, []),
     "brutus_last_error": (C.c_char_p, []),
@@ -72,10 +75,8 @@ SIGNATURES = {
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                        _vp, _vp]),
     "brutus_fit_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
-                                   _i32, C.POINTER(Params), _vp, _sz, _i64, _vp,
-                                   _vp, _vp, _vp, _vp, _vp, _vp]),
-    "brutus_fit_gather": (C.c_int, [_vp, _i64, _i32, _i32, C.POINTER(Params), _vp,
-                                    _sz, _i64, _vp, _vp, _vp, _vp]),
+                                   _i32, C.POINTER(Params), _vp, _sz, _i64, _vp, _vp,
+                                   _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "brutus_last_timing": (C.c_int, [C.POINTER(C.c_int), C.POINTER(C.c_char_p),
                                      C.POINTER(C.c_float), C.c_int]),
     "brutus_enable_timing": (None, [C.c_int]),
@@ -84,13 +85,13 @@ SIGNATURES = {
     "brutus_debug_exp10": (C.c_int, [_vp, _vp, _i64, _vp]),
     "brutus_debug_math": (C.c_int, [_i32, _vp, _vp, _i64, _vp]),
     "brutus_post_workspace_bytes": (_sz, [_i32, _i64, _i32]),
-    "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "brutus_post_batch": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                     _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                     _vp, _vp, _vp]),
-    "brutus_post_batch_numpy": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "brutus_post_batch_numpy": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, C.POINTER(PostParams), _vp, _sz, _vp, _vp, _vp,
                                           _vp, _i32, _vp, _vp, _sz, _vp]),
-    "brutus_post_batch_numpy_phase": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
+    "brutus_post_batch_numpy_phase": (C.c_int, [_i32, _i64, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
                                                 _vp, _vp, C.POINTER(PostParams), _vp, _sz, _vp,
                                                 _vp, _vp, _vp, _i32, _vp, _vp, _sz, _i32, _vp]),
     "brutus_debug_mt_stream": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
@@ -131,7 +132,7 @@ def lib():
         fn = getattr(L, name)   # AttributeError if the .so is stale
         fn.restype = res
         fn.argtypes = args
-    if L.brutus_abi_version() != 1:
+    if L.brutus_abi_version() != ABI_VERSION:
         raise BrutusError("brutus_amd: ABI version mismatch")
     # jump-ahead polynomials of MT19937 (data, see tools/gen_mt_jump.py): lets many
     # workgroups walk one numpy random stream; without the file one workgroup does

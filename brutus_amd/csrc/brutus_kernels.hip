@@ -45,6 +45,7 @@
 #include <vector>
 
 #include "../../include/brutus_amd.h"
+#include "../../include/brutus_amd_debug.h"
 
 #include "common.hpp"
 #include "fastmath.hpp"
@@ -72,7 +73,7 @@ int padded_nb(int nfilt) {
 int64_t pad_models(int64_t n) { return (n + TILE - 1) / TILE * TILE; }
 
 struct Workspace {
-    Planes pl;
+    Planes pl;          // brutus_loglike_batch only: the caller's output planes + lnlp, step
     StarPrep *stars;
     double *part;       // per-(tile, star) partial maxima
     double *vmax_lnlp;  // (S,)
@@ -81,35 +82,41 @@ struct Workspace {
     int32_t *n_unconv;  // (1,)
     int64_t *counts;    // (S, NCHUNK)
     int64_t *offsets;   // (S, NCHUNK)
-    // fast path
-    int32_t *ids;       // (S,) star list of a fused-scan launch
+    // brutus_fit_batch
+    int32_t *ids;       // (S,) star list of a launch
     int32_t *kfix;      // (S,)
-    double *thr_cull, *maxns, *maxns_part, *maxsurv, *thr_sel;
-    int32_t *surv_idx;  // (S * nmodel,) worst case
-    int64_t *surv_off;  // (S + 1,)
-    int32_t *wbase_surv, *wbase_sel;   // (NCHUNK * S + 1,): chunk-major work items
-    ItemGeom *items_surv, *items_sel;  // one record per work item
+    double *thr_cull, *maxsurv, *thr_sel;
+    int32_t *surv_idx;  // (S * nmodel,) worst case: candidate lists, then band queues, then derived lists
+    int64_t *surv_off;  // (S + 1,) candidate list offsets; [S] = candidates of the batch
+    int64_t *coffsets;  // (S, NCHUNK) candidate list offsets per chunk (kept for k_rec_index)
+    int64_t *dcounts, *doffsets;       // (S, NCHUNK) derived lists
+    int64_t *der_off;                  // (S + 1,)
+    int32_t *wbase_surv, *wbase_der;   // (NCHUNK * S + 1,): chunk-major work items
+    ItemGeom *items_surv, *items_der;  // one record per work item
     int32_t *bandn;                    // (S * NCHUNK,) band-queue fill of k_sel_classify
-    unsigned long long *mask;          // (S, nmodel_pad / 64) membership words
-    // second-generation path (fit2_kernels.hpp)
+    unsigned long long *mask, *dmask;  // (S, nmodel_pad / 64) selected / selected-and-derived
+    unsigned long long *smask;         // candidate bit-mask, same layout
+    double *step_st, *lnprob_st;       // (S * nmodel,) worst case: flux-phase step size and final
+                                       // first-cut statistic, by candidate-list position
     Star32 *s32;                       // (S,)
     float *lnlp32, *lnpr32;            // (S, nmodel) float32 statistics
     float *part32, *st32;              // (nblk2, S, NV32), (S, NV32)
     int32_t *status, *ids_all;         // (S,)
     double *nomA, *nomB, *candS;       // (S,)
-    unsigned long long *smask;         // survivor bit-mask, layout of `mask`
     float *aud;                        // (S,) run-time audit of eps
     StarPrep *stars_tmp;               // (1,) scratch for the deep K1 probe
     size_t part_doubles;
     size_t bytes;
 };
 
+// (2 MiB: the granule of the device's large pages -- every array the list kernels stream
+// through starts on a page boundary of its own)
 size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+size_t align_big(size_t x) { return (x + ((size_t)2 << 20) - 1) & ~(((size_t)2 << 20) - 1); }
 
-// Lay the workspace out over `base` (may be null: sizing only).  When the
-// caller supplies the output planes (loglike_batch) they are used instead of
-// workspace planes.
-Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
+// Lay the workspace out over `base` (may be null: sizing only).  fit = false:
+// brutus_loglike_batch (the caller supplies the output planes); fit = true: brutus_fit_batch.
+Workspace carve(char *base, int64_t nmodel, int nstar, bool fit) {
     Workspace w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -117,19 +124,15 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         off += align_up(n);
         return p;
     };
-    const size_t plane = (size_t)nstar * (size_t)nmodel * sizeof(double);
+    auto take_big = [&](size_t n) {       // plane-sized arrays: absolute 2 MiB alignment
+        off = align_big((size_t)base + off) - (size_t)base;
+        char *p = base ? base + off : nullptr;
+        off += n;
+        return p;
+    };
+    const size_t pairs = (size_t)nstar * (size_t)nmodel;
     const int64_t ntile = pad_models(nmodel) / TILE;
     w.pl.nmodel = nmodel;
-    w.pl.lnlp = (double *)take(plane);
-    w.pl.step = (double *)take(plane);
-    if (own_outputs) {
-        w.pl.lnl = (double *)take(plane);
-        w.pl.chi2 = (double *)take(plane);
-        w.pl.scale = (double *)take(plane);
-        w.pl.av = (double *)take(plane);
-        w.pl.rv = (double *)take(plane);
-        for (int q = 0; q < 6; ++q) w.pl.icov[q] = (double *)take(plane);
-    }
     w.stars = (StarPrep *)take(sizeof(StarPrep) * nstar);
     w.part_doubles = (size_t)ntile * (size_t)(nstar * 2 * KCAP > 1024 ? nstar * 2 * KCAP : 1024);
     w.part = (double *)take(sizeof(double) * w.part_doubles);
@@ -140,31 +143,34 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
     w.n_unconv = (int32_t *)take(sizeof(int32_t) * 4);
     w.counts = (int64_t *)take(sizeof(int64_t) * nstar * NCHUNK);
     w.offsets = (int64_t *)take(sizeof(int64_t) * nstar * NCHUNK);
-    if (own_outputs) {
-        w.pl.lnprob = (double *)take(plane);
+    if (!fit) {
+        w.pl.lnlp = (double *)take_big(sizeof(double) * pairs);
+        w.pl.step = (double *)take_big(sizeof(double) * pairs);
+    } else {
         w.ids = (int32_t *)take(sizeof(int32_t) * nstar);
         w.kfix = (int32_t *)take(sizeof(int32_t) * nstar);
         w.thr_cull = (double *)take(sizeof(double) * nstar);
-        w.maxns = (double *)take(sizeof(double) * nstar);
-        w.maxns_part = (double *)take(sizeof(double) * nstar * NCHUNK);
         w.maxsurv = (double *)take(sizeof(double) * nstar);
         w.thr_sel = (double *)take(sizeof(double) * nstar);
-        w.surv_idx = (int32_t *)take(sizeof(int32_t) * (size_t)nstar * (size_t)nmodel);
         w.surv_off = (int64_t *)take(sizeof(int64_t) * (nstar + 1));
+        w.der_off = (int64_t *)take(sizeof(int64_t) * (nstar + 1));
+        w.coffsets = (int64_t *)take(sizeof(int64_t) * nstar * NCHUNK);
+        w.dcounts = (int64_t *)take(sizeof(int64_t) * nstar * NCHUNK);
+        w.doffsets = (int64_t *)take(sizeof(int64_t) * nstar * NCHUNK);
         w.wbase_surv = (int32_t *)take(sizeof(int32_t) * ((size_t)NCHUNK * nstar + 1));
-        w.wbase_sel = (int32_t *)take(sizeof(int32_t) * ((size_t)NCHUNK * nstar + 1));
+        w.wbase_der = (int32_t *)take(sizeof(int32_t) * ((size_t)NCHUNK * nstar + 1));
         {
             const size_t nit = (size_t)nstar * ((size_t)(pad_models(nmodel) / TILE) + NCHUNK);
             w.items_surv = (ItemGeom *)take(sizeof(ItemGeom) * nit);
-            w.items_sel = (ItemGeom *)take(sizeof(ItemGeom) * nit);
+            w.items_der = (ItemGeom *)take(sizeof(ItemGeom) * nit);
         }
         w.bandn = (int32_t *)take(sizeof(int32_t) * (size_t)NCHUNK * nstar);
-        w.mask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
-                                            (size_t)(pad_models(nmodel) / 64));
+        const size_t words = (size_t)nstar * (size_t)(pad_models(nmodel) / 64);
+        w.mask = (unsigned long long *)take_big(sizeof(unsigned long long) * words);
+        w.dmask = (unsigned long long *)take_big(sizeof(unsigned long long) * words);
+        w.smask = (unsigned long long *)take_big(sizeof(unsigned long long) * words);
         const size_t nblk2 = (size_t)(ntile + F2_T - 1) / F2_T;
         w.s32 = (Star32 *)take(sizeof(Star32) * nstar);
-        w.lnlp32 = (float *)take(sizeof(float) * (size_t)nstar * (size_t)nmodel);
-        w.lnpr32 = (float *)take(sizeof(float) * (size_t)nstar * (size_t)nmodel);
         w.part32 = (float *)take(sizeof(float) * nblk2 * nstar * NV32);
         w.st32 = (float *)take(sizeof(float) * nstar * NV32);
         w.status = (int32_t *)take(sizeof(int32_t) * nstar);
@@ -172,11 +178,14 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool own_outputs) {
         w.nomA = (double *)take(sizeof(double) * nstar);
         w.nomB = (double *)take(sizeof(double) * nstar);
         w.candS = (double *)take(sizeof(double) * nstar);
-        w.smask = (unsigned long long *)take(sizeof(unsigned long long) * (size_t)nstar *
-                                             (size_t)(pad_models(nmodel) / 64));
         w.aud = (float *)take(sizeof(float) * nstar * 4);
+        w.lnlp32 = (float *)take_big(sizeof(float) * pairs);
+        w.lnpr32 = (float *)take_big(sizeof(float) * pairs);
+        w.surv_idx = (int32_t *)take_big(sizeof(int32_t) * pairs);
+        w.step_st = (double *)take_big(sizeof(double) * pairs);
+        w.lnprob_st = (double *)take_big(sizeof(double) * pairs);
     }
-    w.bytes = off;
+    w.bytes = align_big(off) + (base ? 0 : (size_t)4 << 20);     // (sizing: room for the base's own offset)
     return w;
 }
 
@@ -340,171 +349,9 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
 
-// ---- fast path host orchestration ------------------------------------------
+// ---- hot path host orchestration (brutus_fit_batch) ----------------------------------
 constexpr int FS_TILES_PER_BLOCK = 8;
 constexpr int PERSIST_BLOCKS = 4096;
-
-template <int NB, bool RVF>
-void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, int64_t nmodel_pad,
-                  int nstar, const StarPrep *stars, const DevParams &p, const int32_t *k1,
-                  const int32_t *k2, const int32_t *surv_idx, const int64_t *surv_off,
-                  const int32_t *wbase, const ItemGeom *items, const Planes &pl, double *part,
-                  float *surv32, const double *thr_cull) {
-    if (first)
-        hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
-                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase,
-                           items, pl, part, surv32, thr_cull);
-    else
-        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
-                           nmodel, nmodel_pad, nstar, stars, p, k1, k2, surv_idx, surv_off, wbase,
-                           items, pl, part, surv32, thr_cull);
-}
-
-template <int NB, int KS, int G, bool RVF>
-int launch_fscan(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> &ids,
-                 const std::vector<int32_t> &kfix, const DevParams &p, Workspace &w, int accept,
-                 hipStream_t st, Timer &tm) {
-    const int64_t nmodel_pad = pad_models(nmodel);
-    const int ntile = (int)(nmodel_pad / TILE);
-    const int nblkx = (ntile + FS_TILES_PER_BLOCK - 1) / FS_TILES_PER_BLOCK;
-    const int nrun = (int)ids.size();
-    HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
-    constexpr int NV = 2 * KS + 2;
-    const size_t shmem = (size_t)G * NV * TILE * sizeof(double);
-    tm.begin("k_fscan");
-    hipLaunchKernelGGL((k_fscan<NB, KS, G, RVF>), dim3(nblkx, (nrun + G - 1) / G), dim3(TILE), shmem, st,
-                       grid, nmodel, nmodel_pad, nstar, nrun, w.ids, w.stars, p, w.kfix,
-                       FS_TILES_PER_BLOCK, ntile, w.pl, w.part);
-    tm.end();
-    hipLaunchKernelGGL(k_fdecide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, nrun, w.ids, KS,
-                       w.part, p, accept, w.k1, w.thr_cull, w.maxns);
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NB, bool RVF>
-int run_select_emit(const float *grid, int64_t nmodel, int nstar, const DevParams &p, Workspace &w,
-                    int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
-                    hipStream_t st, Timer &tm, int path = 1) {
-    const int64_t nmodel_pad = pad_models(nmodel);
-    const int ntile = (int)(nmodel_pad / TILE);
-    tm.begin("k_select");
-    if (path == 1)
-        hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                           w.pl.lnprob, w.thr_sel, (const double *)nullptr, w.counts,
-                           (double *)nullptr, w.mask);
-    // path 2: k_sel_classify / k_sel_band have left the membership words and the chunk counts
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts,
-                       w.offsets, d_sel_off, w.wbase_sel);
-    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_sel,
-                       w.offsets, d_sel_off, w.items_sel);
-    hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                       w.mask, w.offsets, capacity, d_sel_idx);
-    tm.end();
-    tm.begin("k_emit");
-    hipLaunchKernelGGL((k_emit<NB, RVF>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid, nmodel,
-                       nmodel_pad, nstar, w.stars, p, w.k1, w.thr_cull, d_sel_idx, d_sel_off,
-                       w.wbase_sel, w.items_sel, w.pl, capacity, d_sel_vals,
-                       path == 2 ? (const float *)w.lnpr32 : (const float *)nullptr, w.surv_off);
-    tm.end();
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-template <int NB, bool RVF>
-int run_fast(const float *grid, int64_t nmodel, int nstar, const DevParams &p, int max_iter,
-             Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
-             int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2, hipStream_t st, Timer &tm) {
-    const int64_t nmodel_pad = pad_models(nmodel);
-    const int ntile = (int)(nmodel_pad / TILE);
-    std::vector<int32_t> ids(nstar), kfix(nstar, 2), k1(nstar, 0);
-    for (int s = 0; s < nstar; ++s) ids[s] = s;
-
-    // ---- fused scan, speculating K1 = 2 --------------------------------------
-    if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, ids, kfix, p, w, 0, st, tm)) return rc;
-    HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    std::vector<int32_t> listA, listB;
-    for (int s = 0; s < nstar; ++s) {
-        if (k1[s] == 1) listA.push_back(s);
-        if (k1[s] == 0) listB.push_back(s);
-    }
-    if (!listA.empty()) {   // converged after ONE sweep: redo those stars with one sweep
-        for (int s : listA) kfix[s] = 1;
-        if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, listA, kfix, p, w, 1, st, tm)) return rc;
-    }
-    if (!listB.empty()) {   // needs more than two sweeps: probe up to eight
-        for (int s : listB) kfix[s] = 8;
-        if (int rc = launch_fscan<NB, 8, 1, RVF>(grid, nmodel, nstar, listB, kfix, p, w, 0, st, tm)) return rc;
-        HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        std::vector<int32_t> listC;
-        for (int s : listB) {
-            if (k1[s] == 0)     // more than eight sweeps: probe deeper, no cap but max_iter
-                if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &k1[s], st)) return rc;
-            if (k1[s] > max_iter)
-                return fail(BRUTUS_ENOCONV, "magnitude phase of star %d needs %d sweeps (max_iter %d)", s,
-                            k1[s], max_iter);
-            if (k1[s] != 8) {
-                kfix[s] = k1[s];
-                listC.push_back(s);
-            }
-        }
-        if (!listC.empty())
-            if (int rc = launch_fscan<NB, 2, 4, RVF>(grid, nmodel, nstar, listC, kfix, p, w, 1, st, tm)) return rc;
-    }
-
-    // ---- cull: ordered survivor lists -----------------------------------------
-    tm.begin("k_surv_compact");
-    hipLaunchKernelGGL(k_cmp_count, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile, w.pl.lnlp,
-                       w.thr_cull, w.pl.lnprob, w.counts, w.maxns_part, w.mask);
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
-                       w.surv_off, w.wbase_surv);
-    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_surv,
-                       w.offsets, w.surv_off, w.items_surv);
-    hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), dim3(TILE), 0, st, nmodel, ntile,
-                       w.mask, w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
-    tm.end();
-
-    // ---- flux phase on survivors ------------------------------------------------
-    hipLaunchKernelGGL(k_set_i32, dim3((nstar + 255) / 256), dim3(256), 0, st, w.k2, nstar, 2);
-    int32_t h_unconv = 0;
-    int iter = 2;
-    for (int first = 1;; first = 0) {
-        HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
-        tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
-                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, (float *)nullptr,
-                              (const double *)nullptr);
-        tm.end();
-        hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
-                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
-        HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        if (h_unconv == 0) break;
-        if (iter >= max_iter)
-            return fail(BRUTUS_ENOCONV, "flux phase not converged after %d iterations for %d star(s)",
-                        iter, h_unconv);
-        ++iter;
-    }
-
-    // ---- first cut of lnpost + records ------------------------------------------
-    hipLaunchKernelGGL(k_sel_thresh, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxns_part,
-                       w.maxsurv, p.ln_wt, w.thr_sel);
-    if (int rc = run_select_emit<NB, RVF>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
-                                     d_sel_off, st, tm))
-        return rc;
-    if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-    if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipGetLastError());
-    return 0;
-}
-
-
-// ---- second-generation fast path (fit2_kernels.hpp) -----------------------------
-std::mutex g_path_mu;
-std::unordered_map<const void *, int> g_ws_path;     // workspace -> path of its last fit (1 / 2)
 
 int env_int(const char *name, int dflt) {
     const char *v = getenv(name);
@@ -513,6 +360,41 @@ int env_int(const char *name, int dflt) {
 double env_double(const char *name, double dflt) {
     const char *v = getenv(name);
     return v && *v ? atof(v) : dflt;
+}
+
+template <int NB, bool RVF>
+void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, int64_t nmodel_pad,
+                  int nstar, const DevParams &p, const Workspace &w, const RecPlanes &rec) {
+    if (first)
+        hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
+                           nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx, w.surv_off,
+                           w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part, w.lnpr32,
+                           w.thr_cull);
+    else
+        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
+                           nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx, w.surv_off,
+                           w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part, w.lnpr32,
+                           w.thr_cull);
+}
+
+// Exact K1 of the stars in `ids` by probing KS = 8 sweeps in float64 (k1 = 0: more needed).
+template <int NB, bool RVF>
+int launch_k1probe(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> &ids,
+                   const DevParams &p, Workspace &w, hipStream_t st, Timer &tm) {
+    constexpr int KS = 8;
+    const int64_t nmodel_pad = pad_models(nmodel);
+    const int ntile = (int)(nmodel_pad / TILE);
+    const int nblkx = (ntile + FS_TILES_PER_BLOCK - 1) / FS_TILES_PER_BLOCK;
+    const int nrun = (int)ids.size();
+    HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
+    tm.begin("k_k1probe");
+    hipLaunchKernelGGL((k_k1probe<NB, KS, RVF>), dim3(nblkx, nrun), dim3(TILE), 0, st, grid, nmodel,
+                       nmodel_pad, nstar, nrun, w.ids, w.stars, p, FS_TILES_PER_BLOCK, ntile, w.part);
+    tm.end();
+    hipLaunchKernelGGL(k_k1_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, w.ids, KS, w.part,
+                       p.ln_init, w.k1);
+    HIP_TRY(hipGetLastError());
+    return 0;
 }
 
 // Exact number of magnitude sweeps of ONE star by probing kmax = 16, 32, ... sweeps
@@ -577,21 +459,26 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     return 0;
 }
 
+// h_counts[0] = selected models of the batch (= d_rec_off[nstar]), [1] = candidates of the
+// cull (the record slots the flux phase owns), [2] = record slots needed in all.
 template <int NB, bool RVF>
-int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevParams &p,
-              int max_iter, Workspace &w, int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
-              int64_t *d_sel_off, int32_t *h_k1, int32_t *h_k2, hipStream_t st, Timer &tm) {
+int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevParams &p,
+            int max_iter, Workspace &w, int64_t capacity, int32_t *d_rec_idx, int32_t *d_rec_slot,
+            double *d_rec_vals, int64_t *d_rec_off, int32_t *h_k1, int32_t *h_k2, int64_t *h_counts,
+            hipStream_t st, Timer &tm) {
     constexpr int G = 4;
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     const int nblkx = (ntile + F2_T - 1) / F2_T;
     const dim3 blk(TILE);
+    const RecPlanes rec{d_rec_vals, capacity};
     std::vector<int32_t> ids(nstar), kfix(nstar, 2), k1(nstar, 0), status(nstar, 0);
     for (int s = 0; s < nstar; ++s) ids[s] = s;
     HIP_TRY(hipMemcpyAsync(w.ids_all, ids.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
     const int audit_on = env_int("BRUTUS_AUDIT", 0);
     float *aud = audit_on ? w.aud : nullptr;
     if (aud) HIP_TRY(hipMemsetAsync(w.aud, 0, sizeof(float) * nstar * 4, st));
+    h_counts[0] = h_counts[1] = h_counts[2] = 0;
 
     // ---- float32 pass over the whole grid; K1 where float32 can decide it ----------
     hipLaunchKernelGGL(k_prep32, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.stars,
@@ -606,8 +493,7 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
         if (status[s] == 2) probe.push_back(s);
     }
     if (!probe.empty()) {   // float32 could not decide: exact probe (float64, up to 8 sweeps, then deeper)
-        for (int s : probe) kfix[s] = 8;
-        if (int rc = launch_fscan<NB, 8, 1, RVF>(grid, nmodel, nstar, probe, kfix, p, w, 0, st, tm)) return rc;
+        if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, probe, p, w, st, tm)) return rc;
         HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int s : probe) {
@@ -637,29 +523,38 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
     tm.begin("k_surv_compact");
     hipLaunchKernelGGL(k_cmp_count32, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.lnlp32, w.candS,
                        w.counts, w.smask);
-    hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, w.counts, w.offsets,
-                       w.surv_off, w.wbase_surv);
+    {
+        const OffsetsJob job{w.counts, w.coffsets, w.surv_off, w.wbase_surv};
+        hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, job, job);
+    }
     hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_surv,
-                       w.offsets, w.surv_off, w.items_surv);
+                       w.coffsets, w.surv_off, w.items_surv);
     hipLaunchKernelGGL(k_cmp_scatter, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.smask,
-                       w.offsets, (int64_t)nstar * nmodel, w.surv_idx);
+                       w.coffsets, (int64_t)nstar * nmodel, w.surv_idx);
     tm.end();
+    int64_t h_ncand = 0;
+    HIP_TRY(hipMemcpyAsync(&h_ncand, w.surv_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 
-    // ---- exact cull test + flux phase on the candidates -----------------------------------
+    // ---- exact cull test + flux phase on the candidates; results into the record planes ------
     hipLaunchKernelGGL(k_set_i32, dim3((nstar + 255) / 256), dim3(256), 0, st, w.k2, nstar, 2);
     int32_t h_unconv = 0;
     int iter = 2;
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2,
-                              w.surv_idx, w.surv_off, w.wbase_surv, w.items_surv, w.pl, w.part, w.lnpr32,
-                              w.thr_cull);
+        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, p, w, rec);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
         HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (first && h_ncand > capacity) {
+            // the flux phase keeps its results in the record planes: nothing to go on with
+            h_counts[1] = h_ncand;
+            h_counts[2] = 2 * h_ncand;       // (the derived records come on top; a guess)
+            return fail(BRUTUS_ENOMEM, "record buffer too small: %lld candidate slots, capacity %lld",
+                        (long long)h_ncand, (long long)capacity);
+        }
         if (h_unconv == 0) break;
         if (iter >= max_iter)
             return fail(BRUTUS_ENOCONV, "flux phase not converged after %d iterations for %d star(s)",
@@ -667,7 +562,7 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
         ++iter;
     }
 
-    // ---- exact first-cut threshold, selection mask, ordered lists, records ---------------
+    // ---- exact first-cut threshold, selection masks ---------------------------------------
     hipLaunchKernelGGL(k_nomB, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxsurv, w.s32, w.nomB);
     tm.begin("k_top");
     hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
@@ -678,27 +573,46 @@ int run_fast2(const float *grid, int64_t nmodel, int nfilt, int nstar, const Dev
                        w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
     tm.begin("k_sel_classify");
     hipLaunchKernelGGL(k_sel_classify, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.s32,
-                       w.lnpr32, w.pl.lnprob, w.surv_off, w.thr_sel, w.counts, w.mask, w.surv_idx,
-                       w.bandn);
+                       w.lnpr32, w.lnprob_st, w.surv_off, w.thr_sel, w.counts, w.mask, w.dcounts,
+                       w.dmask, w.surv_idx, w.bandn);
     tm.end();
     tm.begin("k_sel_band");      // (the candidate lists in surv_idx are no longer needed)
     hipLaunchKernelGGL((k_sel_band<NB, RVF>), dim3(NCHUNK / SB_C, nstar, SB_Z), blk, 0, st, grid, nmodel, nmodel_pad,
                        ntile, w.stars, p, w.k1, w.lnpr32, w.thr_sel, w.surv_idx, w.bandn, w.counts,
-                       w.mask, aud ? aud + 2 * nstar : nullptr);
+                       w.mask, w.dcounts, w.dmask, aud ? aud + 2 * nstar : nullptr);
     tm.end();
-    if (int rc = run_select_emit<NB, RVF>(grid, nmodel, nstar, p, w, capacity, d_sel_idx, d_sel_vals,
-                                          d_sel_off, st, tm, 2))
-        return rc;
+
+    // ---- record index (model, slot) in np.where order; values of the derived records -------
+    tm.begin("k_select");
+    {
+        const OffsetsJob sel{w.counts, w.offsets, d_rec_off, nullptr};
+        const OffsetsJob der{w.dcounts, w.doffsets, w.der_off, w.wbase_der};
+        hipLaunchKernelGGL(k_offsets, dim3(2), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, sel, der);
+    }
+    hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_der,
+                       w.doffsets, w.der_off, w.items_der);
+    // (the band queues in surv_idx are no longer needed either: it now takes the derived lists)
+    hipLaunchKernelGGL(k_rec_index, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, nstar, w.mask, w.dmask,
+                       w.smask, w.offsets, w.doffsets, w.coffsets, w.surv_off, capacity, d_rec_idx,
+                       d_rec_slot, w.surv_idx);
+    tm.end();
+    tm.begin("k_derive");
+    hipLaunchKernelGGL((k_derive<NB, RVF>), dim3(PERSIST_BLOCKS), blk, 0, st, grid, nmodel_pad, nstar,
+                       w.stars, p, w.k1, w.surv_idx, w.wbase_der, w.items_der, w.surv_off, rec);
+    tm.end();
+    int64_t h_nder = 0;
+    HIP_TRY(hipMemcpyAsync(&h_counts[0], d_rec_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(&h_nder, w.der_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    h_counts[1] = h_ncand;
+    h_counts[2] = h_ncand + h_nder;
+    if (h_counts[2] > capacity)
+        return fail(BRUTUS_ENOMEM, "record buffer too small: %lld slots needed, capacity %lld",
+                    (long long)h_counts[2], (long long)capacity);
     return 0;
-}
-
-// which path brutus_fit_batch takes: 2 (default) unless BRUTUS_FIT_PATH=1
-int fit_path(int64_t nmodel) {
-    (void)nmodel;
-    return env_int("BRUTUS_FIT_PATH", 2) == 1 ? 1 : 2;
 }
 
 
@@ -1055,43 +969,19 @@ int mt_walk(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states, st
 // specialisation computes the same thing
 inline bool rv_pinned(const DevParams &p) { return p.rvmin == p.rvmax && p.rv_mean == p.rvmin; }
 
-int dispatch_fast(int nb, int path, int nfilt, const float *grid, int64_t nmodel, int nstar,
-                  const DevParams &p, int max_iter, Workspace &w, int64_t capacity,
-                  int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off, int32_t *h_k1,
-                  int32_t *h_k2, hipStream_t st, Timer &tm) {
+int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar,
+                 const DevParams &p, int max_iter, Workspace &w, int64_t capacity,
+                 int32_t *d_rec_idx, int32_t *d_rec_slot, double *d_rec_vals, int64_t *d_rec_off,
+                 int32_t *h_k1, int32_t *h_k2, int64_t *h_counts, hipStream_t st, Timer &tm) {
     const bool rvf = rv_pinned(p);
 #define BRUTUS_CASE(N)                                                                             \
     case N:                                                                                        \
-        if (path == 2)                                                                             \
-            return rvf ? run_fast2<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,  \
-                                            d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm)  \
-                       : run_fast2<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity, \
-                                             d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);\
-        return rvf ? run_fast<N, true>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,   \
-                                       d_sel_vals, d_sel_off, h_k1, h_k2, st, tm)                  \
-                   : run_fast<N, false>(grid, nmodel, nstar, p, max_iter, w, capacity, d_sel_idx,  \
-                                        d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);
-    switch (nb) {
-        BRUTUS_CASE(8)
-        BRUTUS_CASE(12)
-        BRUTUS_CASE(16)
-        BRUTUS_CASE(24)
-        BRUTUS_CASE(32)
-    }
-#undef BRUTUS_CASE
-    return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
-}
-
-int dispatch_select_emit(int nb, int path, const float *grid, int64_t nmodel, int nstar,
-                         const DevParams &p, Workspace &w, int64_t capacity, int32_t *d_sel_idx,
-                         double *d_sel_vals, int64_t *d_sel_off, hipStream_t st, Timer &tm) {
-    const bool rvf = rv_pinned(p);
-#define BRUTUS_CASE(N)                                                                             \
-    case N:                                                                                        \
-        return rvf ? run_select_emit<N, true>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,      \
-                                              d_sel_vals, d_sel_off, st, tm, path)                 \
-                   : run_select_emit<N, false>(grid, nmodel, nstar, p, w, capacity, d_sel_idx,     \
-                                               d_sel_vals, d_sel_off, st, tm, path);
+        return rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,        \
+                                      d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,    \
+                                      h_counts, st, tm)                                            \
+                   : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,       \
+                                       d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,   \
+                                       h_counts, st, tm);
     switch (nb) {
         BRUTUS_CASE(8)
         BRUTUS_CASE(12)
@@ -1160,7 +1050,8 @@ int brutus_grid_relayout(const float *d_models_aos, int64_t nmodel, int nfilt, f
 
 size_t brutus_workspace_bytes(int64_t nmodel, int nfilt, int nstar) {
     if (check_common(nmodel, nfilt, nstar)) return 0;
-    return carve(nullptr, nmodel, nstar, true).bytes;
+    const size_t a = carve(nullptr, nmodel, nstar, true).bytes, b = carve(nullptr, nmodel, nstar, false).bytes;
+    return a > b ? a : b;
 }
 
 int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nstar,
@@ -1201,44 +1092,19 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int
     return 0;
 }
 
-int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt, int nstar,
-                      const brutus_params *params, void *d_workspace, size_t workspace_bytes,
-                      int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals,
-                      int64_t *d_sel_off, void *stream) {
-    if (int rc = check_common(nmodel, nfilt, nstar)) return rc;
-    DevParams p;
-    if (int rc = make_params(params, p)) return rc;
-    if (!d_grid_soa || !d_workspace || !d_sel_idx || !d_sel_vals || !d_sel_off || capacity < 0)
-        return fail(BRUTUS_EINVAL, "bad gather arguments");
-    Workspace w = carve((char *)d_workspace, nmodel, nstar, true);
-    if (w.bytes > workspace_bytes) return fail(BRUTUS_ENOMEM, "workspace too small");
-    hipStream_t st = (hipStream_t)stream;
-    Timer tm(st);
-    int path = 1;
-    {
-        std::lock_guard<std::mutex> lk(g_path_mu);
-        auto it = g_ws_path.find(d_workspace);
-        if (it != g_ws_path.end()) path = it->second;
-    }
-    int rc = dispatch_select_emit(padded_nb(nfilt), path, d_grid_soa, nmodel, nstar, p, w, capacity,
-                                  d_sel_idx, d_sel_vals, d_sel_off, st, tm);
-    if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
-    return 0;
-}
-
 int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nstar,
                      const double *d_flux, const double *d_err, const uint8_t *d_mask,
                      const double *d_parallax, const double *d_parallax_err, int has_parallax,
                      const brutus_params *params, void *d_workspace, size_t workspace_bytes,
-                     int64_t capacity, int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
-                     int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2, void *stream) {
+                     int64_t capacity, int32_t *d_rec_idx, int32_t *d_rec_slot, double *d_rec_vals,
+                     int64_t *d_rec_off, int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
+                     int64_t *h_counts, void *stream) {
     if (int rc = check_common(nmodel, nfilt, nstar)) return rc;
     DevParams p;
     if (int rc = make_params(params, p)) return rc;
-    if (!d_grid_soa || !d_flux || !d_err || !d_mask || !d_workspace || !d_sel_idx || !d_sel_vals ||
-        !d_sel_off || !d_ndim || capacity < 0)
-        return fail(BRUTUS_EINVAL, "NULL device pointer");
+    if (!d_grid_soa || !d_flux || !d_err || !d_mask || !d_workspace || !d_rec_idx || !d_rec_slot ||
+        !d_rec_vals || !d_rec_off || !d_ndim || !h_counts || capacity < 0 || capacity > INT32_MAX)
+        return fail(BRUTUS_EINVAL, "NULL pointer or capacity outside [0, 2^31)");
     Workspace w = carve((char *)d_workspace, nmodel, nstar, true);
     if (w.bytes > workspace_bytes)
         return fail(BRUTUS_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.bytes,
@@ -1249,15 +1115,11 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
                              has_parallax, w, d_ndim, st))
         return rc;
     const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
-    const int path = fit_path(nmodel);
-    {
-        std::lock_guard<std::mutex> lk(g_path_mu);
-        g_ws_path[d_workspace] = path;
-    }
-    int rc = dispatch_fast(padded_nb(nfilt), path, nfilt, d_grid_soa, nmodel, nstar, p, max_iter, w,
-                           capacity, d_sel_idx, d_sel_vals, d_sel_off, h_k1, h_k2, st, tm);
+    int rc = dispatch_fit(padded_nb(nfilt), nfilt, d_grid_soa, nmodel, nstar, p, max_iter, w,
+                          capacity, d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,
+                          h_counts, st, tm);
+    (void)hipStreamSynchronize(st);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);
     tm.collect();
     return 0;
@@ -1569,7 +1431,7 @@ size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc) {
 }  // extern "C"
 
 namespace {
-int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                       const double *d_sel_vals, const int64_t *d_sel_off, const double *d_lnprior,
                       const double *d_feh, const double *d_loga, const double *d_coords,
                       const double *d_parallax, const double *d_parallax_err,
@@ -1580,7 +1442,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                   "post params layout");
     if (nstar < 1 || nstar > BRUTUS_MAX_BATCH || capacity < 1)
         return fail(BRUTUS_EINVAL, "bad post dimensions");
-    if (!d_sel_idx || !d_sel_vals || !d_sel_off || !d_lnprior || !d_coords || !params ||
+    if (!d_sel_idx || !d_rec_slot || !d_sel_vals || !d_sel_off || !d_lnprior || !d_coords || !params ||
         !d_workspace || !d_out_idx || !d_out_vals || !h_star_out || !h_flags)
         return fail(BRUTUS_EINVAL, "NULL pointer");
     if (params->nmc < 1 || params->ndraws < 1 || !(params->wt_thresh > 0.))
@@ -1605,7 +1467,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
     hipLaunchKernelGGL(k_post_geom, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, d_coords,
                        d_parallax, d_parallax_err, dc, w.geom);
     tm.begin("k_post_lnp1");
-    hipLaunchKernelGGL(k_post_lnp1, g2, blk, 0, st, pp, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+    hipLaunchKernelGGL(k_post_lnp1, g2, blk, 0, st, pp, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                        w.geom, d_lnprior, d_feh, d_loga, w.lnp1, w.part);
     tm.end();
     tm.begin("k_post_cut2");
@@ -1613,7 +1475,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                        w.counts, w.mask);
     hipLaunchKernelGGL(k_post_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, pp, nstar, w.counts,
                        w.offsets, w.off2, w.nbase, w.flags, w.nsel);
-    hipLaunchKernelGGL(k_post_scatter2, g2, blk, 0, st, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+    hipLaunchKernelGGL(k_post_scatter2, g2, blk, 0, st, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                        d_lnprior, w.mask, w.offsets, w.rp);
     tm.end();
     {   // objects with more than nsel_max survivors: sort + clip on the device
@@ -1642,7 +1504,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
             hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
                                capacity, 0, nitem, w.mc_counter, (const double *)nullptr,
-                               (const int64_t *)nullptr, w.mc_stage, d_sel_idx, d_sel_vals, d_sel_off,
+                               (const int64_t *)nullptr, w.mc_stage, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp,
                                w.part_max, w.part_chi2);
         }
@@ -1657,7 +1519,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
         tm.end();
         tm.begin("k_post_draw");
         hipLaunchKernelGGL(k_post_draw, gdraw, dim3(64), 0, st, pp, 0, (const double *)nullptr,
-                           (const int64_t *)nullptr, (const double *)nullptr, capacity, d_sel_idx,
+                           (const int64_t *)nullptr, (const double *)nullptr, capacity, d_sel_idx, d_rec_slot,
                            d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh,
                            d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
         tm.end();
@@ -1766,14 +1628,14 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
                     hipLaunchKernelGGL(k_post_mc_arr, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk,
                                        sizeof(double) * (TILE / 64) * MCA_R * 3 * pp.nmc,
                                        st, pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
-                                       (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx,
+                                       (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx, d_rec_slot,
                                        d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
                                        d_loga, w.rp, w.part_max, w.part_chi2);
                 else
                     hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
                                        pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, w.mc_stage,
-                                       d_sel_idx, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
+                                       d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
                                        w.geom, d_feh, d_loga, w.rp, w.part_max, w.part_chi2);
             }
             tm.end();
@@ -1789,7 +1651,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
             tm.begin("k_post_draw");
             hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, ng), dim3(64), 0, st, pp, s0,
                                (const double *)zbase, (const int64_t *)w.mt_zoff,
-                               (const double *)w.mt_uni, capacity, d_sel_idx, d_sel_vals, d_sel_off,
+                               (const double *)w.mt_uni, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.cdf,
                                w.star_out, d_out_idx, d_out_vals);
             tm.end();
@@ -1815,19 +1677,19 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx,
 
 extern "C" {
 
-int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                       const double *d_sel_vals, const int64_t *d_sel_off, const double *d_lnprior,
                       const double *d_feh, const double *d_loga, const double *d_coords,
                       const double *d_parallax, const double *d_parallax_err,
                       const brutus_post_params *params, void *d_workspace, size_t workspace_bytes,
                       int32_t *d_out_idx, double *d_out_vals, double *h_star_out,
                       int32_t *h_flags, uint64_t *h_nbase, void *stream) {
-    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, h_nbase, stream, nullptr);
 }
 
-int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                             const double *d_sel_vals, const int64_t *d_sel_off,
                             const double *d_lnprior, const double *d_feh, const double *d_loga,
                             const double *d_coords, const double *d_parallax,
@@ -1839,12 +1701,12 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
     if ((nstream != 1 && nstream != nstar) || !h_states || !d_zbuf || zbuf_doubles < 1024)
         return fail(BRUTUS_EINVAL, "bad numpy-stream arguments");
     MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles, 0};
-    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
 }
 
-int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                                   const double *d_sel_vals, const int64_t *d_sel_off,
                                   const double *d_lnprior, const double *d_feh, const double *d_loga,
                                   const double *d_coords, const double *d_parallax,
@@ -1857,7 +1719,7 @@ int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_
         phase < 0 || phase > 2)
         return fail(BRUTUS_EINVAL, "bad numpy-stream arguments");
     MtArgs mt{nstream, h_states, d_zbuf, zbuf_doubles, phase};
-    return post_batch_impl(nstar, capacity, d_sel_idx, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
+    return post_batch_impl(nstar, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
 }
@@ -2000,9 +1862,7 @@ int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
     const void *src = nullptr;
     size_t have = 0;
     switch (which) {
-        case 0: src = w.pl.lnlp; have = 8 * plane; break;       // path 1: float64 cull statistic
-        case 1: src = w.pl.lnprob; have = 8 * plane; break;     // path 1: float64 first-cut statistic
-        case 2: src = w.lnlp32; have = 4 * plane; break;        // path 2: float32 statistics
+        case 2: src = w.lnlp32; have = 4 * plane; break;        // float32 statistics
         case 3: src = w.lnpr32; have = 4 * plane; break;
         case 4: src = w.aud; have = 4 * (size_t)nstar * 4; break;
         case 5: src = w.s32; have = sizeof(Star32) * (size_t)nstar; break;

@@ -1,6 +1,6 @@
-// fit2_kernels.hpp -- second-generation hot path behind brutus_fit_batch
-// Part of the single translation unit brutus_kernels.hip (included after
-// fit_kernels.hpp); everything lives in that unit's anonymous namespace.
+// fit2_kernels.hpp -- the hot path behind brutus_fit_batch: float32 proof pass, exact
+// thresholds, selection.  Part of the single translation unit brutus_kernels.hip (included
+// after fit_kernels.hpp); everything lives in that unit's anonymous namespace.
 //
 // Why.  The reference's per-star control flow hangs on maxima over the whole grid
 // (fitting.py:246-264 K1, :758-759 cull, :798-799 K2, :988-991 first cut), but
@@ -11,26 +11,32 @@
 //   k_pre32    every (star, model) in float32 (centred magnitudes, fluxes scaled to
 //              O(1)): approximate cull statistic lnl_p~ and first-cut statistic
 //              lnprob~ (4 + 4 B per pair), float32 maxima per 2048-model block, and the
-//              sweep statistics that decide K1 when they are clear of the tolerances.
-//              About 1/3 of the issue slots of the float64 scan it replaces.
+//              sweep statistics that decide K1 when they are clear of the tolerances
+//              (else k_k1probe, exact).
 //   k_top      float64 re-evaluation of the models within 2 eps of the float32 maximum
 //              (only the blocks whose float32 maximum is that high are touched)
 //              ->  EXACT max lnl_p, i.e. the exact cull threshold.
 //   k_cmp_count32 + k_offsets + k_items + k_cmp_scatter
 //              ordered list of the models with lnl_p~ >= threshold - eps, cut into work
 //              items by (star, model chunk) segment and numbered chunk-major.
-//   k_fflux    (fit_kernels.hpp, second-generation mode) exact cull test in float64, flux
-//              iterations for the survivors; results staged in candidate-list order
-//              (full-line writes, dense read-back), the survivor's list position left as
-//              a tag in the lnprob~ plane (surv_tag).
+//   k_fflux    (fit_kernels.hpp) exact cull test in float64, flux iterations for the
+//              survivors; their results are written ONCE, at the candidate's list position,
+//              straight into the caller's record planes (full-line writes) -- that is the
+//              survivors' final storage; the list position is also left as a tag in the
+//              lnprob~ plane (surv_tag).
 //   k_top (B)  exact maximum of lnprob over the non-survivors that could exceed the
 //              survivors' maximum  ->  EXACT first-cut threshold.
 //   k_sel_classify + k_sel_band
-//              selection bit-mask: float32 decides when |lnprob~ - thr| > eps, the
-//              models inside the band are queued and re-evaluated in float64 with dense
-//              lanes; survivors by their final value.
-//   k_offsets + k_cmp_scatter + k_emit   ordered records, each written once: survivors
-//              from the staged results, the rest derived (K1 sweeps + full MLE).
+//              two bit-masks: selected, and selected-but-not-a-survivor ("derived").
+//              float32 decides when |lnprob~ - thr| > eps, the models inside the band are
+//              queued and re-evaluated in float64 with dense lanes; survivors by their
+//              final value.
+//   k_offsets + k_items + k_rec_index
+//              ordered record index from the bit-masks alone: (model, slot of its values)
+//              per selected model in np.where order; derived models get the slots behind
+//              the candidates' and form the work list of ...
+//   k_derive   (fit_kernels.hpp) ... K1 sweeps + full MLE for the selected models the cull
+//              dropped, dense lanes, full-line writes.
 //
 // float32 never produces an output value or a decision: a lane whose float32 value
 // is NaN or inside the error band is re-evaluated in float64.  `eps` is a per-star
@@ -433,7 +439,7 @@ __global__ void k_pre_decide(int nblkx, int nstar, const int32_t *__restrict__ s
             K1 = 1;
             st = (rvf || K == 1) ? 0 : 1;
         } else if (cont1) {
-            if (rvf) {            // pinned Rv: sweep 2 never moves (see k_fscan)
+            if (rvf) {            // pinned Rv: sweep 2 never moves (see k_k1probe)
                 K1 = 2;
                 st = 0;
             } else if (K >= 2) {
@@ -482,7 +488,7 @@ __device__ __forceinline__ void mag_phase(const Tile64<NB, RVF> &t, const StarPr
     rv = p.rv_mean;
     if constexpr (RVF) {
         // pinned Rv: the first sweep lands on the (clamped) minimiser, later ones move by
-        // rounding noise only (see k_fscan); one step, like k_fscan / k_emit
+        // rounding noise only (see k_k1probe); one step, like k_derive
         GramR Gm;
         gram_init_rf<NB>(t.c, t.R, sp, Gm);
         double a_, c_;
@@ -671,7 +677,7 @@ __global__ void k_nomB(int nstar, const double *__restrict__ maxsurv, const Star
 }
 
 // Ordered compaction of a float32 plane: {i : !(plane[s][i] < thr[s])} (NaN counts as a
-// hit).  Same outputs as k_cmp_count.
+// hit): one membership word per wave and tile, one count per (star, model chunk).
 __global__ void __launch_bounds__(TILE)
 k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
               const double *__restrict__ thr, int64_t *__restrict__ counts,
@@ -719,16 +725,19 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
 // Models inside the band |lnprob~ - thr| <= eps (or NaN) go to the block's region of
 // `bandq` (starts at s * nmodel + first model of the chunk: cannot overflow) and are
 // re-evaluated in float64, with dense lanes, by k_sel_band, which ORs the outcome into
-// the membership words.  Outputs as k_cmp_count: membership words + per-chunk counts.
+// the membership words.  Outputs: membership words + per-chunk counts of the selected
+// models (mask, counts) and of those among them that are not survivors of the cull, whose
+// values k_derive has to compute (dmask, dcounts).
 __global__ void __launch_bounds__(TILE)
 k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
                const float *__restrict__ lnpr32,
                const double *__restrict__ lnprob_st, const int64_t *__restrict__ cand_off,
                const double *__restrict__ thr_sel,
                int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
+               int64_t *__restrict__ dcounts, unsigned long long *__restrict__ dmask,
                int32_t *__restrict__ bandq, int32_t *__restrict__ bandn) {
     __shared__ int qn;
-    __shared__ int wsum[4];
+    __shared__ int wsum[4], dsum[4];
     if (threadIdx.x == 0) qn = 0;
     __syncthreads();
     const int s = blockIdx.y, c = blockIdx.x;
@@ -737,7 +746,7 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
     const double e = (double)s32[s].eps;
     const int64_t cbase = cand_off[s];
     int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
-    int n = 0;
+    int n = 0, nd = 0;
     constexpr int U = 4;      // tiles in flight per lane
     for (int tb = t0; tb < t1; tb += U) {
         float v32[U];
@@ -758,29 +767,40 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
             const int t = tb + u;
             if (t >= t1) break;
             const int64_t i = (int64_t)t * TILE + threadIdx.x;
-            bool yes = false, bd = false;
+            bool yes = false, der = false, bd = false;
             if (i < nmodel) {
                 if (surv_is(v32[u])) {
                     yes = vst[u] > th;
                 } else {
                     const double v = (double)v32[u];
-                    yes = v >= th + e;
+                    yes = der = v >= th + e;
                     bd = !yes && !(v < th - e);
                 }
             }
             n += yes ? 1 : 0;
-            const unsigned long long b = __ballot(yes);
-            if ((threadIdx.x & 63) == 0)
-                mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
+            nd += der ? 1 : 0;
+            const unsigned long long b = __ballot(yes), bdr = __ballot(der);
+            if ((threadIdx.x & 63) == 0) {
+                const int64_t a = (int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6);
+                mask[a] = b;
+                dmask[a] = bdr;
+            }
             if (bd) queue[atomicAdd(&qn, 1)] = (int32_t)i;
         }
     }
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
+    for (int off = 32; off > 0; off >>= 1) {
+        n += __shfl_xor(n, off, 64);
+        nd += __shfl_xor(nd, off, 64);
+    }
+    if ((threadIdx.x & 63) == 0) {
+        wsum[threadIdx.x >> 6] = n;
+        dsum[threadIdx.x >> 6] = nd;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
         counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        dcounts[(int64_t)s * NCHUNK + c] = dsum[0] + dsum[1] + dsum[2] + dsum[3];
         bandn[s * NCHUNK + c] = qn;
     }
 }
@@ -797,6 +817,7 @@ k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, i
            const float *__restrict__ lnpr32, const double *__restrict__ thr_sel,
            const int32_t *__restrict__ bandq, const int32_t *__restrict__ bandn,
            int64_t *__restrict__ counts, unsigned long long *__restrict__ mask,
+           int64_t *__restrict__ dcounts, unsigned long long *__restrict__ dmask,
            float *__restrict__ aud) {
     const int s = blockIdx.y, c0 = blockIdx.x * SB_C;
     int pre[SB_C + 1];
@@ -832,9 +853,11 @@ k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, i
         const double lnprob =
             first_cut_lnprob(sp, final_lnl<false>(sp, p, m.chi2, false), m.scale, m.i00);
         audit(aud, s, lnpr32[(int64_t)s * nmodel + i], lnprob, th);
-        if (lnprob > th) {
+        if (lnprob > th) {       // (a band model is never a survivor: selected = derived)
             atomicOr(mask + (int64_t)s * (4 * ntile) + (i >> 6), 1ull << (i & 63));
+            atomicOr(dmask + (int64_t)s * (4 * ntile) + (i >> 6), 1ull << (i & 63));
             atomicAdd(reinterpret_cast<unsigned long long *>(counts + (int64_t)s * NCHUNK + c), 1ull);
+            atomicAdd(reinterpret_cast<unsigned long long *>(dcounts + (int64_t)s * NCHUNK + c), 1ull);
         }
     }
 }

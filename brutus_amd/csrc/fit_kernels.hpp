@@ -1,27 +1,22 @@
-// fit_kernels.hpp -- fused scan + compact flux phase + record emit behind brutus_fit_batch
+// fit_kernels.hpp -- float64 building blocks of brutus_fit_batch: Gram-form magnitude
+// sweeps, the MLE, the exact K1 probe, ordered compaction, the flux phase on the candidate
+// lists (k_fflux), the record index (k_rec_index) and the derived records (k_derive).
 // Part of the single translation unit brutus_kernels.hip (included there, in
-// this order: common, fastmath, grid_kernels, fit_kernels, cluster_kernels,
-// post_kernels); everything lives in that unit's anonymous namespace.
+// this order: common, fastmath, grid_kernels, fit_kernels, fit2_kernels, cluster_kernels,
+// mt_kernels, post_kernels, offsets_kernels); everything lives in that unit's anonymous
+// namespace.  The pipeline that strings these kernels together is described at the top of
+// fit2_kernels.hpp.
 #pragma once
 
 namespace {
 
-// ===========================================================================
-// FAST PATH (brutus_fit_batch): fused full-grid scan + compact flux phase
-// ===========================================================================
 // The magnitude phase is a weighted linear least-squares problem in
 // (offset, Av, Av*Rv) for every (star, model).  Instead of carrying the Nb
-// residuals through the sweeps as the reference does, the fast path forms the
+// residuals through the sweeps as the reference does, the hot path forms the
 // ten weighted inner products of {1, r0, dr, y = mag_obs - mag_model} once and
 // runs every sweep (fitting.py:176-243) on those scalars: the update formulas
 // are algebraically identical, the results agree to rounding (~1e-14), and a
 // sweep costs ~45 flops instead of ~14*Nb.
-//
-// One fused kernel then does, per (star, model): Gram sums -> 2 speculative
-// sweeps with convergence statistics -> MLE at the sweep-2 state -> cull
-// statistic lnl_p and the "not a survivor" first-cut statistic lnprob_ns.
-// K1 = 2 for >90 % of stars; stars with a different K1 are re-run (a few
-// percent of the batch).  Only two full planes are written (16 B per pair).
 
 struct Gram {   // weighted inner products of {1, a=r0, b=dr, y}; weights 1/mags_var
     double ua, ub, uy, aa, ab, bb, ay, by, yy;
@@ -260,37 +255,6 @@ __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)
     o.i22 = r_den;
 }
 
-// The three MLE quantities the fused scan needs (scale, chi2, i00 = sum F^2/V) in
-// ONE pass over the bands: with s = sum(d F / V) / sum(F^2 / V),
-//   chi2 = sum (d - s F)^2 / V = D2 - 2 s sum(d F / V) + s^2 sum(F^2 / V),
-// D2 = sum d^2 / V being a per-star constant (StarPrep::D2).  No per-band flux
-// array stays live (24 VGPRs at 12 bands) and the second band loop goes away.
-// The expansion cancels ~4 digits (D2 ~ 1e4-1e5 against chi2 ~ 10): chi2 is good
-// to ~1e-11 absolute -- it only feeds the cull / first-cut decisions here; every
-// reported value comes from the two-pass form (mle_fast*).
-template <int NB, bool RVF>
-__device__ __forceinline__ void mle_scan(const Coef<NB> &c, const double (&R)[RVF ? NB : 1],
-                                         const double (&F0)[NB], const StarPrep &sp, double av,
-                                         double rv, const double *__restrict__ tbl, Mle &o) {
-    const double mav = -0.4 * av;
-    double s_num = 0., s_den = 0.;
-#pragma unroll
-    for (int j = 0; j < NB; ++j) {
-        double Rj;
-        if constexpr (RVF) Rj = R[j];
-        else Rj = (double)c.r0[j] + rv * (double)c.dr[j];
-        const double f = F0[j] * fast_exp10(mav * Rj, tbl);
-        const double fw = f * sp.iV[j];
-        s_num += sp.d[j] * fw;
-        s_den += f * fw;
-    }
-    double s = s_num / s_den;
-    if (s <= 1e-20) s = 1e-20;
-    o.scale = s;
-    o.i00 = s_den;
-    o.chi2 = fma(-s, s_num, sp.D2) + s * fma(s, s_den, -s_num);
-}
-
 // F0 of model i from the band-major table (coalesced) / of one model from its row.
 template <int NB>
 __device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t nmodel_pad,
@@ -308,7 +272,7 @@ __device__ __forceinline__ void compute_F0_fast(const Coef<NB> &c, double (&F0)[
     for (int j = 0; j < NB; ++j) F0[j] = poly_exp10(-0.4 * (double)c.m[j]);
 }
 // ... or with the table-driven form where registers allow: bit-identical to the
-// tabulated F0 the scan reads
+// tabulated F0 the scans read
 template <int NB>
 __device__ __forceinline__ void compute_F0_tbl(const Coef<NB> &c, const double *__restrict__ tbl,
                                                double (&F0)[NB]) {
@@ -351,32 +315,25 @@ __device__ __forceinline__ double cull_stat(const StarPrep &sp, const Mle &m) {
     return lnlp;
 }
 
-// FS_G = stars per workgroup of the fused scan (LDS: FS_G * NV * 2 KiB)
-
-// Fused full-grid scan.  grid = (ceil(ntile / tiles_per_block), ceil(nrun / FS_G)).
-//   FS_G             stars per workgroup (LDS = FS_G * NV * 2 KiB)
-//   star_ids[nrun]   stars (indices into `stars`) handled by this launch
-//   kfix[star]       number of magnitude sweeps before the MLE
-// Per (block.x, star) emits NV = 2*KS + 2 maxima into part[(bx * nstar + star) * NV + v]:
-//   v = 2k, 2k+1 : L_k, T_k for sweep k < KS   (only sweeps <= kfix are run)
-//   v = 2KS      : max lnl_p;  v = 2KS+1 : max lnprob_ns
-//   RVF              pinned-Rv specialisation (see GramR)
-template <int NB, int KS, int FS_G, bool RVF>
-__global__ void __launch_bounds__(TILE, 3)   // <=168 VGPRs: 3 waves/SIMD (LDS allows 3 blocks/CU)
-k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
-        const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
-        const int32_t *__restrict__ kfix, int tiles_per_block, int ntile, Planes pl,
-        double *__restrict__ part) {
-    constexpr int NV = 2 * KS + 2;
-    extern __shared__ double smax[];   // [FS_G][NV][TILE]
+// Exact float64 probe of the number of magnitude sweeps K1 for the stars whose float32
+// statistics (k_pre32) could not decide it.  One star per blockIdx.y, up to KS sweeps of
+// fitting.py:176-243 on the Gram scalars; per (block.x, star) the maxima
+//   part[(bx * nstar + star) * 2 KS + 2k], [+ 2k + 1] = L_k = max logwt,
+//                                                       T_k = max{logwt : step >= mtol}
+// that k_k1_decide turns into K1 (fitting.py:246-264).  Nothing else is computed: the
+// statistics of the state after K1 sweeps come from a k_pre32 re-run.
+template <int NB, int KS, bool RVF>
+__global__ void __launch_bounds__(TILE)
+k_k1probe(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+          const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
+          int tiles_per_block, int ntile, double *__restrict__ part) {
+    constexpr int NV = 2 * KS;
     __shared__ double slot[4];
-    __shared__ double s_tbl[64];
-    stage_exp_table(s_tbl);
-    __syncthreads();
-    const int g0 = blockIdx.y * FS_G;
-    const int ng = min(FS_G, nrun - g0);
-    for (int q = threadIdx.x; q < FS_G * NV * TILE; q += TILE) smax[q] = -INFINITY;
-    // each thread only ever touches its own column of smax: no barrier needed
+    const int s = star_ids[blockIdx.y];
+    const StarPrep &sp = stars[s];
+    double mx[NV];
+#pragma unroll
+    for (int v = 0; v < NV; ++v) mx[v] = -INFINITY;
     const int t0 = blockIdx.x * tiles_per_block;
     const int t1 = min(ntile, t0 + tiles_per_block);
     for (int t = t0; t < t1; ++t) {
@@ -384,90 +341,54 @@ k_fscan(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const bool live = i < nmodel;
         Coef<NB> c;
         load_coef<NB>(grid, nmodel_pad, i, c);
-        double F0[NB];
-        load_F0<NB>(grid, nmodel_pad, i, F0);
-        double R[RVF ? NB : 1];
-        if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
-        for (int g = 0; g < ng; ++g) {
-            const int s = star_ids[g0 + g];
-            const StarPrep &sp = stars[s];
-            double av = p.av_mean, rv = p.rv_mean;
-            const int K = kfix[s];
-            double *col = smax + (size_t)g * NV * TILE + threadIdx.x;
-            Mle m;
-            if constexpr (RVF) {
-                GramR G;
-                gram_init_rf<NB>(c, R, sp, G);
-                // With Rv pinned the objective is exactly quadratic in (offset, Av)
-                // and a sweep is its Newton step with the offset eliminated: the
-                // first sweep lands on the (clamped) minimiser, every later one
-                // moves by rounding noise (<< mtol) and leaves logwt unchanged.
-                // So one sweep is computed; sweeps 2..K only enter the statistics
-                // (L_k = L_1, no step above tolerance), which makes K1 <= 2 as in
-                // the reference.
-                double dav, lw;
-                gram_sweep_rf(G, sp.S, p, av, dav, lw);
+        double av = p.av_mean, rv = p.rv_mean;
+        if constexpr (RVF) {
+            // With Rv pinned the objective is exactly quadratic in (offset, Av) and a
+            // sweep is its Newton step with the offset eliminated: the first sweep lands
+            // on the (clamped) minimiser, every later one moves by rounding noise
+            // (<< mtol) and leaves logwt unchanged.  So one sweep is computed; sweeps
+            // 2..KS only enter the statistics (L_k = L_1, no step above tolerance),
+            // which makes K1 <= 2 as in the reference.
+            double R[NB];
+            coef_R<NB>(c, p.rv_mean, R);
+            GramR G;
+            gram_init_rf<NB>(c, R, sp, G);
+            double dav, lw;
+            gram_sweep_rf(G, sp.S, p, av, dav, lw);
+            if (live && lw == lw) {
+                mx[0] = lw > mx[0] ? lw : mx[0];
+                if (fabs(dav) >= p.mtol) mx[1] = lw > mx[1] ? lw : mx[1];
+#pragma unroll
+                for (int k = 1; k < KS; ++k) mx[2 * k] = lw > mx[2 * k] ? lw : mx[2 * k];
+            }
+        } else {
+            Gram G;
+            gram_init<NB>(c, sp, G);
+#pragma unroll
+            for (int k = 0; k < KS; ++k) {
+                double dav, drv, lw;
+                gram_sweep(G, sp.S, p, av, rv, dav, drv, lw);
                 if (live && lw == lw) {
-                    if (lw > col[0]) col[0] = lw;
-                    if (fabs(dav) >= p.mtol && lw > col[TILE]) col[TILE] = lw;
-                    for (int k = 1; k < K && k < KS; ++k) {
-                        double *c0 = col + (size_t)(2 * k) * TILE;
-                        if (lw > c0[0]) c0[0] = lw;
-                    }
+                    const bool big = (fabs(dav) >= p.mtol) || (fabs(drv) >= p.mtol);
+                    mx[2 * k] = lw > mx[2 * k] ? lw : mx[2 * k];
+                    if (big) mx[2 * k + 1] = lw > mx[2 * k + 1] ? lw : mx[2 * k + 1];
                 }
-                mle_scan<NB, true>(c, R, F0, sp, av, rv, s_tbl, m);
-            } else {
-                Gram G;
-                gram_init<NB>(c, sp, G);
-                for (int k = 0; k < K; ++k) {
-                    double dav, drv, lw;
-                    gram_sweep(G, sp.S, p, av, rv, dav, drv, lw);
-                    if (k < KS && live && lw == lw) {
-                        const bool big = (fabs(dav) >= p.mtol) || (fabs(drv) >= p.mtol);
-                        double *c0 = col + (size_t)(2 * k) * TILE;
-                        if (lw > c0[0]) c0[0] = lw;
-                        if (big && lw > c0[TILE]) c0[TILE] = lw;
-                    }
-                }
-                mle_scan<NB, false>(c, R, F0, sp, av, rv, s_tbl, m);
-            }
-            const double lnl = -0.5 * m.chi2;
-            double lnlp = lnl;
-            if (sp.has_par) {
-                const double dp = sqrt(m.scale) - sp.par;
-                lnlp = lnl - 0.5 * (dp * dp * sp.par_ivar);
-            }
-            const double lnprob =
-                first_cut_lnprob(sp, final_lnl<RVF>(sp, p, m.chi2, false), m.scale, m.i00);
-            if (live) {
-                const int64_t o = (int64_t)s * pl.nmodel + i;
-                pl.lnlp[o] = lnlp;
-                pl.lnprob[o] = lnprob;
-                double *c0 = col + (size_t)(2 * KS) * TILE;
-                if (lnlp > c0[0]) c0[0] = lnlp;          // NaN never wins
-                if (lnprob > c0[TILE]) c0[TILE] = lnprob;
             }
         }
     }
-    for (int g = 0; g < ng; ++g) {
-        const int s = star_ids[g0 + g];
-        for (int v = 0; v < NV; ++v)
-            block_max_store(smax[((size_t)g * NV + v) * TILE + threadIdx.x], slot,
-                            part + ((int64_t)blockIdx.x * nstar + s) * NV + v);
-    }
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+        block_max_store(mx[v], slot, part + ((int64_t)blockIdx.x * nstar + s) * NV + v);
 }
 
-// Reduce the fused-scan partials of the stars in `star_ids` and decide.
-//   accept == 0: derive K1 from (L_k, T_k); k1[s] = K1 (0 = not converged in KS)
-//   always: thr_cull[s] = max lnl_p + ln(init_thresh);  maxns[s] = max lnprob_ns
-__global__ void k_fdecide(int nblkx, int nstar, int nrun, const int32_t *__restrict__ star_ids,
-                          int KS, const double *__restrict__ part, DevParams p, int accept,
-                          int32_t *__restrict__ k1, double *__restrict__ thr_cull,
-                          double *__restrict__ maxns) {
-    __shared__ double sm[KCAP * 2 + 2][4];
+// K1 of the probed stars from the partials of k_k1probe (0 = not converged in KS sweeps).
+__global__ void k_k1_decide(int nblkx, int nstar, const int32_t *__restrict__ star_ids, int KS,
+                            const double *__restrict__ part, double ln_init,
+                            int32_t *__restrict__ k1) {
+    __shared__ double sm[KCAP * 2][4];
     const int s = star_ids[blockIdx.x];
-    const int NV = 2 * KS + 2;
-    double v[KCAP * 2 + 2];
+    const int NV = 2 * KS;
+    double v[KCAP * 2];
     for (int q = 0; q < NV; ++q) v[q] = -INFINITY;
     for (int b = threadIdx.x; b < nblkx; b += blockDim.x) {
         const double *pp = part + ((int64_t)b * nstar + s) * NV;
@@ -479,82 +400,39 @@ __global__ void k_fdecide(int nblkx, int nstar, int nrun, const int32_t *__restr
     }
     __syncthreads();
     if (threadIdx.x != 0) return;
-    for (int q = 0; q < NV; ++q) {
-        double m = sm[q][0];
-        for (int w = 1; w < 4; ++w) m = sm[q][w] > m ? sm[q][w] : m;
-        v[q] = m;
-    }
-    if (!accept) {
-        int K1 = 0;
-        for (int k = 0; k < KS; ++k) {
-            const double L = v[2 * k] > -BIG ? v[2 * k] : -BIG;
-            if (!(v[2 * k + 1] > L + p.ln_init)) {
-                K1 = k + 1;
-                break;
-            }
+    int K1 = 0;
+    for (int k = 0; k < KS; ++k) {
+        double L = sm[2 * k][0], T = sm[2 * k + 1][0];
+        for (int w = 1; w < 4; ++w) {
+            L = sm[2 * k][w] > L ? sm[2 * k][w] : L;
+            T = sm[2 * k + 1][w] > T ? sm[2 * k + 1][w] : T;
         }
-        k1[s] = K1;
+        L = L > -BIG ? L : -BIG;
+        if (!(T > L + ln_init)) {
+            K1 = k + 1;
+            break;
+        }
     }
-    thr_cull[s] = v[2 * KS] + p.ln_init;
-    maxns[s] = v[2 * KS + 1];
+    k1[s] = K1;
 }
 
-// Ordered compaction of one (nstar, nmodel) plane against a per-star threshold:
-// {i : plane[s][i] > thr[s]}.  grid = (NCHUNK, nstar).  Optionally also the
-// maximum of `other[s][i]` over the complement (models that fail the test).
-__global__ void __launch_bounds__(TILE)
-k_cmp_count(int64_t nmodel, int ntile, const double *__restrict__ plane,
-            const double *__restrict__ thr, const double *__restrict__ other,
-            int64_t *__restrict__ counts, double *__restrict__ other_max,
-            unsigned long long *__restrict__ mask) {
-    __shared__ int wsum[4];
-    __shared__ double slot[4];
-    const int s = blockIdx.y, c = blockIdx.x;
-    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
-    const double th = thr[s];
-    int n = 0;
-    double om = -INFINITY;
-    for (int t = t0; t < t1; ++t) {
-        const int64_t i = (int64_t)t * TILE + threadIdx.x;
-        bool hit = false;
-        if (i < nmodel) {
-            const int64_t o = (int64_t)s * nmodel + i;
-            if (plane[o] > th) {
-                hit = true;
-                ++n;
-            } else if (other) {
-                const double x = other[o];
-                if (x > om) om = x;
-            }
-        }
-        // one 64-bit membership word per wave: the scatter pass reads these
-        // instead of the 8-byte-per-model plane
-        const unsigned long long b = __ballot(hit);
-        if ((threadIdx.x & 63) == 0)
-            mask[(int64_t)s * (4 * ntile) + (int64_t)t * 4 + (threadIdx.x >> 6)] = b;
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) n += __shfl_xor(n, off, 64);
-    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = n;
-    __syncthreads();
-    if (threadIdx.x == 0) counts[(int64_t)s * NCHUNK + c] = wsum[0] + wsum[1] + wsum[2] + wsum[3];
-    if (other) block_max_store(om, slot, other_max + (int64_t)s * NCHUNK + c);
-}
-
-// Exclusive scan of counts[(s, c)] in (s, c) order:
-//   offsets[(s, c)], star_off[s] (star_off[nstar] = total).
-// Work items of the list kernels (k_fflux, k_emit): the segment of star s in model chunk c,
-// cut into pieces of TILE entries, numbered CHUNK-MAJOR: wbase[c * nstar + s] = first item
-// of that segment, wbase[NCHUNK * nstar] = #items.  Workgroups that run at the same time
-// then work on the same 1/NCHUNK of the grid for different stars, and the coefficient rows
-// they gather are L2 hits instead of one fabric read per star.
-// One workgroup of BRUTUS_MAX_BATCH threads, two exclusive scans over the nstar x NCHUNK
-// counts -- star-major for the list offsets, chunk-major for the work items -- each lane
-// taking a run of consecutive entries whose loads are all in flight at once (the serial
-// per-star / per-chunk loops this replaces paid one memory round trip per entry).
+// Exclusive scans of per-(star, chunk) counts, one workgroup per job (blockIdx.x):
+//   offsets[(s, c)] in (s, c) order, star_off[s] (star_off[nstar] = total) and, where wbase
+//   is given, the work items of a list kernel (k_fflux, k_derive): the segment of star s in
+//   model chunk c, cut into pieces of TILE entries, numbered CHUNK-MAJOR:
+//   wbase[c * nstar + s] = first item of that segment, wbase[NCHUNK * nstar] = #items.
+// Workgroups that run at the same time then work on the same 1/NCHUNK of the grid for
+// different stars, and the coefficient rows they gather are L2 hits instead of one fabric
+// read per star.  BRUTUS_MAX_BATCH threads, two exclusive scans over the nstar x NCHUNK counts
+// -- star-major for the list offsets, chunk-major for the work items -- each lane taking a
+// run of consecutive entries whose loads are all in flight at once.
+struct OffsetsJob {
+    const int64_t *counts;
+    int64_t *offsets, *star_off;
+    int32_t *wbase;
+};
 __global__ void __launch_bounds__(BRUTUS_MAX_BATCH)
-k_offsets(int nstar, const int64_t *__restrict__ counts, int64_t *__restrict__ offsets,
-          int64_t *__restrict__ star_off, int32_t *__restrict__ wbase) {
+k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
     constexpr int NT = BRUTUS_MAX_BATCH;
     constexpr int EPT = NCHUNK;                       // entries per lane at the full batch
     typedef hipcub::BlockScan<int64_t, NT> Scan64;
@@ -563,6 +441,8 @@ k_offsets(int nstar, const int64_t *__restrict__ counts, int64_t *__restrict__ o
         typename Scan64::TempStorage a;
         typename Scan32::TempStorage b;
     } tmp;
+    const OffsetsJob job = blockIdx.x == 0 ? job0 : job1;
+    const int64_t *__restrict__ counts = job.counts;
     const int total = nstar * NCHUNK;
     const int ept = (total + NT - 1) / NT;
     const int e0 = threadIdx.x * ept;
@@ -579,14 +459,14 @@ k_offsets(int nstar, const int64_t *__restrict__ counts, int64_t *__restrict__ o
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             if (k < ept && e0 + k < total) {
-                offsets[e0 + k] = pre;
-                if ((e0 + k) % NCHUNK == 0) star_off[(e0 + k) / NCHUNK] = pre;
+                job.offsets[e0 + k] = pre;
+                if ((e0 + k) % NCHUNK == 0) job.star_off[(e0 + k) / NCHUNK] = pre;
             }
             pre += r[k];
         }
-        if (threadIdx.x == 0) star_off[nstar] = all;
+        if (threadIdx.x == 0) job.star_off[nstar] = all;
     }
-    if (!wbase) return;
+    if (!job.wbase) return;
     __syncthreads();
     {
         int32_t r[EPT];
@@ -602,13 +482,14 @@ k_offsets(int nstar, const int64_t *__restrict__ counts, int64_t *__restrict__ o
         Scan32(tmp.b).ExclusiveSum(sum, pre, all);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
-            if (k < ept && e0 + k < total) wbase[e0 + k] = pre;
+            if (k < ept && e0 + k < total) job.wbase[e0 + k] = pre;
             pre += r[k];
         }
-        if (threadIdx.x == 0) wbase[total] = all;
+        if (threadIdx.x == 0) job.wbase[total] = all;
     }
 }
 
+// Ordered list {i : bit i of the star's membership words is set} (= np.where order).
 // A chunk's membership words are fetched 64 tiles (256 words, one per lane) at a time and
 // prefix-summed once; the per-tile loop then runs out of LDS.  (One dependent global load
 // per tile made this kernel latency-bound: 46 round trips per workgroup.)
@@ -648,14 +529,12 @@ k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ 
     }
 }
 
-// Second generation (fit2_kernels.hpp): the float32 lnprob~ plane doubles as the survivor
-// map.  Its genuine entries are negative, -inf or NaN (the value of a survivor is not
-// needed again: survivors are judged by their final float64 lnprob); k_fflux overwrites a
-// survivor's entry with the bit pattern 1 + (position in the star's candidate list), a
-// positive finite word, and leaves a candidate that failed the exact cull test alone.
-// Every later pass (exact first-cut threshold, classification, emit) then reads ONE plane.  The flux-phase results live in
-// candidate-list order ("staging": the Planes arrays indexed by list position), so they
-// are written as full lines and read back densely.
+// The float32 lnprob~ plane doubles as the survivor map.  Its genuine entries are negative,
+// -inf or NaN (the value of a survivor is not needed again: survivors are judged by their
+// final float64 lnprob); k_fflux overwrites a survivor's entry with the bit pattern
+// 1 + (position in the star's candidate list), a positive finite word, and leaves a
+// candidate that failed the exact cull test alone.  Every later pass (exact first-cut
+// threshold, classification) then reads ONE plane.
 __device__ __forceinline__ float surv_tag(int64_t slot) { return __int_as_float((int)slot + 1); }
 __device__ __forceinline__ bool surv_is(float x) {
     const int b = __float_as_int(x);
@@ -746,25 +625,37 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
     }
 }
 
-// Flux phase on the compact survivor lists (fitting.py:758-803), persistent
-// workgroups looping over work items.  First launch: rebuild (av, rv) from K1
-// sweeps, two iterations from lnl_old = -1e300; continuation: one iteration from
-// the state planes.  Writes the state/result planes at the survivors' positions
-// and, per work item and wave, L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
-// M = max final lnprob.
-// Second-generation mode (surv32 != nullptr, fit2_kernels.hpp): the list holds the
-// CANDIDATES (lnl_p~ >= threshold - eps); the first launch applies the exact cull test
-// lnl_p > thr_cull[s] (fitting.py:758-759) and marks the outcome in the float32 plane
-// (survivor tag / -inf, see surv_tag); only survivors iterate, store and enter the
-// statistics, and they store at their LIST POSITION q, not at (star, model).
+// The caller's record value planes (BRUTUS_NVALS x cap float64; include/brutus_amd.h):
+//   0 lnlike, 1 chi2, 2 scale, 3 av, 4 rv, 5..10 icov[00, 01, 02, 11, 12, 22].
+// Slots [0, ncand) belong to the candidates of the cull in candidate-list order -- the flux
+// phase writes its results there and they ARE the survivors' records (nothing copies them
+// again) --, slots [ncand, ncand + nder) to the selected models the cull dropped (k_derive).
+struct RecPlanes {
+    double *vals;
+    int64_t cap;
+    __device__ __forceinline__ double *plane(int v) const { return vals + (int64_t)v * cap; }
+};
+
+// Flux phase on the ordered candidate lists (fitting.py:758-803), persistent workgroups
+// looping over work items.  The list holds the CANDIDATES (lnl_p~ >= threshold - eps).
+// First launch: rebuild (av, rv) from K1 sweeps, exact cull test lnl_p > thr_cull[s]
+// (fitting.py:758-759) whose outcome is marked in the float32 plane (survivor tag / left
+// alone, see surv_tag), two iterations from lnl_old = -1e300 for the survivors;
+// continuation: one iteration from the stored state.  A survivor's results go to the
+// record planes at its LIST POSITION q (full-line writes), its step size and final
+// first-cut statistic lnprob to the workspace arrays step_st / lnprob_st at the same
+// position.  Per work item and wave: L = max lnl_new, T = max{lnl_new : |dlnl| > ltol},
+// M = max final lnprob.  Entries at or beyond the record capacity are skipped (the host
+// sees ncand > capacity and reports BRUTUS_ENOMEM).
 template <int NB, bool RVF, bool FIRST>
 __global__ void __launch_bounds__(TILE, 2)
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
-        const int32_t *__restrict__ k2state, const int32_t *__restrict__ surv_idx,
-        const int64_t *__restrict__ surv_off, const int32_t *__restrict__ wbase,
-        const ItemGeom *__restrict__ items, Planes pl, double *__restrict__ part,
-        float *__restrict__ surv32, const double *__restrict__ thr_cull) {
+        const int32_t *__restrict__ k2state, const int32_t *__restrict__ cand_idx,
+        const int64_t *__restrict__ cand_off, const int32_t *__restrict__ wbase,
+        const ItemGeom *__restrict__ items, RecPlanes rec, double *__restrict__ step_st,
+        double *__restrict__ lnprob_st, double *__restrict__ part, float *__restrict__ surv32,
+        const double *__restrict__ thr_cull) {
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
@@ -778,8 +669,11 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const ItemGeom ig = items[item];
         const int64_t q = ig.q0 + threadIdx.x;
         const int64_t last = ig.q0 + ig.n - 1;
-        return surv_idx[q < last ? q : last];
+        return cand_idx[q < last ? q : last];
     };
+    double *__restrict__ r_lnl = rec.plane(0), *__restrict__ r_chi2 = rec.plane(1),
+                        *__restrict__ r_scale = rec.plane(2), *__restrict__ r_av = rec.plane(3),
+                        *__restrict__ r_rv = rec.plane(4);
     ItemWalk wk;
     wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
     int32_t i_nxt = lane_model(wk.item);
@@ -792,17 +686,13 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         i_nxt = lane_model(wk.item);
         if (k2state[s] < 0) continue;
         const StarPrep &sp = stars[s];
-        const int64_t q = ig.q0 + threadIdx.x;
-        const bool live = (int)threadIdx.x < ig.n;
+        const int64_t q = ig.q0 + threadIdx.x;       // list position = record slot
+        const bool live = (int)threadIdx.x < ig.n && q < rec.cap;
         double L = -INFINITY, T = -INFINITY, M = -INFINITY;
         bool go = live;
-        int64_t i = 0, o = 0;
-        if (live) {
-            i = i_me;
-            o = (int64_t)s * pl.nmodel + i;
-            if (surv32 && !FIRST) go = surv_is(surv32[o]);
-        }
-        const int64_t os = surv32 ? q : o;       // where this entry's state / results live
+        const int64_t i = i_me;
+        const int64_t o = (int64_t)s * nmodel + i;
+        if (!FIRST && live) go = surv_is(surv32[o]);
         if (go) {
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
@@ -819,7 +709,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 if constexpr (RVF) {
                     GramR G;
                     gram_init_rf<NB>(c, R, sp, G);
-                    // (a single sweep would do, see k_fscan; the loop form keeps this
+                    // (a single sweep would do, see k_k1probe; the loop form keeps this
                     // kernel's register allocation below the spill line)
                     for (int k = 0; k < K; ++k) {
                         double a_, c_;
@@ -836,17 +726,17 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 step = 1.0;
                 lnl_old = -BIG;
             } else {
-                av = pl.av[os];
-                rv = RVF ? p.rv_mean : pl.rv[os];     // pinned Rv is not staged
-                step = pl.step[os];
-                lnl_old = -0.5 * pl.chi2[os];
+                av = r_av[q];
+                rv = RVF ? p.rv_mean : r_rv[q];       // pinned Rv is not stored
+                step = step_st[q];
+                lnl_old = -0.5 * r_chi2[q];
             }
             Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
-            if (surv32 && FIRST) {
+            if constexpr (FIRST) {
                 go = cull_stat(sp, m) > thr_cull[s];
-                if (go) surv32[o] = surv_tag(q - surv_off[s]);     // a failed candidate keeps its lnprob~
+                if (go) surv32[o] = surv_tag(q - cand_off[s]);     // a failed candidate keeps its lnprob~
             }
             double lnl_new = lnl_old, dl = 0.;
             for (int it = 0; go && it < niter; ++it) {
@@ -871,14 +761,21 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = lnl_new;
             }
             if (go) {
-                store_mle(pl, os, m);
-                pl.av[os] = av;
-                if constexpr (!RVF) pl.rv[os] = rv;
-                pl.step[os] = step;
                 const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
                 const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
-                pl.lnl[os] = lnl;
-                pl.lnprob[os] = lnprob;
+                r_lnl[q] = lnl;
+                r_chi2[q] = m.chi2;
+                r_scale[q] = m.scale;
+                r_av[q] = av;
+                if constexpr (!RVF) r_rv[q] = rv;
+                rec.plane(5)[q] = m.i00;
+                rec.plane(6)[q] = m.i01;
+                rec.plane(7)[q] = m.i02;
+                rec.plane(8)[q] = m.i11;
+                rec.plane(9)[q] = m.i12;
+                rec.plane(10)[q] = m.i22;
+                step_st[q] = step;
+                lnprob_st[q] = lnprob;
                 M = lnprob;
                 if (lnl_new == lnl_new) {
                     L = lnl_new;
@@ -953,199 +850,155 @@ __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
     }
 }
 
-__global__ void k_sel_thresh(int nstar, const double *__restrict__ maxns_part,
-                             const double *__restrict__ maxsurv, double ln_wt,
-                             double *__restrict__ thr_sel) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= nstar) return;
-    // maximum of the final lnprob plane: survivors (flux phase) and the rest
-    double m = maxsurv[s];
-    for (int c = 0; c < NCHUNK; ++c) {
-        const double x = maxns_part[(int64_t)s * NCHUNK + c];
-        m = x > m ? x : m;
+// The record index: for every selected model, in ascending model order per star
+// (= np.where order, fitting.py:988-991), its model number and the slot of its values.
+// Three membership bit-masks decide everything -- `mask` (selected), `dmask` (selected and
+// NOT a survivor of the cull: values to be derived) and `cmask` (candidates of the cull) --
+// so no value plane and no tag is read:
+//   survivor  -> slot = its position in the candidate lists (where k_fflux left the values)
+//              = coffsets[(s, c)] + rank among the chunk's candidates
+//   derived   -> slot = ncand + position in the derived lists, and the model is appended to
+//                der_idx (the work list of k_derive)
+// A chunk's words are fetched 64 tiles at a time and the three popcounts prefix-summed at
+// once (packed 20 bits each: a window holds 16 384 models).
+__global__ void __launch_bounds__(TILE)
+k_rec_index(int64_t nmodel, int ntile, int nstar, const unsigned long long *__restrict__ mask,
+            const unsigned long long *__restrict__ dmask,
+            const unsigned long long *__restrict__ cmask, const int64_t *__restrict__ offsets,
+            const int64_t *__restrict__ doffsets, const int64_t *__restrict__ coffsets,
+            const int64_t *__restrict__ cand_off, int64_t capacity,
+            int32_t *__restrict__ rec_idx, int32_t *__restrict__ rec_slot,
+            int32_t *__restrict__ der_idx) {
+    typedef hipcub::BlockScan<unsigned long long, TILE> Scan;
+    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ unsigned long long s_word[3][TILE];
+    __shared__ unsigned long long s_pre[TILE];
+    const int s = blockIdx.y, c = blockIdx.x;
+    const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
+    int64_t base = offsets[(int64_t)s * NCHUNK + c];
+    int64_t dbase = doffsets[(int64_t)s * NCHUNK + c] + cand_off[nstar];
+    int64_t cbase = coffsets[(int64_t)s * NCHUNK + c];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const int64_t row = (int64_t)s * (4 * ntile);
+    constexpr unsigned long long F20 = (1ull << 20) - 1ull;
+    for (int tb = t0; tb < t1; tb += TILE / 4) {
+        const int nt = min(TILE / 4, t1 - tb);
+        const bool in = (int)threadIdx.x < 4 * nt;
+        const int64_t a = row + (int64_t)tb * 4 + (in ? threadIdx.x : 0);
+        unsigned long long wm = mask[a], wd = dmask[a], wc = cmask[a];
+        if (!in) wm = wd = wc = 0ull;
+        unsigned long long pre, tot;
+        Scan(s_scan).ExclusiveSum((unsigned long long)__popcll(wm) |
+                                      ((unsigned long long)__popcll(wd) << 20) |
+                                      ((unsigned long long)__popcll(wc) << 40),
+                                  pre, tot);
+        s_word[0][threadIdx.x] = wm;
+        s_word[1][threadIdx.x] = wd;
+        s_word[2][threadIdx.x] = wc;
+        s_pre[threadIdx.x] = pre;
+        __syncthreads();
+#pragma unroll 4
+        for (int k = 0; k < nt; ++k) {
+            const unsigned long long b = s_word[0][4 * k + w];
+            if ((b >> lane) & 1ull) {
+                const unsigned long long bd = s_word[1][4 * k + w], bc = s_word[2][4 * k + w];
+                const unsigned long long pk = s_pre[4 * k + w];
+                const int32_t i = (int32_t)((int64_t)(tb + k) * TILE + threadIdx.x);
+                const int64_t r = base + (int64_t)(pk & F20) + __popcll(b & below);
+                int64_t slot;
+                if ((bd >> lane) & 1ull) {
+                    slot = dbase + (int64_t)((pk >> 20) & F20) + __popcll(bd & below);
+                    der_idx[slot - cand_off[nstar]] = i;
+                } else {
+                    slot = cbase + (int64_t)(pk >> 40) + __popcll(bc & below);
+                }
+                if (r < capacity) {
+                    rec_idx[r] = i;
+                    rec_slot[r] = (int32_t)slot;
+                }
+            }
+        }
+        base += (int64_t)(tot & F20);
+        dbase += (int64_t)((tot >> 20) & F20);
+        cbase += (int64_t)(tot >> 40);
+        __syncthreads();
     }
-    thr_sel[s] = m + ln_wt;
 }
 
-// Emit the records of the selected models (ordered lists from k_cmp_scatter).
-// Survivors of the cull are read from the flux-phase results; the others are
-// re-derived from the grid (K1 sweeps + MLE), which is cheaper than having the
-// full-grid scan write eleven planes.
-// A work item is TILE consecutive entries of one star's list and belongs to ONE WAVE.
-// The two kinds are interleaved in runs of 10-20 models, so the wave first sorts its
-// entries by kind (ballot ranks, two position lists in its private LDS) and then runs
-// dense rounds of 64 lanes of one kind each.  No workgroup barrier anywhere: the waves
-// of a CU sit in different phases (index / tag loads, row gathers, float64 MLE, record
-// stores) and cover each other's latency.  A record row is written by 64 lanes with
-// gaps that another round of the same wave fills microseconds later (merged in L2).
+// Values of the selected models the cull dropped: K1 magnitude sweeps + the full MLE from
+// the model's row (fitting.py:176-243, 502-576; lnl as fitting.py:806-815 leaves it for a
+// non-survivor), which is cheaper than having the full-grid pass write eleven planes.
+// Lane = one entry of the derived lists (dense lanes, no divergence), written at slot
+// ncand + list position: every record plane receives full lines.  Persistent workgroups
+// over chunk-major work items like k_fflux; no barrier in the loop.
 template <int NB, bool RVF>
 __global__ void __launch_bounds__(TILE, 2)
-k_emit(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
-       const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
-       const double *__restrict__ thr_cull, const int32_t *__restrict__ sel_idx,
-       const int64_t *__restrict__ sel_off, const int32_t *__restrict__ wbase,
-       const ItemGeom *__restrict__ items, Planes pl, int64_t capacity,
-       double *__restrict__ sel_vals, const float *__restrict__ surv32,
-       const int64_t *__restrict__ cand_off) {
-    constexpr int NW = TILE / 64;
+k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
+         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
+         const int32_t *__restrict__ der_idx, const int32_t *__restrict__ wbase,
+         const ItemGeom *__restrict__ items, const int64_t *__restrict__ cand_off,
+         RecPlanes rec) {
     __shared__ double s_tbl[64];
-    __shared__ int32_t s_idx[NW][TILE];
-    __shared__ int32_t s_slot[NW][TILE];
-    __shared__ int16_t s_ps[NW][TILE];      // list positions of the survivors, then ...
-    __shared__ int16_t s_pd[NW][TILE];      // ... of the re-derived entries
     stage_exp_table(s_tbl);
     __syncthreads();
-    const int nitem = wbase[NCHUNK * nstar];
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const uint64_t below = (1ull << lane) - 1ull;
-    // geometry of a work item: star, first list position, live entries (0 past the end)
-    auto geom = [&](int item, int &s, int64_t &q0, int &n) {
-        s = 0;
-        q0 = 0;
-        n = 0;
-        if (item < 0) return;
+    auto lane_model = [&](int item) -> int32_t {
+        if (item < 0) return 0;
         const ItemGeom ig = items[item];
-        s = ig.s;
-        q0 = ig.q0;
-        const int64_t room = capacity - q0;          // a record buffer too small: drop the rest
-        n = (int)(room < ig.n ? room : ig.n);
-        n = n > 0 ? n : 0;
+        const int64_t q = ig.q0 + threadIdx.x;
+        const int64_t last = ig.q0 + ig.n - 1;
+        return der_idx[q < last ? q : last];
     };
-    // the entries' models / their kind words (survivor tag, see surv_tag; path 1: 1 or -0.)
-    auto load_idx = [&](int64_t q0, int n, int32_t (&iv)[NW]) {
-#pragma unroll
-        for (int r = 0; r < NW; ++r) iv[r] = r * 64 + lane < n ? sel_idx[q0 + r * 64 + lane] : 0;
-    };
-    auto load_kind = [&](int s, int n, const int32_t (&iv)[NW], float (&kd)[NW]) {
-        const int64_t sb = (int64_t)s * pl.nmodel;
-#pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            kd[r] = -0.f;
-            if (r * 64 + lane < n) {
-                if (surv32) kd[r] = surv32[sb + iv[r]];
-                else kd[r] = pl.lnlp[sb + iv[r]] > thr_cull[s] ? surv_tag(0) : -0.f;
-            }
-        }
-    };
+    const int64_t slot0 = cand_off[nstar];
     ItemWalk wk;
-    wk.init(wbase, nstar, blockIdx.x & 7, (blockIdx.x >> 3) * NW + w,
-            ((gridDim.x + 7 - (blockIdx.x & 7)) >> 3) * NW);
-    int item = wk.item;
-    int s, n, s_n, n_n;
-    int64_t q0, q0_n;
-    int32_t iv[NW], iv_n[NW];
-    float kd[NW], kd_n[NW];
-    geom(item, s, q0, n);
-    load_idx(q0, n, iv);
-    load_kind(s, n, iv, kd);
-    for (; item >= 0; item = wk.item) {
-        // the next item's models are requested now, its kind words once those have
-        // arrived (after the copy rounds): both latencies run under this item's work
+    wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
+    int32_t i_nxt = lane_model(wk.item);
+    while (!wk.done()) {
+        const int item = wk.item;
         wk.next();
-        geom(wk.item, s_n, q0_n, n_n);
-        load_idx(q0_n, n_n, iv_n);
+        const ItemGeom ig = items[item];
+        const int s = ig.s;
+        const int64_t i = i_nxt;
+        i_nxt = lane_model(wk.item);
+        const int64_t slot = slot0 + ig.q0 + threadIdx.x;
+        if ((int)threadIdx.x >= ig.n || slot >= rec.cap) continue;
         const StarPrep &sp = stars[s];
-        const int64_t sbase = (int64_t)s * pl.nmodel;
-        bool sv[NW];
-#pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            const int t = r * 64 + lane;
-            sv[r] = false;
-            if (t < n) {
-                sv[r] = surv_is(kd[r]);
-                s_slot[w][t] = surv_slot(kd[r]);
-                s_idx[w][t] = iv[r];
+        Coef<NB> c;
+        gather_coef<NB>(grid, nmodel_pad, i, c);
+        double F0[NB];
+        compute_F0_tbl<NB>(c, s_tbl, F0);
+        double av = p.av_mean, rv = p.rv_mean;
+        const int K = k1[s];
+        Mle m;
+        if constexpr (RVF) {
+            double R[NB];
+            coef_R<NB>(c, rv, R);
+            GramR G;
+            gram_init_rf<NB>(c, R, sp, G);
+            double a_, c_;
+            if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_k1probe)
+            mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+        } else {
+            Gram G;
+            gram_init<NB>(c, sp, G);
+            for (int kk = 0; kk < K; ++kk) {
+                double a_, b_, c_;
+                gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
             }
+            mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
         }
-        int nS = 0, nD = 0;
-#pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            const int t = r * 64 + lane;
-            const uint64_t bs = __ballot(sv[r]), bd = __ballot(t < n && !sv[r]);
-            if (sv[r]) s_ps[w][nS + __popcll(bs & below)] = (int16_t)t;
-            else if (t < n) s_pd[w][nD + __popcll(bd & below)] = (int16_t)t;
-            nS += __popcll(bs);
-            nD += __popcll(bd);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        // Survivors and re-derived entries take turns, 64 of each (both lists are in position
-        // order): the two kinds of stores into a stretch of the record planes then follow
-        // each other closely and the half-written lines are still in L2 when their other
-        // half arrives.
-        const int nmax = nS > nD ? nS : nD;
-        for (int k0 = 0; k0 < nmax; k0 += 64) {
-        // ---- survivors: copy ---------------------------------------------------------
-        if (const int k = k0 + lane; k < nS) {
-            const int mp = s_ps[w][k];
-            const int64_t o = surv32 ? cand_off[s] + s_slot[w][mp] : sbase + s_idx[w][mp];
-            double rec[BRUTUS_NVALS];
-            rec[0] = pl.lnl[o];
-            rec[1] = pl.chi2[o];
-            rec[2] = pl.scale[o];
-            rec[3] = pl.av[o];
-            rec[4] = RVF ? p.rv_mean : pl.rv[o];
-#pragma unroll
-            for (int v = 0; v < 6; ++v) rec[5 + v] = pl.icov[v][o];
-#pragma unroll
-            for (int v = 0; v < BRUTUS_NVALS; ++v) sel_vals[(int64_t)v * capacity + q0 + mp] = rec[v];
-        }
-        if (k0 == 0) load_kind(s_n, n_n, iv_n, kd_n);
-        // ---- the rest: K1 sweeps + full MLE from the model's row -----------------------
-        if (const int k = k0 + lane; k < nD) {
-            const int mp = s_pd[w][k];
-            const int64_t i = s_idx[w][mp];
-            Coef<NB> c;
-            gather_coef<NB>(grid, nmodel_pad, i, c);
-            double F0[NB];
-            compute_F0_tbl<NB>(c, s_tbl, F0);
-            double av = p.av_mean, rv = p.rv_mean;
-            const int K = k1[s];
-            Mle m;
-            if constexpr (RVF) {
-                double R[NB];
-                coef_R<NB>(c, rv, R);
-                GramR G;
-                gram_init_rf<NB>(c, R, sp, G);
-                double a_, c_;
-                if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_fscan)
-                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
-            } else {
-                Gram G;
-                gram_init<NB>(c, sp, G);
-                for (int kk = 0; kk < K; ++kk) {
-                    double a_, b_, c_;
-                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
-                }
-                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
-            }
-            double *out = sel_vals + q0 + mp;
-            out[0] = final_lnl<RVF>(sp, p, m.chi2, false);
-            out[(int64_t)1 * capacity] = m.chi2;
-            out[(int64_t)2 * capacity] = m.scale;
-            out[(int64_t)3 * capacity] = av;
-            out[(int64_t)4 * capacity] = rv;
-            out[(int64_t)5 * capacity] = m.i00;
-            out[(int64_t)6 * capacity] = m.i01;
-            out[(int64_t)7 * capacity] = m.i02;
-            out[(int64_t)8 * capacity] = m.i11;
-            out[(int64_t)9 * capacity] = m.i12;
-            out[(int64_t)10 * capacity] = m.i22;
-        }
-        }
-        if (nmax == 0) load_kind(s_n, n_n, iv_n, kd_n);
-        // the next item's LDS writes must not pass this item's reads
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        s = s_n;
-        n = n_n;
-        q0 = q0_n;
-#pragma unroll
-        for (int r = 0; r < NW; ++r) {
-            iv[r] = iv_n[r];
-            kd[r] = kd_n[r];
-        }
+        double *out = rec.vals + slot;
+        out[0] = final_lnl<RVF>(sp, p, m.chi2, false);
+        out[(int64_t)1 * rec.cap] = m.chi2;
+        out[(int64_t)2 * rec.cap] = m.scale;
+        out[(int64_t)3 * rec.cap] = av;
+        if constexpr (!RVF) out[(int64_t)4 * rec.cap] = rv;      // pinned Rv is not stored
+        out[(int64_t)5 * rec.cap] = m.i00;
+        out[(int64_t)6 * rec.cap] = m.i01;
+        out[(int64_t)7 * rec.cap] = m.i02;
+        out[(int64_t)8 * rec.cap] = m.i11;
+        out[(int64_t)9 * rec.cap] = m.i12;
+        out[(int64_t)10 * rec.cap] = m.i22;
     }
 }
 

@@ -262,7 +262,7 @@ __device__ __forceinline__ void rec_range_n(int64_t lo, int64_t n, int c, int64_
 
 // P1: lnp of the MLE point for the second cut (fitting.py:1000-1010)
 __global__ void __launch_bounds__(TILE)
-k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
+k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx, const int32_t *__restrict__ rec_slot,
             const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
             const StarGeom *__restrict__ geom, const double *__restrict__ lnprior,
             const double *__restrict__ feh, const double *__restrict__ loga,
@@ -279,13 +279,13 @@ k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx,
     for (int64_t r0 = a; r0 < b; r0 += TILE) {
         const int64_t r = r0 + threadIdx.x;
         if (r < b) {
-            const int64_t i = sel_idx[r];
+            const int64_t i = sel_idx[r], vs = rec_slot[r];       // vs: slot of the record's values
             double Fc[3], Ac[3];
             label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
-            const double scale = sel_vals[2 * cap + r];
+            const double scale = sel_vals[2 * cap + vs];
             const double dist = 1. / sqrt(scale);
-            double v = sel_vals[r] + lnprior[i] + gal_lnprior_dev(pp, g, dist, Fc, Ac, s_tbl);
-            if (g.dust_on) v += dust_lnp(g, dist, sel_vals[3 * cap + r]);      // fitting.py:1009-1010
+            double v = sel_vals[vs] + lnprior[i] + gal_lnprior_dev(pp, g, dist, Fc, Ac, s_tbl);
+            if (g.dust_on) v += dust_lnp(g, dist, sel_vals[3 * cap + vs]);      // fitting.py:1009-1010
             lnp1[r] = v;
             if (v > m) m = v;
         }
@@ -400,7 +400,7 @@ __device__ __forceinline__ bool is_pd3(const double (&C)[6]) {
 }
 
 __global__ void __launch_bounds__(TILE)
-k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const double *__restrict__ sel_vals,
+k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const int32_t *__restrict__ rec_slot, const double *__restrict__ sel_vals,
                 const int64_t *__restrict__ sel_off, const double *__restrict__ lnprior,
                 const unsigned long long *__restrict__ mask, const int64_t *__restrict__ offsets,
                 RecPost rp) {
@@ -423,12 +423,13 @@ k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const double *
         if (sel) {
             const int64_t o = base + woff + rank;
             rp.src[o] = (int32_t)(r - sel_off[s]);
-            rp.lnp[o] = sel_vals[r] + lnprior[sel_idx[r]];
+            const int64_t vs = rec_slot[r];
+            rp.lnp[o] = sel_vals[vs] + lnprior[sel_idx[r]];
             double A[6], C[6];
 #pragma unroll
-            for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + r];
+            for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + vs];
             inv3_sym(A, C);
-            const double scale = sel_vals[2 * cap + r];
+            const double scale = sel_vals[2 * cap + vs];
             const double width = 0.02;
             double count = 1.;
             for (int it = 0; it < 200 && !is_pd3(C); ++it) {       // fitting.py:1045-1065
@@ -546,7 +547,7 @@ __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2;
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
           const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
-          double2 *__restrict__ zs, const int32_t *__restrict__ sel_idx,
+          double2 *__restrict__ zs, const int32_t *__restrict__ sel_idx, const int32_t *__restrict__ rec_slot,
           const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
           const int64_t *__restrict__ off2, const int64_t *__restrict__ nsel,
           const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
@@ -609,13 +610,13 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                 }
                 if (live) {
                     const int64_t r = sel_off[s] + rp.src[o];
-                    const int64_t i = sel_idx[r];
+                    const int64_t i = sel_idx[r], vs = rec_slot[r];
                     double Fc[3], Ac[3], L[6];
                     label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
-                    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
-                                 r0 = sel_vals[4 * cap + r];
+                    const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs],
+                                 r0 = sel_vals[4 * cap + vs];
                     // sum_t lin_t e^{epar_t} over the in-bounds samples, with a
                     // running maximum M of epar only (lin needs none); branch-free
                     double M = -INFINITY, acc = 0.;
@@ -651,7 +652,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
                     rp.lnp[o] = lnp;
                     if (lnp > mx) mx = lnp;
-                    double chi2 = sel_vals[1 * cap + r];
+                    double chi2 = sel_vals[1 * cap + vs];
                     if (g.has_par) {
                         const double dp = sqrt(s0) - g.par;
                         chi2 += dp * dp * g.par_ivar;
@@ -679,7 +680,7 @@ constexpr int MCA_R = 8, MCA_G = 8, MCA_NMC = 64;
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
               const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
-              const int32_t *__restrict__ sel_idx, const double *__restrict__ sel_vals,
+              const int32_t *__restrict__ sel_idx, const int32_t *__restrict__ rec_slot, const double *__restrict__ sel_vals,
               const int64_t *__restrict__ sel_off, const int64_t *__restrict__ off2,
               const int64_t *__restrict__ nsel, const int32_t *__restrict__ flags,
               const StarGeom *__restrict__ geom, const double *__restrict__ feh,
@@ -723,13 +724,13 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                     const bool live = rec8 < nrec;
                     const int64_t o = o0 + (live ? rec8 : 0);
                     const int64_t r = sel_off[s] + rp.src[o];
-                    const int64_t i = sel_idx[r];
+                    const int64_t i = sel_idx[r], vs = rec_slot[r];
                     double Fc[3], Ac[3], L[6];
                     label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
-                    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r],
-                                 r0 = sel_vals[4 * cap + r];
+                    const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs],
+                                 r0 = sel_vals[4 * cap + vs];
                     double M = -INFINITY, acc = 0.;
                     int ninb = 0;
                     const double *const zr = zt + (live ? rec8 : 0) * run;
@@ -781,7 +782,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                         if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
                         rp.lnp[o] = lnp;
                         if (lnp > mx) mx = lnp;
-                        double chi2 = sel_vals[1 * cap + r];
+                        double chi2 = sel_vals[1 * cap + vs];
                         if (g.has_par) {
                             const double dp = sqrt(s0) - g.par;
                             chi2 += dp * dp * g.par_ivar;
@@ -917,7 +918,7 @@ k_post_cdf(int s0, const int64_t *__restrict__ off2, const int64_t *__restrict__
 constexpr int POST_NOUT = 17;   // scale av rv cov[9] lnprob dist red dred logwt
 __global__ void __launch_bounds__(64)
 k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
-            const double *__restrict__ uarr, int64_t cap, const int32_t *__restrict__ sel_idx,
+            const double *__restrict__ uarr, int64_t cap, const int32_t *__restrict__ sel_idx, const int32_t *__restrict__ rec_slot,
             const double *__restrict__ sel_vals, const int64_t *__restrict__ sel_off,
             const int64_t *__restrict__ off2, const int64_t *__restrict__ nselv,
             const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
@@ -948,10 +949,10 @@ k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int
     if (lo >= nsel) lo = nsel - 1;
     const int64_t o = a + lo;
     const int64_t r = sel_off[s] + rp.src[o];
-    const int64_t i = sel_idx[r];
+    const int64_t i = sel_idx[r], vs = rec_slot[r];
     out_idx[(int64_t)s * pp.ndraws + q] = (int32_t)i;
     double *ov = out_vals + ((int64_t)s * pp.ndraws + q) * POST_NOUT;
-    const double s0 = sel_vals[2 * cap + r], a0 = sel_vals[3 * cap + r], r0 = sel_vals[4 * cap + r];
+    const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs], r0 = sel_vals[4 * cap + vs];
     ov[0] = s0;
     ov[1] = a0;
     ov[2] = r0;

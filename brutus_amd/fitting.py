@@ -127,6 +127,45 @@ class DeviceGrid(object):
         return self
 
 
+class Records(object):
+    """Indexed first-cut records of one `brutus_fit_batch` call, device resident
+    (include/brutus_amd.h): record r of the batch = model `idx[r]` with values
+    `vals[:, slot[r]]` (lnlike, chi2, scale, av, rv, icov[00, 01, 02, 11, 12, 22]); the
+    records of star s are `off[s]:off[s + 1]`, in ascending model order.  `rv_const` is
+    not None when Rv was pinned: plane 4 is then unwritten and rv is that constant."""
+
+    __slots__ = ("idx", "slot", "vals", "off", "rv_const", "counts")
+
+    def __init__(self, idx, slot, vals, off, rv_const=None, counts=None):
+        self.idx, self.slot, self.vals, self.off = idx, slot, vals, off
+        self.rv_const, self.counts = rv_const, counts
+
+    @classmethod
+    def dense(cls, idx, vals, off):
+        """Records whose values lie in record order (slot = identity)."""
+        import torch
+        return cls(idx, torch.arange(idx.numel(), dtype=torch.int32, device=idx.device),
+                   vals, off)
+
+    @property
+    def capacity(self):
+        return self.idx.numel()
+
+    def fill_rv(self):
+        """Write the pinned Rv into plane 4 (consumers that read the planes directly)."""
+        if self.rv_const is not None:
+            self.vals[4].fill_(self.rv_const)
+            self.rv_const = None
+
+    def host(self, a, b):
+        """(model indices int64, values (NVALS, b - a)) of records a:b as numpy arrays."""
+        idx = self.idx[a:b].cpu().numpy().astype(np.int64)
+        vals = self.vals.index_select(1, self.slot[a:b].long()).cpu().numpy()
+        if self.rv_const is not None:
+            vals[4] = self.rv_const
+        return idx, vals
+
+
 class _Engine(object):
     """Owns the device workspace and drives the *_batch entry points."""
 
@@ -134,7 +173,7 @@ class _Engine(object):
         self.torch = _torch()
         self.L = _lib.lib()
         self.grid = grid
-        per_star = (14 * 8 + 4) * grid.nmodel + 65536
+        per_star = 104 * grid.nmodel + 65536       # workspace + records / full-grid outputs
         nb = int(max(1, min(_lib.MAX_BATCH, mem_budget // per_star)))
         if max_batch is not None:
             nb = max(1, min(nb, int(max_batch)))
@@ -203,65 +242,73 @@ class _Engine(object):
                        ndim=ndim.cpu().numpy(), k1=k1, k2=k2)
         return out
 
-    def fit_batch_device(self, f, e, m, p, pe, has_par, params, capacity=None,
-                         sel_buffers=None):
-        """Device-resident inputs -> device-resident compact records.
-        Returns (sel_idx, sel_vals, sel_off, ndim, k1, k2) tensors."""
+    def _record_buffers(self, capacity):
+        torch, g = self.torch, self.grid
+        return (torch.empty(capacity, dtype=torch.int32, device=g.device),
+                torch.empty(capacity, dtype=torch.int32, device=g.device),
+                torch.empty((_lib.NVALS, capacity), dtype=torch.float64, device=g.device))
+
+    def fit_batch_device(self, f, e, m, p, pe, has_par, params, buffers=None, grow=True):
+        """Device-resident inputs -> device-resident indexed records (`Records`).
+        Returns (records, ndim tensor, k1, k2).  `buffers` = (idx, slot, vals) tensors to
+        write into (default: the engine's own, kept between calls).  When they are too
+        small the call is repeated with larger ones (`grow`; the engine keeps them, so a
+        steady stream of batches settles after the first) -- `self.regrown` counts that."""
         torch, L, g = self.torch, self.L, self.grid
         S = f.shape[0]
         ws = self._workspace(S)
-        if capacity is None:
-            capacity = max(1 << 20, 4 * S * 4096)
-        if sel_buffers is None or sel_buffers[0].numel() < capacity:
-            sel_idx = torch.empty(capacity, dtype=torch.int32, device=g.device)
-            sel_vals = torch.empty((_lib.NVALS, capacity), dtype=torch.float64,
-                                   device=g.device)
-        else:
-            sel_idx, sel_vals = sel_buffers
-            capacity = sel_idx.numel()
-        sel_off = torch.empty(S + 1, dtype=torch.int64, device=g.device)
+        if buffers is None:
+            buffers = getattr(self, "_rec_bufs", None)
+        if buffers is None:
+            buffers = self._record_buffers(max(1 << 20, (S * g.nmodel) // 8))
+        off = torch.empty(S + 1, dtype=torch.int64, device=g.device)
         ndim = torch.empty(S, dtype=torch.int32, device=g.device)
         k1 = np.zeros(S, dtype=np.int32)
         k2 = np.zeros(S, dtype=np.int32)
-        _lib.check(L.brutus_fit_batch(
-            g.soa.data_ptr(), g.nmodel, g.nfilt, S, f.data_ptr(), e.data_ptr(),
-            m.data_ptr(), p.data_ptr() if p is not None else None,
-            pe.data_ptr() if pe is not None else None, has_par, params,
-            ws.data_ptr(), ws.numel(), capacity, sel_idx.data_ptr(),
-            sel_vals.data_ptr(), sel_off.data_ptr(), ndim.data_ptr(),
-            k1.ctypes.data, k2.ctypes.data, _stream_ptr(torch)))
-        return sel_idx, sel_vals, sel_off, ndim, k1, k2
+        counts = np.zeros(3, dtype=np.int64)
+        while True:
+            idx, slot, vals = buffers
+            capacity = idx.numel()
+            rc = L.brutus_fit_batch(
+                g.soa.data_ptr(), g.nmodel, g.nfilt, S, f.data_ptr(), e.data_ptr(),
+                m.data_ptr(), p.data_ptr() if p is not None else None,
+                pe.data_ptr() if pe is not None else None, has_par, params,
+                ws.data_ptr(), ws.numel(), capacity, idx.data_ptr(), slot.data_ptr(),
+                vals.data_ptr(), off.data_ptr(), ndim.data_ptr(),
+                k1.ctypes.data, k2.ctypes.data, counts.ctypes.data, _stream_ptr(torch))
+            if rc == -2 and grow and b"record buffer too small" in L.brutus_last_error():
+                # the flux phase keeps its results in the record planes themselves, so a
+                # batch that does not fit is redone as a whole
+                self.regrown = getattr(self, "regrown", 0) + 1
+                buffers = idx = slot = vals = None
+                self._rec_bufs = None
+                buffers = self._record_buffers(int(counts[2] * 1.25) + 4096)
+                continue
+            _lib.check(rc)
+            break
+        if buffers is not None and (getattr(self, "_rec_bufs", None) is None
+                                    or self._rec_bufs[0].numel() <= capacity):
+            self._rec_bufs = buffers
+        rv_const = (float(params.rv_gauss[0])
+                    if params.rvlim[0] == params.rvlim[1] == params.rv_gauss[0] else None)
+        return Records(idx, slot, vals, off, rv_const, counts), ndim, k1, k2
 
     def records_device(self, f, e, m, p, pe, has_par, params):
-        """`fit_batch_device` with automatic growth of the record buffers."""
-        torch, L, g = self.torch, self.L, self.grid
-        S = f.shape[0]
-        bufs = getattr(self, "_sel_bufs", None)
-        sel_idx, sel_vals, sel_off, ndim, k1, k2 = self.fit_batch_device(
-            f, e, m, p, pe, has_par, params, sel_buffers=bufs)
-        off = sel_off.cpu().numpy()
-        total, cap = int(off[-1]), sel_idx.numel()
-        if total > cap:
-            cap = int(total * 1.25) + 1024
-            sel_idx = torch.empty(cap, dtype=torch.int32, device=g.device)
-            sel_vals = torch.empty((_lib.NVALS, cap), dtype=torch.float64,
-                                   device=g.device)
-            ws = self._workspace(S)
-            _lib.check(L.brutus_fit_gather(
-                g.soa.data_ptr(), g.nmodel, g.nfilt, S, params, ws.data_ptr(),
-                ws.numel(), cap, sel_idx.data_ptr(), sel_vals.data_ptr(),
-                sel_off.data_ptr(), _stream_ptr(torch)))
-        self._sel_bufs = (sel_idx, sel_vals)
-        return sel_idx, sel_vals, sel_off, off, ndim.cpu().numpy(), k1, k2
+        """`fit_batch_device` plus the host copies the callers need:
+        (records, off, ndim, k1, k2)."""
+        rec, ndim, k1, k2 = self.fit_batch_device(f, e, m, p, pe, has_par, params)
+        return rec, rec.off.cpu().numpy(), ndim.cpu().numpy(), k1, k2
 
-    def post_batch_device(self, sel_idx, sel_vals, sel_off, nstar, statics,
-                          coords, parallax, parallax_err, pp, np_states=None):
-        """`brutus_post_batch` on device-resident records.  `statics` =
+    def post_batch_device(self, rec, nstar, statics,
+                          coords, parallax, parallax_err, pp, np_states=None, dust=None):
+        """`brutus_post_batch` on device-resident `Records`.  `statics` =
         (lnprior, feh, loga) device tensors (feh / loga may be None).
         `np_states` (uint32 (nstream, 628), advanced in place): draw from numpy's own
         legacy stream(s) instead (`brutus_post_batch_numpy`)."""
         torch, L, g = self.torch, self.L, self.grid
-        cap = sel_idx.numel()
+        rec.fill_rv()
+        sel_idx, rec_slot, sel_vals, sel_off = rec.idx, rec.slot, rec.vals, rec.off
+        cap = rec.capacity
         nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
         slot0 = self.__dict__.setdefault("_post_slots", {}).setdefault(0, {})
         # (one set of buffers with pipeline slot 0: the two forms never run at the same time)
@@ -289,8 +336,10 @@ class _Engine(object):
                     gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.25 * free))))
                     zb = slot0["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
                                                      device=g.device)
+                self._set_dust(dust)          # one-shot context: before EVERY (re)try
                 rc = L.brutus_post_batch_numpy(
-                    nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
+                    nstar, cap, sel_idx.data_ptr(), rec_slot.data_ptr(), sel_vals.data_ptr(),
+                    sel_off.data_ptr(),
                     lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
                     loga.data_ptr() if loga is not None else None, t_coords.data_ptr(),
                     t_par.data_ptr(), t_perr.data_ptr(), pp, self._post_ws.data_ptr(),
@@ -308,8 +357,10 @@ class _Engine(object):
                 _lib.check(rc)
                 break
             return (out_idx.cpu().numpy(), out_vals.cpu().numpy(), star_out, flags, nbase)
+        self._set_dust(dust)
         _lib.check(L.brutus_post_batch(
-            nstar, cap, sel_idx.data_ptr(), sel_vals.data_ptr(), sel_off.data_ptr(),
+            nstar, cap, sel_idx.data_ptr(), rec_slot.data_ptr(), sel_vals.data_ptr(),
+            sel_off.data_ptr(),
             lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
             loga.data_ptr() if loga is not None else None, t_coords.data_ptr(),
             t_par.data_ptr(), t_perr.data_ptr(), pp, self._post_ws.data_ptr(),
@@ -320,8 +371,17 @@ class _Engine(object):
                 nbase)
 
     # ---- brutus_post_batch_numpy in two halves (pipelined across batches) --------------
-    def post_numpy_begin(self, slot, sel_idx, sel_vals, sel_off, nstar, statics, coords,
-                         parallax, parallax_err, pp, np_states):
+    def _set_dust(self, dust):
+        """Line-of-sight dust context of the NEXT post call of this thread
+        (`brutus_post_set_dust` is one-shot: it has to precede every call and every retry).
+        `dust` = (t_los, t_ok) device tensors or None."""
+        if dust is not None:
+            t_los, t_ok = dust
+            _lib.check(self.L.brutus_post_set_dust(t_los.data_ptr(), t_ok.data_ptr(),
+                                                   int(t_los.shape[2]), 0., 1., 1., 0.2))
+
+    def post_numpy_begin(self, slot, rec, nstar, statics, coords,
+                         parallax, parallax_err, pp, np_states, dust=None):
         """Phase 1 of `brutus_post_batch_numpy_phase` in pipeline slot `slot` (own
         workspace, normal buffer and outputs): cuts, covariances, stream walk; `np_states`
         is advanced.  False if the objects do not fit the slot's buffer as one group
@@ -330,7 +390,8 @@ class _Engine(object):
         torch, L, g = self.torch, self.L, self.grid
         ctxs = self.__dict__.setdefault("_post_slots", {})
         ctx = ctxs.setdefault(slot, {})
-        cap = sel_idx.numel()
+        rec.fill_rv()
+        cap = rec.capacity
         nbytes = L.brutus_post_workspace_bytes(nstar, cap, pp.nmc)
         if ctx.get("ws") is None or ctx["ws"].numel() < nbytes:
             ctx["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
@@ -340,7 +401,10 @@ class _Engine(object):
             ctx["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64, device=g.device)
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)
         lnprior, feh, loga = statics
-        ctx["keep"] = (sel_idx, sel_vals, sel_off, dev(coords), dev(parallax), dev(parallax_err))
+        # everything phase 2 reads stays referenced until `post_numpy_end` (the dust tables
+        # too: phase 2 evaluates the line-of-sight prior inside the Monte Carlo integral)
+        ctx["keep"] = (rec.idx, rec.vals, rec.off, dev(coords), dev(parallax), dev(parallax_err),
+                       rec.slot, dust)
         ctx["out"] = (torch.empty((nstar, pp.ndraws), dtype=torch.int32, device=g.device),
                       torch.empty((nstar, pp.ndraws, 17), dtype=torch.float64, device=g.device),
                       np.zeros((nstar, 4)), np.zeros(nstar, dtype=np.int32))
@@ -348,8 +412,10 @@ class _Engine(object):
 
         def call(phase):
             k, o = ctx["keep"], ctx["out"]
+            if phase == 1:
+                self._set_dust(k[7])
             return L.brutus_post_batch_numpy_phase(
-                nstar, cap, k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
+                nstar, cap, k[0].data_ptr(), k[6].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
                 lnprior.data_ptr(), feh.data_ptr() if feh is not None else None,
                 loga.data_ptr() if loga is not None else None, k[3].data_ptr(), k[4].data_ptr(),
                 k[5].data_ptr(), pp, ctx["ws"].data_ptr(), ctx["ws"].numel(), o[0].data_ptr(),
@@ -374,56 +440,30 @@ class _Engine(object):
         return res
 
     @staticmethod
-    def record_of(sel_idx, sel_vals, off, s, ndim, k1=0, k2=0):
+    def record_of(rec, off, s, ndim, k1=0, k2=0):
         """One object's first-cut records as the host-stage dict."""
-        a, b = int(off[s]), int(off[s + 1])
-        idx = sel_idx[a:b].cpu().numpy()
-        vals = sel_vals[:, a:b].cpu().numpy()
-        return dict(sel=idx.astype(np.int64), lnlike=vals[0], chi2=vals[1],
+        idx, vals = rec.host(int(off[s]), int(off[s + 1]))
+        return dict(sel=idx, lnlike=vals[0], chi2=vals[1],
                     scale=vals[2], av=vals[3], rv=vals[4],
                     icov=_icov_from6(vals[5:11]), Ndim=int(ndim), K1=int(k1),
                     K2=int(k2))
 
     def fit_batch(self, flux, err, mask, parallax, parallax_err, params):
         """Host numpy in -> list of per-star compact record dicts."""
-        torch, L, g = self.torch, self.L, self.grid
+        torch, g = self.torch, self.grid
         S = flux.shape[0]
         with torch.cuda.device(g.device):
             f, e, m, p, pe, has_par = self._upload(flux, err, mask, parallax,
                                                    parallax_err)
-            bufs = getattr(self, "_sel_bufs", None)
-            sel_idx, sel_vals, sel_off, ndim, k1, k2 = self.fit_batch_device(
-                f, e, m, p, pe, has_par, params, sel_buffers=bufs)
-            off = sel_off.cpu().numpy()
-            total = int(off[-1])
-            cap = sel_idx.numel()
-            if total > cap:
-                cap = int(total * 1.25) + 1024
-                sel_idx = torch.empty(cap, dtype=torch.int32, device=g.device)
-                sel_vals = torch.empty((_lib.NVALS, cap), dtype=torch.float64,
-                                       device=g.device)
-                ws = self._workspace(S)
-                _lib.check(L.brutus_fit_gather(
-                    g.soa.data_ptr(), g.nmodel, g.nfilt, S, params,
-                    ws.data_ptr(), ws.numel(), cap, sel_idx.data_ptr(),
-                    sel_vals.data_ptr(), sel_off.data_ptr(), _stream_ptr(torch)))
-            self._sel_bufs = (sel_idx, sel_vals)
-            idx = sel_idx[:total].cpu().numpy()
-            vals = sel_vals[:, :total].cpu().numpy()
-            ndim = ndim.cpu().numpy()
+            rec, off, ndim, k1, k2 = self.records_device(f, e, m, p, pe, has_par, params)
+            idx, vals = rec.host(0, int(off[-1]))
         out = []
         for s in range(S):
             a, b = int(off[s]), int(off[s + 1])
-            icov = np.empty((b - a, 3, 3))
-            icov[:, 0, 0] = vals[5, a:b]
-            icov[:, 0, 1] = icov[:, 1, 0] = vals[6, a:b]
-            icov[:, 0, 2] = icov[:, 2, 0] = vals[7, a:b]
-            icov[:, 1, 1] = vals[8, a:b]
-            icov[:, 1, 2] = icov[:, 2, 1] = vals[9, a:b]
-            icov[:, 2, 2] = vals[10, a:b]
-            out.append(dict(sel=idx[a:b].astype(np.int64), lnlike=vals[0, a:b],
+            out.append(dict(sel=idx[a:b], lnlike=vals[0, a:b],
                             chi2=vals[1, a:b], scale=vals[2, a:b],
-                            av=vals[3, a:b], rv=vals[4, a:b], icov=icov,
+                            av=vals[3, a:b], rv=vals[4, a:b],
+                            icov=_icov_from6(vals[5:11, a:b]),
                             Ndim=int(ndim[s]), K1=int(k1[s]), K2=int(k2[s])))
         return out
 
@@ -1050,10 +1090,9 @@ class BruteForce(object):
         from . import pdf as _pdf
         dust_tables = None
         if apply_av_prior and lndustprior is _pdf.dust_lnprior:
-            try:
-                dust_tables = _pdf.los_tables(dustfile, data_coords)
-            except Exception:
-                dust_tables = None
+            # built per batch (bounded memory, no catalogue-long Python loop up front);
+            # provider errors surface to the caller
+            dust_tables = lambda a, b: _pdf.los_tables(dustfile, data_coords[a:b])
         dust_ok = (not apply_av_prior and lndustprior is None) or dust_tables is not None
         if (self.device_lnpost and lnprior_ext is None and dust_ok
                 and wt_thresh is not None and wt_thresh > 0
@@ -1213,11 +1252,14 @@ class BruteForce(object):
                 if streams[k % nE] is None:
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
-                    return en.records_device(f, e, m, p, pe, hp, params)
+                    out = en.records_device(f, e, m, p, pe, hp, params)
+                    out[0].fill_rv()
+                    return out
                 with torch.cuda.stream(streams[k % nE]):
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
                     out = en.records_device(f, e, m, p, pe, hp, params)
+                    out[0].fill_rv()
                     streams[k % nE].synchronize()
                     return out
 
@@ -1225,7 +1267,7 @@ class BruteForce(object):
             with torch.cuda.device(dev), torch.cuda.stream(fin_stream):
                 return eng.post_numpy_end(slot)
 
-        def rows(a, S, sel_idx, sel_vals, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
+        def rows(a, S, rec, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
                  nbase, ubase0):
             """The tuples `_fit` yields for the objects of one batch."""
             for s in range(S):
@@ -1237,8 +1279,8 @@ class BruteForce(object):
                     rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
                           PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
                                             n_uniform=int(ubase0) + s * K))
-                    rec = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
-                    yield self._finish_star(rec, parallax[i], parallax_err[i],
+                    rec1 = eng.record_of(rec, off, s, ndim[s], k1[s], k2[s])
+                    yield self._finish_star(rec1, parallax[i], parallax_err[i],
                                             data_coords[i], Nmc_prior, lnprior,
                                             wt_thresh, cdf_thresh, lngalprior, None,
                                             None, dlabels, avlim, rvlim, mem_lim, rs,
@@ -1266,10 +1308,10 @@ class BruteForce(object):
                 S = b - a
                 with torch.cuda.device(dev):
                     if ahead:
-                        (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = fut.result()
+                        (rec, off, ndim, k1, k2) = fut.result()
                         fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
                     else:
-                        (sel_idx, sel_vals, sel_off, off, ndim, k1, k2) = scan(kb)
+                        (rec, off, ndim, k1, k2) = scan(kb)
                     pp = _lib.PostParams()
                     pp.nmc, pp.ndraws = int(Nmc_prior), int(Ndraws)
                     pp.return_distreds = 1 if return_distreds else 0
@@ -1299,22 +1341,21 @@ class BruteForce(object):
                             getattr(pp, k)[:] = list(val)
                         else:
                             setattr(pp, k, val)
-                    if dust_tables is not None:      # one-shot context of the next post call
-                        los, ok = dust_tables
-                        t_los = torch.from_numpy(np.ascontiguousarray(los[a:b])).to(dev)
-                        t_ok = torch.from_numpy(np.ascontiguousarray(ok[a:b])).to(dev)
-                        _lib.check(eng.L.brutus_post_set_dust(t_los.data_ptr(), t_ok.data_ptr(),
-                                                              int(los.shape[2]), 0., 1., 1., 0.2))
+                    dust = None
+                    if dust_tables is not None:      # this batch's sightlines; the engine hands
+                        los, ok = dust_tables(a, b)  # them to every post call and retry and keeps
+                        dust = (torch.from_numpy(np.ascontiguousarray(los)).to(dev),     # them alive
+                                torch.from_numpy(np.ascontiguousarray(ok)).to(dev))
                     if pipelined:
                         with torch.cuda.stream(walk_stream):
                             began = eng.post_numpy_begin(
-                                kb % 2, sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
-                                parallax[a:b], parallax_err[a:b], pp, np_states)
+                                kb % 2, rec, S, statics, data_coords[a:b],
+                                parallax[a:b], parallax_err[a:b], pp, np_states, dust=dust)
                         if began:
                             if np_mode == "shared":   # final already: the walk is done
                                 rstate.set_state(words_to_state(np_states[0]))
                             job = finisher.submit(finish, kb % 2)
-                            args = (a, S, sel_idx, sel_vals, off, ndim, k1, k2)
+                            args = (a, S, rec, off, ndim, k1, k2)
                             if pending is not None:
                                 prev, pargs = pending
                                 pending = (job, args)
@@ -1329,8 +1370,8 @@ class BruteForce(object):
                             for row in rows(*(pargs + prev.result() + (0,))):
                                 yield row
                     out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
-                        sel_idx, sel_vals, sel_off, S, statics, data_coords[a:b],
-                        parallax[a:b], parallax_err[a:b], pp, np_states=np_states)
+                        rec, S, statics, data_coords[a:b],
+                        parallax[a:b], parallax_err[a:b], pp, np_states=np_states, dust=dust)
                     ubase0 = pp.uniform_base
                     if np_mode == "shared":      # the caller's generator continues from here
                         rstate.set_state(words_to_state(np_states[0]))
@@ -1338,7 +1379,7 @@ class BruteForce(object):
                         # what the batch consumed from the shared stream
                         rstate.n_normal = int(nbase[S])
                         rstate.n_uniform = int(ubase0) + S * K
-                    for row in rows(a, S, sel_idx, sel_vals, off, ndim, k1, k2, out_idx, out_vals,
+                    for row in rows(a, S, rec, off, ndim, k1, k2, out_idx, out_vals,
                                     star_out, flags, nbase, ubase0):
                         yield row
             if pending is not None:

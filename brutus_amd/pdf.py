@@ -162,19 +162,24 @@ def _los_provider(dustfile):
 
 
 def los_tables(dustfile, coords):
-    """Line-of-sight profiles of many objects as one array for the device stage:
-    `(los (N, 3, nd) = dist, Av_mean, Av_err; ok (N,) int32)`; raises if the provider
-    returns profiles of different lengths."""
+    """Line-of-sight profiles of a batch of objects as one array for the device stage:
+    `(los (N, 3, nd) = dist, Av_mean, Av_err; ok (N,) int32)`.  Profiles shorter than the
+    longest of the batch are padded by repeating their last node, which leaves
+    `numpy.interp` (end value beyond the table) and the device's interpolation unchanged.
+    Called per batch (`coords[a:b]`), so neither the Python loop over sightlines nor the
+    table ever spans the whole catalogue."""
     q = _los_provider(dustfile)
     rows, ok = [], []
     for c in np.asarray(coords, dtype=np.float64):
-        d, m, e = (np.asarray(x, dtype=np.float64) for x in q(c))
+        d, m, e = (np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in q(c))
+        if not (d.shape == m.shape == e.shape) or d.ndim != 1 or d.size < 2:
+            raise ValueError("a line-of-sight profile needs >= 2 nodes of (dist, mean, err)")
         good = bool(np.all(np.isfinite(m) & np.isfinite(e)))
         ok.append(1 if good else 0)
         rows.append(np.stack([d, np.where(np.isfinite(m), m, 0.), np.where(np.isfinite(e), e, 0.)]))
-    nd = {r.shape[1] for r in rows}
-    if len(nd) != 1 or nd.pop() < 2:
-        raise ValueError("line-of-sight profiles must share one distance grid length")
+    nd = max(r.shape[1] for r in rows)
+    rows = [r if r.shape[1] == nd else np.concatenate(
+        [r, np.repeat(r[:, -1:], nd - r.shape[1], axis=1)], axis=1) for r in rows]
     return np.stack(rows), np.asarray(ok, dtype=np.int32)
 
 

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BRUTUS_ABI_VERSION 1
+#define BRUTUS_ABI_VERSION 2
 #define BRUTUS_MAX_FILT 32   /* bands per fit (device register budget)            */
 #define BRUTUS_MAX_BATCH 256 /* stars per brutus_*_batch call                     */
 #define BRUTUS_NVALS 11      /* lnlike, chi2, scale, av, rv, icov[00,01,02,11,12,22] */
@@ -105,30 +105,31 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                          int32_t *h_k2, void *stream);
 
 /* The fit() hot path: loglike + lnpost's parallax clip + first wt_thresh cut
- * (fitting.py:976-991), emitting only the selected models, in ascending model
- * order per star (= np.where order):
- *   d_sel_idx  (capacity,) int32   model index
- *   d_sel_vals (BRUTUS_NVALS, capacity) float64
- *   d_sel_off  (nstar + 1,) int64  record range of star s is [off[s], off[s+1])
- * Records beyond `capacity` are dropped; off[nstar] always holds the true
- * total so the caller can re-run brutus_fit_gather with a larger buffer. */
+ * (fitting.py:976-991), emitting only the selected models as INDEXED RECORDS:
+ *   d_rec_idx  (capacity,) int32   model index, ascending per star (= np.where order)
+ *   d_rec_slot (capacity,) int32   column of that record's values in d_rec_vals
+ *   d_rec_vals (BRUTUS_NVALS, capacity) float64
+ *   d_rec_off  (nstar + 1,) int64  record range of star s is [off[s], off[s+1])
+ * i.e. value v of record r is d_rec_vals[v * capacity + d_rec_slot[r]].  The indirection
+ * exists because a value is written exactly once, where it is computed: columns
+ * [0, ncand) belong to the candidates of the likelihood cull (fitting.py:758-759) in
+ * candidate-list order and receive the flux-phase results (fitting.py:778-803) of those
+ * that survive it; columns [ncand, ncand + nder) receive the selected models the cull
+ * dropped.  Columns of candidates that fail the cull or the first cut are never referenced.
+ * When Rv is pinned (rvlim[0] == rvlim[1] == rv_gauss[0]) plane 4 (rv) is NOT written:
+ * every record's rv is rv_gauss[0].
+ * h_counts (host, 3 x int64): [0] selected models of the batch (= off[nstar]),
+ * [1] ncand, [2] columns needed = ncand + nder.  BRUTUS_ENOMEM if [2] > capacity (or
+ * already [1] > capacity: then [2] is an estimate): call again with larger buffers. */
 int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                      int nstar, const double *d_flux, const double *d_err,
                      const uint8_t *d_mask, const double *d_parallax,
                      const double *d_parallax_err, int has_parallax,
                      const brutus_params *params, void *d_workspace,
                      size_t workspace_bytes, int64_t capacity,
-                     int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
-                     int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
-                     void *stream);
-
-/* Re-emit the selection of the last brutus_fit_batch on this workspace (same
- * grid, params and nstar) into a larger record buffer. */
-int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
-                      int nstar, const brutus_params *params, void *d_workspace,
-                      size_t workspace_bytes, int64_t capacity,
-                      int32_t *d_sel_idx, double *d_sel_vals, int64_t *d_sel_off,
-                      void *stream);
+                     int32_t *d_rec_idx, int32_t *d_rec_slot, double *d_rec_vals,
+                     int64_t *d_rec_off, int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
+                     int64_t *h_counts, void *stream);
 
 /* ---- lnpost on the device ------------------------------------------------------
  * Everything of fitting.lnpost after the first cut (fitting.py:1000-1107) and
@@ -139,7 +140,8 @@ int brutus_fit_gather(const float *d_grid_soa, int64_t nmodel, int nfilt,
  * normal j / uniform q are functions of (seed, j) / (seed, q), so the result is
  * what the reference produces when it is handed that object as `rstate`.
  *
- * Input = the device-resident records brutus_fit_batch emitted.  Output per
+ * Input = the device-resident indexed records brutus_fit_batch emitted (d_sel_idx = its
+ * d_rec_idx, d_rec_slot, d_sel_vals = d_rec_vals, d_sel_off = d_rec_off, same capacity).  Output per
  * object s and draw q < ndraws:
  *   d_out_idx  (nstar, ndraws) i32      resampled model index
  *   d_out_vals (nstar, ndraws, 17) f64  scale, av, rv, cov_sar[9], lnprob,
@@ -171,7 +173,7 @@ typedef struct brutus_post_params {
 } brutus_post_params;
 
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc);
-int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                       const double *d_sel_vals, const int64_t *d_sel_off,
                       const double *d_lnprior, const double *d_feh,
                       const double *d_loga, const double *d_coords,
@@ -194,7 +196,7 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx,
  *   nstream == nstar object s has its own stream (per-object seeds: sharded runs)
  * d_zbuf (zbuf_doubles float64) receives the normals of a group of objects; an object
  * needs 3 * nmc * Nsel + 3 doubles; BRUTUS_ENOMEM if a single object does not fit. */
-int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                             const double *d_sel_vals, const int64_t *d_sel_off,
                             const double *d_lnprior, const double *d_feh,
                             const double *d_loga, const double *d_coords,
@@ -213,7 +215,7 @@ int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_id
  * -- use the whole-call form then); phase 2 = Monte Carlo integral, evidence, draws,
  * outputs, with the SAME arguments, workspace and buffer, on any stream / thread, after
  * phase 1 returned.  phase 0 = brutus_post_batch_numpy. */
-int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx,
+int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                                   const double *d_sel_vals, const int64_t *d_sel_off,
                                   const double *d_lnprior, const double *d_feh, const double *d_loga,
                                   const double *d_coords, const double *d_parallax,
@@ -240,21 +242,6 @@ int brutus_post_set_dust(const double *d_los, const int32_t *d_ok, int nd,
  * start windows from a doubling tree of jumps); without them by one. */
 int brutus_set_mt_jump(const uint32_t *h_polys, int npoly, int64_t stride0,
                        int64_t stride1);
-
-/* Test hook: walk numpy stream(s) for nobj objects needing h_nnorm[o] normals and nuni
- * uniforms each (normals of object o at d_z + sum over earlier objects of
- * (h_nnorm rounded up to even) + 2; uniforms at d_u + o * nuni). */
-int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states,
-                           const int64_t *h_nnorm, int nuni, double *d_z, double *d_u,
-                           void *stream);
-
-/* Test hooks for the two building blocks above. */
-int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
-                     double *d_uniforms, void *stream);
-int brutus_debug_galprior(const brutus_post_params *params, int n,
-                          const double *d_dist, const double *d_coord,
-                          const double *d_feh, const double *d_loga, double *d_out,
-                          void *stream);
 
 /* ---- cluster mode ------------------------------------------------------------
  * Hot block of cluster.isochrone_loglike (cluster.py:336-414): for nobj objects
@@ -321,34 +308,6 @@ int brutus_offsets_bootstrap(int band, int nobj, int nsamps, int nfilt, int n, i
                              void *d_workspace, size_t workspace_bytes, double *d_meds,
                              void *stream);
 
-
-/* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
- * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
- * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated
- * on a known byte count (MI355X_MICROARCH.md, HBM section). */
-int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
-                             void *stream);
-/* Plain device copy with 16 B per lane (nbytes a multiple of 16): the streaming
- * ceiling MI355X_MICROARCH.md quotes (6.29 TB/s) is measured with this access. */
-int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes,
-                            void *stream);
-
-/* Test hooks: y[i] = the kernels' own 10^x / e^x / ln x for n inputs
- * (which = 0, 1, 2 in brutus_debug_math). */
-int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
-int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n,
-                      void *stream);
-
-/* Test hook: copy one internal array of the workspace of the last brutus_fit_batch
- * (same nmodel / nfilt / nstar) into a caller-owned device buffer.  which =
- * 0, 1: float64 planes (nstar, nmodel) of the cull / first-cut statistic (path 1);
- * 2, 3: the float32 statistics of path 2; 4: run-time audit max|f32 - f64| (3, nstar)
- * (BRUTUS_AUDIT=1); 5: per-star float32 block; 6, 7: exact cull / first-cut
- * thresholds (nstar,) f64; 8: float32 maxima (nstar, 10); 9: K1 status (nstar,) i32. */
-int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
-                      int nfilt, int nstar, int which, void *d_dst, size_t nbytes,
-                      void *stream);
-int brutus_debug_sizeof_star32(void);
 
 /* Name and average duration (HIP events on `stream`) of the kernels launched
  * by the last *_batch call; used by bench.py for the roofline line. */

@@ -1,0 +1,61 @@
+/*
+ * brutus_amd_debug.h -- test hooks and measurement aids exported by libbrutus_amd.so.
+ * NOT part of the product ABI (include/brutus_amd.h): nothing in brutus_amd/fitting.py's
+ * product path calls these; tests/ and bench.py's calibration stream do.
+ */
+#ifndef BRUTUS_AMD_DEBUG_H
+#define BRUTUS_AMD_DEBUG_H
+
+#include "brutus_amd.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Test hook: walk numpy stream(s) for nobj objects needing h_nnorm[o] normals and nuni
+ * uniforms each (normals of object o at d_z + sum over earlier objects of
+ * (h_nnorm rounded up to even) + 2; uniforms at d_u + o * nuni). */
+int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states,
+                           const int64_t *h_nnorm, int nuni, double *d_z, double *d_u,
+                           void *stream);
+
+/* Test hooks for the two building blocks above. */
+int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
+                     double *d_uniforms, void *stream);
+int brutus_debug_galprior(const brutus_post_params *params, int n,
+                          const double *d_dist, const double *d_coord,
+                          const double *d_feh, const double *d_loga, double *d_out,
+                          void *stream);
+
+/* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
+ * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
+ * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated
+ * on a known byte count (MI355X_MICROARCH.md, HBM section). */
+int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
+                             void *stream);
+/* Plain device copy with 16 B per lane (nbytes a multiple of 16): the streaming
+ * ceiling MI355X_MICROARCH.md quotes (6.29 TB/s) is measured with this access. */
+int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes,
+                            void *stream);
+
+/* Test hooks: y[i] = the kernels' own 10^x / e^x / ln x for n inputs
+ * (which = 0, 1, 2 in brutus_debug_math). */
+int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
+int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n,
+                      void *stream);
+
+/* Test hook: copy one internal array of the workspace of the last brutus_fit_batch
+ * (same nmodel / nfilt / nstar) into a caller-owned device buffer.  which =
+ * 2, 3: the float32 statistics (nstar, nmodel) of the cull / first cut; 4: run-time audit max|f32 - f64| (3, nstar)
+ * (BRUTUS_AUDIT=1); 5: per-star float32 block; 6, 7: exact cull / first-cut
+ * thresholds (nstar,) f64; 8: float32 maxima (nstar, 10); 9: K1 status (nstar,) i32. */
+int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
+                      int nfilt, int nstar, int which, void *d_dst, size_t nbytes,
+                      void *stream);
+int brutus_debug_sizeof_star32(void);
+
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BRUTUS_AMD_DEBUG_H */

@@ -8,8 +8,8 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "brutus_amd.h")).read()
+def _declared(header="brutus_amd.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(brutus_[a-z0-9_]+)\s*\(", txt)))
 
@@ -22,22 +22,26 @@ def test_library_exports_every_declared_symbol():
         __graft_entry__.build_hip()
     L = ctypes.CDLL(_lib.LIB_PATH)
     names = _declared()
+    debug = _declared("brutus_amd_debug.h")
     assert len(names) >= 10
-    for n in names:
+    for n in names + debug:
         assert hasattr(L, n), n
-    # the ctypes table mirrors the header one to one
-    assert sorted(_lib.SIGNATURES) == names
+    # the ctypes table mirrors the two headers one to one; test hooks and measurement aids
+    # are declared apart from the product ABI
+    assert sorted(_lib.SIGNATURES) == sorted(names + debug)
+    assert sorted(_lib.DEBUG_NAMES) == debug
+    assert not [n for n in names if "debug" in n or "calibrate" in n]
 
 
 def test_abi_version_and_queries():
     from brutus_amd import _lib
     L = _lib.lib()
-    assert L.brutus_abi_version() == 1
+    assert L.brutus_abi_version() == _lib.ABI_VERSION == 2
     assert L.brutus_padded_filters(6) == 8
     assert L.brutus_padded_filters(12) == 12
     assert L.brutus_padded_filters(33) < 0
     assert L.brutus_grid_soa_bytes(1000, 12) == 8 * 12 * 1024 * 4
-    assert L.brutus_workspace_bytes(750000, 12, 64) > 13 * 8 * 750000 * 64
+    assert L.brutus_workspace_bytes(750000, 12, 64) > 28 * 750000 * 64
     assert L.brutus_workspace_bytes(750000, 40, 64) == 0
 
 

@@ -1,18 +1,28 @@
-"""Second-generation hot path of brutus_fit_batch (float32 pre-classification +
-exact thresholds + float64 on candidates, csrc/fit2_kernels.hpp) against the
-first-generation path (float64 on every model), which the other GPU tests pin to
-the oracle and the reference goldens.  The two must emit IDENTICAL record sets;
-values may differ in the last bits only where a different but equivalent
-exponential routine is used.  Also checks the run-time audit of the float32
-error bound `eps` and the K1 logic (float32 decision / exact probe / deep probe).
+"""The hot path of brutus_fit_batch (float32 proof pass + exact thresholds + float64 on the
+candidates, records written once where they are computed: csrc/fit2_kernels.hpp,
+csrc/fit_kernels.hpp) against INDEPENDENT evaluations of the same quantities:
+
+* the library's generic full-grid pipeline behind `loglike_batch` (residual-carrying
+  sweeps, every model in float64, ocml `exp10`) + the first cut on the host -- itself pinned
+  to the reference-generated goldens in tests/test_gpu_parity.py;
+* the C restatement of the reference (oracle/loglike_ref.c).
+
+Selected sets, K1 and K2 must be identical; values agree to 1e-9 (the two device paths
+use different but equivalent exponential routines and summation forms).  Also: the
+run-time audit of the float32 error bound `eps`, the K1 logic (float32 decision / exact
+probe / deep probe), record-buffer growth, and the bench's own launch geometry
+(128-star sub-batches on three engines / streams at once).
 """
-import ctypes as C
 import os
+import threading
 
 import numpy as np
 import pytest
 
+from helpers import relerr
+
 pytestmark = pytest.mark.gpu
+WT = 1e-3
 
 
 class _Env(object):
@@ -32,14 +42,55 @@ class _Env(object):
                 os.environ[k] = v
 
 
-def _both_paths(eng, st, params, with_par=True):
-    out = {}
-    par = st["parallax"] if with_par else None
-    perr = st["parallax_err"] if with_par else None
-    for path in (1, 2):
-        with _Env(BRUTUS_FIT_PATH=path, BRUTUS_AUDIT=1):
-            out[path] = eng.fit_batch(st["flux"], st["err"], st["mask"], par, perr, params)
-    return out
+def _first_cut(lnl, scale, icov00, par, perr):
+    """`lnpost`'s parallax clip + first cut (reference fitting.py:976-991) on full-grid
+    arrays -> selected model indices."""
+    from brutus_amd.pdf import scale_parallax_lnprior
+    with np.errstate(all="ignore"):
+        lnprob = lnl + scale_parallax_lnprior(scale, 1. / np.sqrt(np.abs(icov00)), par, perr)
+    lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+    return np.where(lnprob > np.log(WT) + lnprob.max())[0]
+
+
+def _params(kw):
+    from brutus_amd import fitting
+    return fitting._make_params(
+        kw.get("avlim", (0., 20.)), (0., 1e6), kw.get("rvlim", (1., 8.)),
+        kw.get("rv_gauss", (3.32, 0.18)), kw.get("ltol", 3e-2), 1e-2, 5e-3,
+        kw.get("dim_prior", True), wt_thresh=WT)
+
+
+def _vs_full_grid(grid, st, kw, with_par=True, tol=1e-9, audit_frac=0.25):
+    """Records of the hot path against `loglike_batch` + host first cut; returns the
+    records.  Runs with BRUTUS_AUDIT=1 and checks the float32 bound."""
+    from brutus_amd import fitting
+    S = st["flux"].shape[0]
+    par = st["parallax"] if with_par else np.full(S, np.nan)
+    perr = st["parallax_err"] if with_par else np.full(S, np.nan)
+    eng = fitting._Engine(grid, max_batch=S, mem_budget=200e9)
+    with _Env(BRUTUS_AUDIT=1):
+        recs = eng.fit_batch(st["flux"], st["err"], st["mask"], par, perr, _params(kw))
+    aud, eps = _audit(eng, grid.nmodel, grid.nfilt, S)
+    assert np.all(aud.max(axis=0) < audit_frac * eps), (aud.max(axis=0) / eps).max()
+    full = fitting.loglike_batch(
+        st["flux"], st["err"], st["mask"], grid, avlim=kw.get("avlim", (0., 20.)),
+        rvlim=kw.get("rvlim", (1., 8.)), rv_gauss=kw.get("rv_gauss", (3.32, 0.18)),
+        dim_prior=kw.get("dim_prior", True), ltol=kw.get("ltol", 3e-2), parallax=par,
+        parallax_err=perr, max_batch=min(S, 8))
+    for i, rec in enumerate(recs):
+        sel = _first_cut(full["lnl"][i], full["scale"][i], full["icov6"][0, i], par[i], perr[i])
+        assert rec["K1"] == full["k1"][i] and rec["K2"] == full["k2"][i], \
+            (kw, i, rec["K1"], full["k1"][i], rec["K2"], full["k2"][i])
+        assert np.array_equal(sel, rec["sel"]), (kw, i, sel.size, rec["sel"].size)
+        for k in ("lnl", "chi2", "scale", "rv"):
+            assert relerr(full[k][i][sel], rec["lnlike" if k == "lnl" else k]) < tol, (kw, i, k)
+        assert np.max(np.abs(full["av"][i][sel] - rec["av"])) < tol, (kw, i)
+        ic = full["icov6"][:, i, :][:, sel]
+        d = np.sqrt(np.abs(ic[[0, 3, 5]]))                  # sqrt of the diagonal
+        pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
+        for q, (a, b) in enumerate(pairs):
+            assert np.max(np.abs(rec["icov"][:, a, b] - ic[q]) / (d[a] * d[b])) < tol, (kw, i, q)
+    return recs
 
 
 def _audit(eng, nmodel, nfilt, S):
@@ -57,22 +108,10 @@ def _audit(eng, nmodel, nfilt, S):
     return aud.cpu().numpy(), s32[:, 4 * 32 + 9].cpu().numpy()
 
 
-def _assert_same(r1, r2, tag, exact=True):
-    for i, (a, b) in enumerate(zip(r1, r2)):
-        assert a["K1"] == b["K1"] and a["K2"] == b["K2"], (tag, i, a["K1"], b["K1"], a["K2"], b["K2"])
-        assert np.array_equal(a["sel"], b["sel"]), (tag, i, a["sel"].size, b["sel"].size)
-        for k in ("lnlike", "chi2", "scale", "av", "rv", "icov"):
-            if exact:
-                assert np.array_equal(a[k], b[k]), (tag, i, k)
-            else:
-                d = np.abs(a[k] - b[k]) / np.maximum(np.abs(a[k]), 1e-12)
-                assert d.max() < 1e-9, (tag, i, k, d.max())
-
-
 @pytest.mark.parametrize("kw", [dict(), dict(rvlim=(3.32, 3.32)), dict(ltol=3e-3),
                                 dict(dim_prior=False), dict(avlim=(0., 0.8))],
                          ids=["default", "rv_pinned", "ltol", "no_dim_prior", "avlim"])
-def test_paths_agree_small_grid_edge_cases(kw):
+def test_records_vs_full_grid_small_grid_edge_cases(kw):
     """30k x 8 lattice grid, 24 stars incl. a negative flux (large K2), masked
     bands, NaN parallaxes; K1 = 1, 2 and > 2 all occur."""
     from brutus_amd import fitting, synth
@@ -80,42 +119,24 @@ def test_paths_agree_small_grid_edge_cases(kw):
     st = synth.make_stars(models, 24, seed=21)
     st["flux"][3, 2] = -abs(st["flux"][3, 2])
     st["mask"][5, [1, 6]] = False
-    grid = fitting.DeviceGrid(models)
-    eng = fitting._Engine(grid, max_batch=24)
-    params = fitting._make_params(
-        kw.get("avlim", (0., 20.)), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
-        kw.get("ltol", 3e-2), 1e-2, 5e-3, kw.get("dim_prior", True), wt_thresh=1e-3)
-    r = _both_paths(eng, st, params)
-    # general-mode survivors: path 1 evaluates 10^x with the table-free polynomial in
-    # its flux kernel and so does path 2 (same kernel) -> identical bits everywhere
-    _assert_same(r[1], r[2], kw)
-    aud, eps = _audit(eng, 30000, 8, 24)
-    assert np.all(aud.max(axis=0) < 0.25 * eps), (aud.max(axis=0) / eps).max()
+    recs = _vs_full_grid(fitting.DeviceGrid(models), st, kw)
+    assert len({r["K1"] for r in recs}) > 1 or "rvlim" in kw
 
 
 @pytest.mark.parametrize("config", [2, 3])
-def test_paths_agree_full_size(config):
+def test_records_vs_full_grid_full_size(config):
     """BASELINE configs[1] / configs[2] at 750k x 12, the bench's grid and stars."""
     from brutus_amd import fitting, synth
     models, _, _ = synth.make_mist_like_grid(750000, 12)
-    S = 24
-    with_par = config == 3
-    st = synth.make_stars(models, S, seed=77 + config, with_parallax=with_par)
-    grid = fitting.DeviceGrid(models)
-    eng = fitting._Engine(grid, max_batch=S, mem_budget=100e9)
-    rvlim = (3.32, 3.32) if config == 2 else (1., 8.)
-    params = fitting._make_params((0., 20.), (0., 1e6), rvlim, (3.32, 0.18),
-                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
-    r = _both_paths(eng, st, params, with_par)
-    _assert_same(r[1], r[2], config)
-    aud, eps = _audit(eng, 750000, 12, S)
-    assert np.all(aud.max(axis=0) < 0.25 * eps), (aud.max(axis=0) / eps).max()
+    st = synth.make_stars(models, 24, seed=77 + config, with_parallax=config == 3)
+    kw = dict(rvlim=(3.32, 3.32)) if config == 2 else dict()
+    _vs_full_grid(fitting.DeviceGrid(models), st, kw, with_par=config == 3)
 
 
 def test_high_signal_to_noise_and_sharp_posteriors():
     """float32 is weakest at high S/N (the chi2 cancels against sum (S/N)^2): stars
     with 0.2 % photometry and precise parallaxes -> eps grows with them, the record
-    sets stay identical and the audit stays inside eps."""
+    sets stay exact and the audit stays inside eps."""
     from brutus_amd import fitting, synth
     models, _, _ = synth.make_mist_like_grid(200000, 12, seed=5)
     S = 16
@@ -124,14 +145,9 @@ def test_high_signal_to_noise_and_sharp_posteriors():
     st["parallax_err"] = np.where(np.isfinite(st["parallax_err"]),
                                   np.minimum(st["parallax_err"], 0.02), np.nan)
     grid = fitting.DeviceGrid(models)
-    eng = fitting._Engine(grid, max_batch=S)
     for rvlim in ((1., 8.), (3.32, 3.32)):
-        params = fitting._make_params((0., 20.), (0., 1e6), rvlim, (3.32, 0.18),
-                                      3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
-        r = _both_paths(eng, st, params)
-        _assert_same(r[1], r[2], rvlim)
-        aud, eps = _audit(eng, 200000, 12, S)
-        assert np.all(aud.max(axis=0) < 0.5 * eps), (aud.max(axis=0) / eps).max()
+        # (chi2 ~ 1e5 at this S/N: values compared relative to their size)
+        _vs_full_grid(grid, st, dict(rvlim=rvlim), tol=1e-8, audit_frac=0.5)
 
 
 def test_random_order_grid_and_tiny_shapes():
@@ -141,12 +157,8 @@ def test_random_order_grid_and_tiny_shapes():
         models, _, _ = synth.make_grid(nmodel, nfilt, seed=nmodel)
         st = synth.make_stars(models, nstar, seed=nmodel + 1)
         grid = fitting.DeviceGrid(models)
-        eng = fitting._Engine(grid, max_batch=nstar)
         for rvlim in ((1., 8.), (3.32, 3.32)):
-            params = fitting._make_params((0., 20.), (0., 1e6), rvlim, (3.32, 0.18),
-                                          3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
-            r = _both_paths(eng, st, params)
-            _assert_same(r[1], r[2], (nmodel, nfilt, rvlim))
+            _vs_full_grid(grid, st, dict(rvlim=rvlim), audit_frac=1.0)
 
 
 def test_many_sweeps_star_is_not_an_error():
@@ -155,60 +167,147 @@ def test_many_sweeps_star_is_not_an_error():
     the C oracle's, records equal the oracle's (reference fitting.py:173-264 has no
     sweep cap)."""
     from brutus_amd import fitting, synth
-    from brutus_amd.pdf import scale_parallax_lnprior
     from oracle import c_oracle
     models, _, _ = synth.make_mist_like_grid(40000, 12, seed=8)
     st = synth.make_stars(models, 6, seed=31)
     kw = dict(rv_gauss=(3.32, 5.), ltol=3e-3)
     grid = fitting.DeviceGrid(models)
     eng = fitting._Engine(grid, max_batch=6)
-    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), kw["rv_gauss"],
-                                  kw["ltol"], 1e-2, 5e-3, True, wt_thresh=1e-3)
+    recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
+                         st["parallax_err"], _params(kw))
     k1s = []
-    for path in (1, 2):
-        with _Env(BRUTUS_FIT_PATH=path):
-            recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
-                                 st["parallax_err"], params)
-        for i, rec in enumerate(recs):
-            tr = {}
-            lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
-                st["flux"][i], st["err"][i], st["mask"][i], models, parallax=st["parallax"][i],
-                parallax_err=st["parallax_err"][i], trace=tr, **kw)
-            with np.errstate(all="ignore"):
-                lnprob = lnl + scale_parallax_lnprior(
-                    sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), st["parallax"][i],
-                    st["parallax_err"][i])
-            lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
-            sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
-            assert rec["K1"] == tr["K1"] and rec["K2"] == tr["K2"], (path, i, rec["K1"], tr["K1"])
-            assert np.array_equal(sel, rec["sel"]), (path, i)
-            assert np.max(np.abs(lnl[sel] - rec["lnlike"])) < 1e-7
-            k1s.append(tr["K1"])
+    for i, rec in enumerate(recs):
+        tr = {}
+        lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+            st["flux"][i], st["err"][i], st["mask"][i], models, parallax=st["parallax"][i],
+            parallax_err=st["parallax_err"][i], trace=tr, **kw)
+        sel = _first_cut(lnl, sc, icov[:, 0, 0], st["parallax"][i], st["parallax_err"][i])
+        assert rec["K1"] == tr["K1"] and rec["K2"] == tr["K2"], (i, rec["K1"], tr["K1"])
+        assert np.array_equal(sel, rec["sel"]), i
+        assert np.max(np.abs(lnl[sel] - rec["lnlike"])) < 1e-7
+        k1s.append(tr["K1"])
     assert max(k1s) > 8, k1s      # the case the old 8-sweep cap rejected
 
 
-def test_record_buffer_regrowth_replays_select_and_emit():
-    """Record buffers too small for a batch: `records_device` grows them and
-    `brutus_fit_gather` replays selection + emit from the workspace (survivor tags in the
-    float32 plane, staged flux-phase results, candidate offsets) without redoing the scan;
-    the records equal those of a run whose buffers were large enough from the start."""
-    import torch
-    from brutus_amd import fitting, synth
+def test_record_buffer_growth():
+    """Record buffers too small for a batch -- below the candidate slots, then below
+    candidates + derived records: `fit_batch_device` reports BRUTUS_ENOMEM with the sizes it
+    needs, the engine grows the buffers and repeats the batch; the records equal those of a
+    run whose buffers were large enough from the start, and the next batch needs no growth."""
+    from brutus_amd import _lib, fitting, synth
     models, _, _ = synth.make_mist_like_grid(60000, 12, seed=4)
     st = synth.make_stars(models, 12, seed=5)
     grid = fitting.DeviceGrid(models)
-    params = fitting._make_params((0., 20.), (0., 1e6), (1., 8.), (3.32, 0.18),
-                                  3e-2, 1e-2, 5e-3, True, wt_thresh=1e-3)
+    params = _params({})
     ref = fitting._Engine(grid, max_batch=12).fit_batch(
         st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"], params)
+    nsel = sum(len(r["sel"]) for r in ref)
     eng = fitting._Engine(grid, max_batch=12)
     up = eng._upload(st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"])
-    eng._sel_bufs = (torch.empty(1000, dtype=torch.int32, device=grid.device),
-                     torch.empty((11, 1000), dtype=torch.float64, device=grid.device))
-    sel_idx, sel_vals, sel_off, off, ndim, k1, k2 = eng.records_device(*up, params)
-    assert sel_idx.numel() > 1000 and int(off[-1]) == sum(len(r["sel"]) for r in ref)
-    for s, r in enumerate(ref):
-        got = eng.record_of(sel_idx, sel_vals, off, s, ndim[s], k1[s], k2[s])
-        assert np.array_equal(got["sel"], r["sel"]), s
-        for k in ("lnlike", "chi2", "scale", "av", "rv", "icov"):
-            assert np.array_equal(got[k], r[k]), (s, k)
+    for cap0 in (1000, None):
+        if cap0 is not None:
+            eng._rec_bufs = eng._record_buffers(cap0)
+        else:
+            # exactly the candidate slots: the flux phase fits, the derived records do not
+            eng._rec_bufs = eng._record_buffers(int(rec.counts[1]))
+        eng.regrown = 0
+        with pytest.raises(_lib.BrutusError):
+            eng.fit_batch_device(*up, params, grow=False)
+        rec, off, ndim, k1, k2 = eng.records_device(*up, params)
+        assert eng.regrown >= 1 and rec.capacity >= rec.counts[2] > rec.counts[1]
+        assert int(off[-1]) == nsel == rec.counts[0]
+        for s, r in enumerate(ref):
+            got = eng.record_of(rec, off, s, ndim[s], k1[s], k2[s])
+            assert np.array_equal(got["sel"], r["sel"]), s
+            for k in ("lnlike", "chi2", "scale", "av", "rv", "icov"):
+                assert np.array_equal(got[k], r[k]), (s, k)
+        n = eng.regrown
+        eng.records_device(*up, params)
+        assert eng.regrown == n
+
+
+@pytest.mark.parametrize("config", [2, 3])
+def test_bench_geometry_three_streams_vs_single_stream_and_c_oracle(config):
+    """bench.py's own launch geometry: 750k x 12, 128-star sub-batches, THREE engines on
+    three HIP streams driven by three host threads at once (bench.py `run_config`).  All
+    3 x 128 record sets must be bit-equal to a single-stream run of the same sub-batches,
+    and 8 randomly chosen stars must match the C oracle (K1 / K2, selected set, values)."""
+    import torch
+    from brutus_amd import fitting, synth
+    from oracle import c_oracle
+    models, _, _ = synth.make_mist_like_grid(750000, 12)
+    with_par = config == 3
+    SB, NS = 128, 3
+    st = synth.make_stars(models, NS * SB, seed=config, with_parallax=with_par)
+    kw = dict(rvlim=(3.32, 3.32)) if config == 2 else dict()
+    params = _params(kw)
+    grid = fitting.DeviceGrid(models)
+    dev = grid.device
+    engines = [fitting._Engine(grid, max_batch=SB, mem_budget=64e9) for _ in range(NS)]
+    subs = []
+    for j in range(NS):
+        sl = slice(j * SB, (j + 1) * SB)
+        subs.append(engines[0]._upload(st["flux"][sl], st["err"][sl], st["mask"][sl],
+                                       st["parallax"][sl] if with_par else None,
+                                       st["parallax_err"][sl] if with_par else None))
+    cap = int(SB * 750000 * 0.62)
+    bufs = [engines[j]._record_buffers(cap) for j in range(NS)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
+    outs = [None] * NS
+
+    def snap(rec, ndim, k1, k2):
+        """Device-side snapshot of a call's records in record order (the buffers are
+        reused by the next call)."""
+        total = int(rec.counts[0])
+        vals = rec.vals.index_select(1, rec.slot[:total].long())
+        if rec.rv_const is not None:
+            vals[4] = rec.rv_const
+        return (rec.idx[:total].clone(), vals, rec.off.clone(), ndim.clone(),
+                torch.from_numpy(k1.copy()), torch.from_numpy(k2.copy()))
+
+    def worker(j):
+        torch.cuda.set_device(dev)
+        with torch.cuda.stream(streams[j]):
+            for rep in range(2):          # twice: the second pass runs against warm buffers
+                o = engines[j].fit_batch_device(*subs[j], params, buffers=bufs[j], grow=False)
+            outs[j] = snap(*o)
+            streams[j].synchronize()
+
+    th = [threading.Thread(target=worker, args=(j,)) for j in range(NS)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert all(o is not None for o in outs)
+    torch.cuda.synchronize()
+    # the same sub-batches one after the other on one engine / the default stream
+    for j in range(NS):
+        one = snap(*engines[0].fit_batch_device(*subs[j], params, buffers=bufs[0], grow=False))
+        for a, b, name in zip(outs[j], one, ("idx", "vals", "off", "ndim", "k1", "k2")):
+            assert torch.equal(a, b), (config, j, name)
+        del one
+    rng = np.random.RandomState(100 + config)
+    for g in rng.choice(NS * SB, size=8, replace=False):
+        j, s = divmod(int(g), SB)
+        off = outs[j][2].cpu().numpy()
+        a, b = int(off[s]), int(off[s + 1])
+        idx = outs[j][0][a:b].cpu().numpy()
+        vals = outs[j][1][:, a:b].cpu().numpy()
+        ndim, k1, k2 = (outs[j][q].cpu().numpy() for q in (3, 4, 5))
+        par = st["parallax"][g] if with_par else np.nan
+        perr = st["parallax_err"][g] if with_par else np.nan
+        tr = {}
+        lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+            st["flux"][g], st["err"][g], st["mask"][g], models, parallax=par,
+            parallax_err=perr, trace=tr, **kw)
+        sel = _first_cut(lnl, sc, icov[:, 0, 0], par, perr)
+        assert k1[s] == tr["K1"] and k2[s] == tr["K2"] and ndim[s] == nd, (config, g)
+        assert np.array_equal(sel, idx), (config, g, sel.size, b - a)
+        assert relerr(lnl[sel], vals[0]) < 1e-8
+        assert relerr(chi2[sel], vals[1]) < 1e-8
+        assert relerr(sc[sel], vals[2]) < 1e-8
+        assert np.max(np.abs(av[sel] - vals[3])) < 1e-8
+        assert relerr(rv[sel], vals[4]) < 1e-8
+        d = np.sqrt(np.abs(np.einsum('nii->ni', icov[sel])))
+        for q, (x, y) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
+            assert np.max(np.abs(vals[5 + q] - icov[sel][:, x, y]) / (d[:, x] * d[:, y])) < 1e-8

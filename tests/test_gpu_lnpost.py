@@ -365,9 +365,18 @@ def test_device_psd_repair_on_crafted_records():
     for k, (a, b) in enumerate(((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))):
         vals[5 + k] = ic[:, a, b]
     up = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dtype=dt)
-    sel_idx = up(np.arange(n), torch.int32)
-    sel_vals = up(vals, torch.float64)
-    sel_off = up(np.array([0, n]), torch.int64)
+    # indexed records (include/brutus_amd.h): the values sit in shuffled columns of a
+    # buffer that also holds columns no record refers to
+    cap = n + 37
+    slot = np.random.RandomState(3).permutation(cap)[:n]
+    spread = np.full((_lib.NVALS, cap), np.nan)
+    spread[:, slot] = vals
+    idx_pad = np.zeros(cap, dtype=np.int64)
+    idx_pad[:n] = np.arange(n)
+    slot_pad = np.zeros(cap, dtype=np.int64)
+    slot_pad[:n] = slot
+    rec = fitting.Records(up(idx_pad, torch.int32), up(slot_pad, torch.int32),
+                          up(spread, torch.float64), up(np.array([0, n]), torch.int64))
     statics = (up(z["lnprior"], torch.float64), up(lab['feh'], torch.float64),
                up(lab['loga'], torch.float64))
     pp = _lib.PostParams()
@@ -385,7 +394,7 @@ def test_device_psd_repair_on_crafted_records():
         else:
             setattr(pp, k, val)
     out_idx, out_vals, star_out, flags, nbase = eng.post_batch_device(
-        sel_idx, sel_vals, sel_off, 1, statics, coord, par, perr, pp)
+        rec, 1, statics, coord, par, perr, pp)
     res = (z["lnl"].copy(), 8, z["chi2"].copy(), z["scale"].copy(), z["av"].copy(),
            z["rv"].copy(), z["icov"].copy())
     ref = O.finish_star(res, z["lnprior"].copy(), lab, coord[0], par[0], perr[0],

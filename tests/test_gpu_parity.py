@@ -642,26 +642,29 @@ def test_cabi_error_codes():
                                      st["parallax"], st["parallax_err"])
     ws = eng._workspace(2)
     idx = torch.empty(16, dtype=torch.int32, device="cuda")
+    slot = torch.empty(16, dtype=torch.int32, device="cuda")
     vals = torch.empty((11, 16), dtype=torch.float64, device="cuda")
     off = torch.empty(3, dtype=torch.int64, device="cuda")
     ndim = torch.empty(2, dtype=torch.int32, device="cuda")
+    counts = np.zeros(3, dtype=np.int64)
     args = lambda wsn, ns: (grid.soa.data_ptr(), grid.nmodel, grid.nfilt, ns,
                             f.data_ptr(), e.data_ptr(), m.data_ptr(), p.data_ptr(),
                             pe.data_ptr(), hp, params, ws.data_ptr(), wsn, 16,
-                            idx.data_ptr(), vals.data_ptr(), off.data_ptr(),
-                            ndim.data_ptr(), None, None, None)
+                            idx.data_ptr(), slot.data_ptr(), vals.data_ptr(), off.data_ptr(),
+                            ndim.data_ptr(), None, None, counts.ctypes.data, None)
     assert L.brutus_fit_batch(*args(1024, 2)) == -2          # BRUTUS_ENOMEM
     assert b"workspace" in L.brutus_last_error()
     assert L.brutus_fit_batch(*args(ws.numel(), 0)) == -1    # BRUTUS_EINVAL
     assert L.brutus_fit_batch(*args(ws.numel(), 1000)) == -1
-    # capacity smaller than the selection: records are dropped, totals stay true
-    assert L.brutus_fit_batch(*args(ws.numel(), 2)) == 0
-    total = int(off.cpu()[-1])
-    assert total > 16
+    # record buffers smaller than the batch needs: BRUTUS_ENOMEM, nothing written out of
+    # bounds, and the sizes to come back with
+    assert L.brutus_fit_batch(*args(ws.numel(), 2)) == -2
+    assert b"record buffer too small" in L.brutus_last_error()
+    assert counts[1] > 16 and counts[2] >= counts[1]
     recs = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"],
                          st["parallax_err"], params)
-    assert sum(len(r["sel"]) for r in recs) == total
-    assert np.array_equal(idx.cpu().numpy(), recs[0]["sel"][:16].astype(np.int32))
+    rb = eng._rec_bufs[0].numel()
+    assert sum(len(r["sel"]) for r in recs) <= rb and eng.regrown == 0
 
 
 def test_device_exp_and_log_accuracy():

@@ -31,10 +31,8 @@ eng = fitting._Engine(grid, max_batch=B, mem_budget=64e9)
 up = eng._upload(st["flux"], st["err"], st["mask"],
                  st["parallax"] if config == 3 else None,
                  st["parallax_err"] if config == 3 else None)
-cap = max(32 << 20, B * 600000)
-bufs = (torch.empty(cap, dtype=torch.int32, device=dev),
-        torch.empty((_lib.NVALS, cap), dtype=torch.float64, device=dev))
+bufs = eng._record_buffers(max(32 << 20, int(B * 750000 * 0.62)))
 for _ in range(3):
-    eng.fit_batch_device(*up, params, sel_buffers=bufs)
+    eng.fit_batch_device(*up, params, buffers=bufs, grow=False)
 torch.cuda.synchronize()
 print("pmc workload done: calibration n=%d (read %d B, write %d B), batch %d" % (n, 4 * n, 8 * n, B))

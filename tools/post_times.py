@@ -44,11 +44,9 @@ def main():
     counts = {}
     orig = fitting._Engine.post_batch_device
 
-    def counted(self, sel_idx, sel_vals, sel_off, nstar, statics, coords, parallax,
-                parallax_err, pp, **kw2):
-        out = orig(self, sel_idx, sel_vals, sel_off, nstar, statics, coords, parallax,
-                   parallax_err, pp, **kw2)
-        counts["first_cut"] = int(sel_off.cpu().numpy()[nstar])
+    def counted(self, rec, nstar, statics, coords, parallax, parallax_err, pp, **kw2):
+        out = orig(self, rec, nstar, statics, coords, parallax, parallax_err, pp, **kw2)
+        counts["first_cut"] = int(rec.off.cpu().numpy()[nstar])
         counts["second_cut"] = int(out[4][nstar] - out[4][0]) // (3 * pp.nmc)
         return out
 
