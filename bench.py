@@ -172,6 +172,15 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     return res
 
 
+def traffic_commit():
+    """Commit the PMC table under profiles/ was measured on (None if not recorded)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f).get("commit")
+    except (IOError, ValueError):
+        return None
+
+
 def measured_traffic(kernel, batch, config):
     """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes kept under
     profiles/ (FETCH_SIZE and WRITE_SIZE in separate runs, corrected with the
@@ -504,6 +513,9 @@ def roofline_of(res, args, config, world):
             # PMC bytes of every kernel of one sub-batch call, scaled to one step
             rl["traffic"] = traffic * (float(args.batch) / SB)
             rl["traffic_over_algorithmic"] = traffic / (SB * g)
+            rl["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
+                                    "passes of tools/pmc_workload.py, not measured in this run")
+            rl["traffic_from_commit"] = traffic_commit()
     return rl
 
 

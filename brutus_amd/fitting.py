@@ -180,6 +180,7 @@ class _Engine(object):
         self.batch = nb
         self._ws = None
         self._ws_batch = 0
+        self.regrown = 0       # record-buffer growths (each repeats a batch)
 
     def _workspace(self, nstar):
         torch = self.torch

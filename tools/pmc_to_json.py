@@ -11,7 +11,9 @@ brutus_fit_batch calls of the workload (3), i.e. one row = HBM bytes that kernel
 moves per call (several launches for k_top / k_fflux / k_offsets ...).  The row
 "__total__" is the sum over all kernels: the real traffic of one call.
 
-usage: pmc_to_json.py fetch.db write.db config batch calib_n [out.json] [ncalls]
+usage: PMC_COMMIT=<hash> pmc_to_json.py fetch.db write.db config batch calib_n [out.json] [ncalls]
+(the commit the table was measured on travels with it: bench.py echoes it as
+roofline.traffic_from_commit, so a table that has gone stale is visible)
 """
 import json
 import os
@@ -68,7 +70,8 @@ def main():
     rows.append({"kernel": "__total__", "config": config, "batch": batch,
                  "read_bytes_per_launch": round(trd), "write_bytes_per_launch": round(twr),
                  "hbm_bytes_per_launch": round(trd + twr)})
-    json.dump({"source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
+    json.dump({"commit": os.environ.get("PMC_COMMIT", "unknown"),
+               "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                          "tools/pmc_workload.py; counters in KiB, corrected with k_calib_stream; bytes per brutus_fit_batch call",
                "fetch_correction": f_fac, "write_correction": w_fac, "rows": rows},
               open(out, "w"), indent=1)

@@ -1,11 +1,12 @@
 #!/bin/bash
 # One profiling pass on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag> [batch]     e.g. tools/profile_round.sh r01_v4 128
+#   tools/profile_round.sh <tag> [batch] [commit]     e.g. tools/profile_round.sh r01_v4 128 $(git rev-parse --short HEAD)
 # kernel trace of the bench (configs[1] and [2], one stream), PMC FETCH_SIZE / WRITE_SIZE passes for
 # configs[1] and configs[2] (separate runs, kernel-trace only), summaries into
 # gpurun_out/<tag>_*.txt; raw databases stay in gpurun_out/.
 tag=${1:-prof}
 B=${2:-128}
+export PMC_COMMIT=${3:-unknown}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out
 mkdir -p $O
