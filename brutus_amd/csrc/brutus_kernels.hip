@@ -41,6 +41,7 @@
 
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -340,11 +341,13 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
                       int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
                       hipStream_t st, Timer &tm) {
     switch (nb) {
-        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
         case 12: return run_pipeline<12>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+#ifndef BRUTUS_DEV_NB12_ONLY      // (tools/ab/build.sh: kernel A/B builds in seconds; never set for the product)
+        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
         case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
         case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
         case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+#endif
     }
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
@@ -362,19 +365,21 @@ double env_double(const char *name, double dflt) {
     return v && *v ? atof(v) : dflt;
 }
 
+// nact == 0: the opening launch (all stars); else a continuation over the `nact` stars listed
+// in w.ids (device) that are still iterating.
 template <int NB, bool RVF>
-void launch_fflux(hipStream_t st, int first, const float *grid, int64_t nmodel, int64_t nmodel_pad,
+void launch_fflux(hipStream_t st, int nact, const float *grid, int64_t nmodel, int64_t nmodel_pad,
                   int nstar, const DevParams &p, const Workspace &w, const RecPlanes &rec) {
-    if (first)
+    if (nact == 0)
         hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
                            nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx, w.surv_off,
                            w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part, w.lnpr32,
-                           w.thr_cull);
+                           w.thr_cull, (const int32_t *)nullptr, 0);
     else
-        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
-                           nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx, w.surv_off,
-                           w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part, w.lnpr32,
-                           w.thr_cull);
+        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(NCHUNK * nact * CONT_P), dim3(TILE), 0, st,
+                           grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx,
+                           w.surv_off, w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part,
+                           w.lnpr32, w.thr_cull, w.ids, nact);
 }
 
 // Exact K1 of the stars in `ids` by probing KS = 8 sweeps in float64 (k1 = 0: more needed).
@@ -539,14 +544,16 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     hipLaunchKernelGGL(k_set_i32, dim3((nstar + 255) / 256), dim3(256), 0, st, w.k2, nstar, 2);
     int32_t h_unconv = 0;
     int iter = 2;
+    std::vector<int32_t> k2s(nstar), act;
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
-        launch_fflux<NB, RVF>(st, first, grid, nmodel, nmodel_pad, nstar, p, w, rec);
+        launch_fflux<NB, RVF>(st, (int)act.size(), grid, nmodel, nmodel_pad, nstar, p, w, rec);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
                            p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
         HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(k2s.data(), w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         if (first && h_ncand > capacity) {
             // the flux phase keeps its results in the record planes: nothing to go on with
@@ -560,6 +567,10 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
             return fail(BRUTUS_ENOCONV, "flux phase not converged after %d iterations for %d star(s)",
                         iter, h_unconv);
         ++iter;
+        act.clear();                 // the stars still iterating: the next launch walks their segments only
+        for (int s = 0; s < nstar; ++s)
+            if (k2s[s] >= 0) act.push_back(s);
+        HIP_TRY(hipMemcpyAsync(w.ids, act.data(), sizeof(int32_t) * act.size(), hipMemcpyHostToDevice, st));
     }
 
     // ---- exact first-cut threshold, selection masks ---------------------------------------
@@ -983,11 +994,13 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
                                        d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,   \
                                        h_counts, st, tm);
     switch (nb) {
-        BRUTUS_CASE(8)
         BRUTUS_CASE(12)
+#ifndef BRUTUS_DEV_NB12_ONLY
+        BRUTUS_CASE(8)
         BRUTUS_CASE(16)
         BRUTUS_CASE(24)
         BRUTUS_CASE(32)
+#endif
     }
 #undef BRUTUS_CASE
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
@@ -1163,11 +1176,13 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                            pm, ps);                                                               \
         break;
     switch (nb) {
-        BRUTUS_CL(8)
         BRUTUS_CL(12)
+#ifndef BRUTUS_DEV_NB12_ONLY
+        BRUTUS_CL(8)
         BRUTUS_CL(16)
         BRUTUS_CL(24)
         BRUTUS_CL(32)
+#endif
     }
 #undef BRUTUS_CL
     tm.end();
