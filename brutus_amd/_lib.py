@@ -57,7 +57,8 @@ class PostParams(C.Structure):
                 ("f_halo", C.c_double), ("feh_mean", C.c_double * 3),
                 ("feh_sigma", C.c_double * 3), ("age_mean", C.c_double * 3),
                 ("age_sigma", C.c_double * 3), ("age_lnnorm", C.c_double * 3),
-                ("min_age", C.c_double), ("max_age", C.c_double)]
+                ("min_age", C.c_double), ("max_age", C.c_double),
+                ("frame_mat", C.c_double * 9), ("frame_off", C.c_double * 3)]
 
 
 # name -> (restype, argtypes); mirrors include/brutus_amd.h (product ABI) and
@@ -73,7 +74,7 @@ SIGNATURES = {
     "brutus_loglike_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp,
                                        _vp, _i32, C.POINTER(Params), _vp, _sz,
                                        _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp,
-                                       _vp, _vp]),
+                                       _vp, _vp, _vp, _vp]),
     "brutus_fit_batch": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp,
                                    _i32, C.POINTER(Params), _vp, _sz, _i64, _vp, _vp,
                                    _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -258,12 +258,13 @@ struct Timer {
 struct Workspace;
 template <int NB>
 int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &p, int max_iter,
-                  Workspace &w, int32_t *k1_out, hipStream_t st);
+                  Workspace &w, int32_t *k1_out, hipStream_t st, const double *av_init = nullptr,
+                  const double *rv_init = nullptr);
 
 template <int NB>
 int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &p,
                  int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
-                 hipStream_t st, Timer &tm) {
+                 hipStream_t st, Timer &tm, const double *av_init, const double *rv_init) {
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     const dim3 gridA(ntile, (nstar + STAR_GROUP - 1) / STAR_GROUP);
@@ -276,7 +277,7 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin("k_mag_stats");
         hipLaunchKernelGGL(k_mag_stats<NB>, gridA, blk, 0, st, grid, nmodel, nmodel_pad, nstar,
-                           w.stars, p, kmax, w.part);
+                           w.stars, p, kmax, w.part, av_init, rv_init);
         tm.end();
         hipLaunchKernelGGL(k_reduce_decide, dim3(nstar), dim3(256), 0, st, 0, ntile, nstar,
                            2 * kmax, w.part, p.ln_init, (double *)nullptr, w.k1, w.n_unconv);
@@ -292,7 +293,8 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
             HIP_TRY(hipStreamSynchronize(st));
             for (int s = 0; s < nstar; ++s)
                 if (hk[s] == 0)
-                    if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &hk[s], st)) return rc;
+                    if (int rc = probe_k1_deep<NB>(grid, nmodel, s, p, max_iter, w, &hk[s], st, av_init, rv_init))
+                        return rc;
             break;
         }
         kmax = kmax * 2 > KCAP ? KCAP : kmax * 2;
@@ -301,7 +303,7 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
     // ---- phase 2: MLE at the converged (Av, Rv); cull statistic -------------
     tm.begin("k_mag_mle");
     hipLaunchKernelGGL(k_mag_mle<NB>, gridA, blk, 0, st, grid, nmodel, nmodel_pad, nstar, w.stars,
-                       p, w.k1, w.pl, w.part);
+                       p, w.k1, w.pl, w.part, av_init, rv_init);
     tm.end();
     hipLaunchKernelGGL(k_reduce_decide, dim3(nstar), dim3(256), 0, st, 1, ntile, nstar, 1, w.part,
                        0.0, w.vmax_lnlp, (int32_t *)nullptr, (int32_t *)nullptr);
@@ -339,14 +341,14 @@ int run_pipeline(const float *grid, int64_t nmodel, int nstar, const DevParams &
 
 int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, const DevParams &p,
                       int max_iter, Workspace &w, int32_t *h_k1, int32_t *h_k2,
-                      hipStream_t st, Timer &tm) {
+                      hipStream_t st, Timer &tm, const double *av_init, const double *rv_init) {
     switch (nb) {
-        case 12: return run_pipeline<12>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 12: return run_pipeline<12>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
 #ifndef BRUTUS_DEV_NB12_ONLY      // (tools/ab/build.sh: kernel A/B builds in seconds; never set for the product)
-        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
-        case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
-        case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
-        case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm);
+        case 8: return run_pipeline<8>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
+        case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
+        case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
+        case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
 #endif
     }
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
@@ -406,7 +408,8 @@ int launch_k1probe(const float *grid, int64_t nmodel, int nstar, const std::vect
 // with the residual-carrying kernels (no cap but max_iter; fitting.py:173-264).
 template <int NB>
 int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &p, int max_iter,
-                  Workspace &w, int32_t *k1_out, hipStream_t st) {
+                  Workspace &w, int32_t *k1_out, hipStream_t st, const double *av_init,
+                  const double *rv_init) {
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     HIP_TRY(hipMemcpyAsync(w.stars_tmp, w.stars + star, sizeof(StarPrep), hipMemcpyDeviceToDevice, st));
@@ -415,7 +418,7 @@ int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &
         if (kmax > max_iter) kmax = max_iter;
         if (kmax > cap) kmax = cap;
         hipLaunchKernelGGL(k_mag_stats<NB>, dim3(ntile, 1), dim3(TILE), 0, st, grid, nmodel,
-                           nmodel_pad, 1, w.stars_tmp, p, kmax, w.part);
+                           nmodel_pad, 1, w.stars_tmp, p, kmax, w.part, av_init, rv_init);
         hipLaunchKernelGGL(k_k1_deep_decide, dim3(1), dim3(256), 0, st, ntile, kmax, w.part,
                            p.ln_init, w.k1 + star);
         HIP_TRY(hipMemcpyAsync(k1_out, w.k1 + star, sizeof(int32_t), hipMemcpyDeviceToHost, st));
@@ -1073,7 +1076,7 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int
                          const brutus_params *params, void *d_workspace, size_t workspace_bytes,
                          double *d_lnl, double *d_chi2, double *d_scale, double *d_av, double *d_rv,
                          double *d_icov, int32_t *d_ndim, int32_t *h_k1, int32_t *h_k2,
-                         void *stream) {
+                         const double *d_av_init, const double *d_rv_init, void *stream) {
     if (int rc = check_common(nmodel, nfilt, nstar)) return rc;
     DevParams p;
     if (int rc = make_params(params, p)) return rc;
@@ -1097,7 +1100,7 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int
         return rc;
     const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
     int rc = dispatch_pipeline(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, max_iter, w, h_k1,
-                               h_k2, st, tm);
+                               h_k2, st, tm, d_av_init, d_rv_init);
     if (rc) return rc;
     HIP_TRY(hipStreamSynchronize(st));
     fix_k2(h_k2, nstar);
@@ -1479,7 +1482,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
     DustCtx dc = g_dust;                 // one-shot: set by brutus_post_set_dust on this thread
     g_dust = DustCtx{};
     if (dc.d_los && (dc.nd < 2 || dc.nd > 4096)) return fail(BRUTUS_EINVAL, "bad dust table");
-    hipLaunchKernelGGL(k_post_geom, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, d_coords,
+    hipLaunchKernelGGL(k_post_geom, dim3((nstar + 63) / 64), dim3(64), 0, st, pp, nstar, d_coords,
                        d_parallax, d_parallax_err, dc, w.geom);
     tm.begin("k_post_lnp1");
     hipLaunchKernelGGL(k_post_lnp1, g2, blk, 0, st, pp, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,

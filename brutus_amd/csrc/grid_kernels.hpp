@@ -16,9 +16,10 @@ struct MagState {
 
 template <int NB>
 __device__ __forceinline__ void mag_init(const Coef<NB> &c, const StarPrep &sp,
-                                         const DevParams &p, MagState<NB> &st) {
-    st.av = p.av_mean;   // fitting.py:700-703
-    st.rv = p.rv_mean;
+                                         const DevParams &p, double av0, double rv0,
+                                         MagState<NB> &st) {
+    st.av = av0;         // fitting.py:697-703: av_init / rv_init, by default the prior means
+    st.rv = rv0;
     double P = 0., Q = 0.;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
@@ -284,19 +285,23 @@ template <int NB>
 __global__ void __launch_bounds__(TILE)
 k_mag_stats(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
             const StarPrep *__restrict__ stars, DevParams p, int kmax,
-            double *__restrict__ part) {
+            double *__restrict__ part, const double *__restrict__ av_init,
+            const double *__restrict__ rv_init) {
     __shared__ double slot[4];
     const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
     const bool live = i < nmodel;
     Coef<NB> c;
     load_coef<NB>(grid, nmodel_pad, i, c);
+    // per-model starting point (the `av_init` / `rv_init` arrays of fitting.py:697-703)
+    const double av0 = av_init ? av_init[live ? i : nmodel - 1] : p.av_mean;
+    const double rv0 = rv_init ? rv_init[live ? i : nmodel - 1] : p.rv_mean;
     const int s0 = blockIdx.y * STAR_GROUP;
     const int s1 = min(nstar, s0 + STAR_GROUP);
     const double ninf = -INFINITY;
     for (int s = s0; s < s1; ++s) {
         const StarPrep &sp = stars[s];
         MagState<NB> st;
-        mag_init<NB>(c, sp, p, st);
+        mag_init<NB>(c, sp, p, av0, rv0, st);
         double *out = part + ((int64_t)blockIdx.x * nstar + s) * (2 * kmax);
         for (int k = 0; k < kmax; ++k) {
             mag_sweep<NB>(c, sp, p, st);
@@ -371,12 +376,15 @@ template <int NB>
 __global__ void __launch_bounds__(TILE)
 k_mag_mle(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
           const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
-          Planes pl, double *__restrict__ part) {
+          Planes pl, double *__restrict__ part, const double *__restrict__ av_init,
+          const double *__restrict__ rv_init) {
     __shared__ double slot[4];
     const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
     const bool live = i < nmodel;
     Coef<NB> c;
     load_coef<NB>(grid, nmodel_pad, i, c);
+    const double av0 = av_init ? av_init[live ? i : nmodel - 1] : p.av_mean;
+    const double rv0 = rv_init ? rv_init[live ? i : nmodel - 1] : p.rv_mean;
     double F0[NB];
     compute_F0<NB>(c, F0);
     const int s0 = blockIdx.y * STAR_GROUP;
@@ -384,7 +392,7 @@ k_mag_mle(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, in
     for (int s = s0; s < s1; ++s) {
         const StarPrep &sp = stars[s];
         MagState<NB> st;
-        mag_init<NB>(c, sp, p, st);
+        mag_init<NB>(c, sp, p, av0, rv0, st);
         const int K = k1[s];
         for (int k = 0; k < K; ++k) mag_sweep<NB>(c, sp, p, st);
         Mle m;

@@ -97,6 +97,7 @@ struct PostParams {     // mirrors brutus_post_params
     double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
     double feh_mean[3], feh_sigma[3];
     double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+    double frame_mat[9], frame_off[3];     // Galactic -> Galactocentric (galprior.astropy_frame)
     // derived on the host side of the ABI call (not part of brutus_post_params)
     double ln_f_thick, ln_f_halo, inv_reff_solar2;
     double inv_R_thin, inv_Z_thin, inv_R_thick, inv_Z_thick, inv_r_q;
@@ -116,7 +117,8 @@ __device__ __forceinline__ uint64_t star_ubase(const PostParams &pp, int s) {
 }
 
 struct StarGeom {      // per object: sightline unit vector and parallax
-    double cb_cl, cb_sl, sb;     // cos b cos l, cos b sin l, sin b
+    double ux, uy, uz;           // frame_mat @ (cos b cos l, cos b sin l, sin b): the sightline's
+                                 // direction in the Galactocentric frame
     double par, par_ivar, par_lnorm;
     int has_par;
     // line-of-sight dust prior (pdf.py:752-840 with a caller-supplied table): los points
@@ -203,7 +205,9 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
 __device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const StarGeom &g, double d,
                                                 const double (&EF)[3], const double (&EA)[3],
                                                 const double *__restrict__ tbl) {
-    const double x = pp.R_solar - d * g.cb_cl, y = d * g.cb_sl, Z = pp.Z_solar + d * g.sb;
+    // Galactocentric position (reference pdf.py:631-635): frame offset + d * direction
+    const double x = fma(d, g.ux, pp.frame_off[0]), y = fma(d, g.uy, pp.frame_off[1]),
+                 Z = fma(d, g.uz, pp.frame_off[2]);
     const double R2 = x * x + y * y;
     const double dZ = fabs(Z) - pp.abs_Z_solar;
     const double Rt = fast_sqrt(R2 + pp.Rs_thin2);
@@ -1015,17 +1019,23 @@ __global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
     if (i < n) dst[i] = src[perm[i]];
 }
 
+// direction of the sightline (l, b) [rad] in the Galactocentric frame of `pp`
+__device__ __forceinline__ void sightline(const PostParams &pp, double l, double b, StarGeom &g) {
+    const double n0 = cos(b) * cos(l), n1 = cos(b) * sin(l), n2 = sin(b);
+    g.ux = pp.frame_mat[0] * n0 + pp.frame_mat[1] * n1 + pp.frame_mat[2] * n2;
+    g.uy = pp.frame_mat[3] * n0 + pp.frame_mat[4] * n1 + pp.frame_mat[5] * n2;
+    g.uz = pp.frame_mat[6] * n0 + pp.frame_mat[7] * n1 + pp.frame_mat[8] * n2;
+}
+
 // per-object geometry / parallax constants
-__global__ void k_post_geom(int nstar, const double *__restrict__ coords,
+__global__ void k_post_geom(PostParams pp, int nstar, const double *__restrict__ coords,
                             const double *__restrict__ par, const double *__restrict__ perr,
                             DustCtx dc, StarGeom *__restrict__ geom) {
     const int s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= nstar) return;
     const double l = coords[2 * s] * (M_PI / 180.), b = coords[2 * s + 1] * (M_PI / 180.);
     StarGeom g;
-    g.cb_cl = cos(b) * cos(l);
-    g.cb_sl = cos(b) * sin(l);
-    g.sb = sin(b);
+    sightline(pp, l, b, g);
     const double p = par ? par[s] : nan(""), pe = perr ? perr[s] : nan("");
     g.has_par = (isfinite(p) && isfinite(pe)) ? 1 : 0;
     g.par = g.has_par ? p : 0.;
@@ -1056,9 +1066,7 @@ __global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict_
     if (i >= n) return;
     StarGeom g;
     const double l = coords[0] * (M_PI / 180.), b = coords[1] * (M_PI / 180.);
-    g.cb_cl = cos(b) * cos(l);
-    g.cb_sl = cos(b) * sin(l);
-    g.sb = sin(b);
+    sightline(pp, l, b, g);
     g.has_par = 0;
     g.dust_on = 0;
     double Fc[3], Ac[3];

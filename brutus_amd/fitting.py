@@ -210,11 +210,22 @@ class _Engine(object):
             pe = torch.from_numpy(np.ascontiguousarray(parallax_err, dtype=np.float64)).to(dev)
         return f, e, m, p, pe, has_par
 
-    def loglike_batch(self, flux, err, mask, parallax, parallax_err, params):
-        """Full-grid outputs for a batch of stars (host numpy in/out)."""
+    def loglike_batch(self, flux, err, mask, parallax, parallax_err, params,
+                      av_init=None, rv_init=None):
+        """Full-grid outputs for a batch of stars (host numpy in/out).  `av_init` /
+        `rv_init`: optional per-model starting values `(Nmodel,)` (fitting.py:697-703)."""
         torch, L, g = self.torch, self.L, self.grid
         S = flux.shape[0]
+
+        def init(a, name):
+            if a is None:
+                return None
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            if a.shape != (g.nmodel,):
+                raise ValueError("`%s` must have one value per model" % name)
+            return torch.from_numpy(a).to(g.device)
         with torch.cuda.device(g.device):
+            t_av0, t_rv0 = init(av_init, "av_init"), init(rv_init, "rv_init")
             f, e, m, p, pe, has_par = self._upload(flux, err, mask, parallax,
                                                    parallax_err)
             ws = self._workspace(S)
@@ -236,6 +247,8 @@ class _Engine(object):
                 ws.data_ptr(), ws.numel(), lnl.data_ptr(), chi2.data_ptr(),
                 scale.data_ptr(), av.data_ptr(), rv.data_ptr(), icov.data_ptr(),
                 ndim.data_ptr(), k1.ctypes.data, k2.ctypes.data,
+                t_av0.data_ptr() if t_av0 is not None else None,
+                t_rv0.data_ptr() if t_rv0 is not None else None,
                 _stream_ptr(torch)))
             out = dict(lnl=lnl.cpu().numpy(), chi2=chi2.cpu().numpy(),
                        scale=scale.cpu().numpy(), av=av.cpu().numpy(),
@@ -487,10 +500,11 @@ def loglike_batch(data, data_err, data_mask, mag_coeffs,
                   rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
                   dim_prior=True, ltol=3e-2, ltol_subthresh=1e-2,
                   init_thresh=5e-3, parallax=None, parallax_err=None,
-                  max_batch=None):
+                  max_batch=None, av_init=None, rv_init=None):
     """`loglike` for many stars at once: `data`, `data_err`, `data_mask` are
     `(Nstar, Nfilt)`, `parallax`/`parallax_err` `(Nstar,)` or None.  Returns a
-    dict of full-grid arrays `(Nstar, Nmodel)` plus `ndim`, `k1`, `k2`."""
+    dict of full-grid arrays `(Nstar, Nmodel)` plus `ndim`, `k1`, `k2`.
+    `av_init` / `rv_init` `(Nmodel,)`: starting values shared by the stars."""
     grid = mag_coeffs if isinstance(mag_coeffs, DeviceGrid) else DeviceGrid(mag_coeffs)
     params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
                           ltol_subthresh, init_thresh, dim_prior)
@@ -505,7 +519,7 @@ def loglike_batch(data, data_err, data_mask, mag_coeffs,
             data[a:b], data_err[a:b], data_mask[a:b],
             None if parallax is None else np.asarray(parallax)[a:b],
             None if parallax_err is None else np.asarray(parallax_err)[a:b],
-            params))
+            params, av_init=av_init, rv_init=rv_init))
     res = {}
     for k in outs[0]:
         ax = 1 if k == "icov6" else 0
@@ -525,12 +539,10 @@ def loglike(data, data_err, data_mask, mag_coeffs,
     values as reference `fitting.loglike` (fitting.py:579-820).
 
     `mag_coeffs` is `(Nmodel, Nfilt, 3)` (numpy, any float dtype) or a
-    `DeviceGrid` already resident on the GPU.  Unlike the reference the inputs
-    are not modified in place.
+    `DeviceGrid` already resident on the GPU.  `av_init` / `rv_init`: per-model starting
+    values of the magnitude phase (default: the prior means, fitting.py:697-703).  Unlike
+    the reference the inputs are not modified in place.
     """
-    if av_init is not None or rv_init is not None:
-        raise NotImplementedError("per-model av_init/rv_init are not supported; "
-                                  "the reference never passes them")
     one = lambda x: None if x is None else np.array([x], dtype=np.float64)
     if parallax is not None and parallax_err is None:
         parallax = None
@@ -540,7 +552,7 @@ def loglike(data, data_err, data_mask, mag_coeffs,
                         dim_prior=dim_prior, ltol=ltol,
                         ltol_subthresh=ltol_subthresh, init_thresh=init_thresh,
                         parallax=one(parallax), parallax_err=one(parallax_err),
-                        max_batch=1)
+                        max_batch=1, av_init=av_init, rv_init=rv_init)
     lnl, Ndim, chi2 = res["lnl"][0], int(res["ndim"][0]), res["chi2"][0]
     if return_vals:
         return (lnl, Ndim, chi2, res["scale"][0], res["av"][0], res["rv"][0],
@@ -818,7 +830,7 @@ class BruteForce(object):
         self._engine_obj = None
 
     # -- set-up (reference fitting.py:1144-1424) ------------------------------
-    def _setup(self, data, data_err, data_mask, data_labels,
+    def _setup(self, data, data_err, data_mask, data_labels=None,
                phot_offsets=None, parallax=None, parallax_err=None,
                av_gauss=None, lnprior=None,
                wt_thresh=1e-3, cdf_thresh=2e-3,
@@ -1031,11 +1043,11 @@ class BruteForce(object):
         if Nmc_prior <= 0:
             raise ValueError("Nmc_prior must be positive (the reference "
                              "divides by it, fitting.py:970)")
-        if wt_thresh is None and cdf_thresh is not None:
-            raise NotImplementedError(
-                "CDF thresholding (wt_thresh=None) discards the best models in "
-                "the reference (ascending sort, fitting.py:993-997); it is not "
-                "reproduced -- use wt_thresh")
+        # wt_thresh=None selects by CDF (fitting.py:992-998, 1017-1022).  The reference
+        # sorts ASCENDING and keeps cdf <= 1 - cdf_thresh, i.e. it drops the most probable
+        # models and hands the rest on in sort order; reproduced as it is --
+        # identical results are the bar -- through the full-grid outputs and a host cut.
+        cdf_mode = wt_thresh is None and cdf_thresh is not None
         (data, data_err, data_mask, _, data_coords,
          lnprior, lngalprior, lndustprior, av_gauss, wt_thresh,
          rstate) = self._setup(data, data_err, data_mask, data_labels=None,
@@ -1070,7 +1082,8 @@ class BruteForce(object):
         params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
                               ltol_subthresh, logl_initthresh, logl_dim_prior,
                               wt_thresh=wt_thresh)
-        step = eng.batch if lnprior_ext is None else max(1, min(eng.batch, 8))
+        step = (eng.batch if lnprior_ext is None and not cdf_mode
+                else max(1, min(eng.batch, 8)))
         from .rng import PhiloxRandomState
         philox_per_object = (seed0 is not None and isinstance(rstate_per_object, str)
                              and rstate_per_object == "philox")
@@ -1134,7 +1147,8 @@ class BruteForce(object):
         try:
             for out in self._fit_loop(eng, params, step, Ndata, data, data_err,
                                       data_mask, parallax, parallax_err,
-                                      data_coords, lnprior_ext, wt_thresh, pool,
+                                      data_coords, lnprior_ext,
+                                      (wt_thresh, cdf_thresh, cdf_mode), pool,
                                       seed0, rstate, rstate_per_object,
                                       (Nmc_prior, lnprior, wt_thresh, cdf_thresh,
                                        lngalprior, lndustprior, dustfile, dlabels,
@@ -1146,22 +1160,23 @@ class BruteForce(object):
                 pool.close()
 
     def _fit_loop(self, eng, params, step, Ndata, data, data_err, data_mask,
-                  parallax, parallax_err, data_coords, lnprior_ext, wt_thresh,
+                  parallax, parallax_err, data_coords, lnprior_ext, cut,
                   pool, seed0, rstate, rstate_per_object, post_args, tail_args):
         (Nmc_prior, lnprior, wt_thresh, cdf_thresh, lngalprior, lndustprior,
          dustfile, dlabels, avlim, rvlim, mem_lim) = post_args
         apply_av_prior, Ndraws, return_distreds = tail_args
+        cdf_mode = cut[2]
         pending = []      # in-flight host-pool results, in object order
         for a in range(0, Ndata, step):
             b = min(Ndata, a + step)
-            if lnprior_ext is None:
+            if lnprior_ext is None and not cdf_mode:
                 recs = eng.fit_batch(data[a:b], data_err[a:b], data_mask[a:b],
                                      parallax[a:b], parallax_err[a:b], params)
             else:
                 recs = self._first_cut_with_ext(eng, data[a:b], data_err[a:b],
                                                 data_mask[a:b], parallax[a:b],
                                                 parallax_err[a:b], params,
-                                                lnprior_ext, a, wt_thresh)
+                                                lnprior_ext, a, wt_thresh, cdf_thresh)
             if pool is not None:
                 # keep the device busy: hand this batch to the pool, yield what
                 # is finished from earlier batches (always in object order)
@@ -1395,15 +1410,17 @@ class BruteForce(object):
                 finisher.shutdown(wait=True)     # a running phase 2 still reads the buffers
 
     def _first_cut_with_ext(self, eng, data, err, mask, par, perr, params,
-                            lnprior_ext, offset, wt_thresh):
-        """External per-object Gaussian label constraints modify lnlike over
-        the whole grid before the first cut (fitting.py:1995-2009); this rare
-        option uses the full-grid device outputs and cuts on the host."""
+                            lnprior_ext, offset, wt_thresh, cdf_thresh=None):
+        """First cut on the host from the full-grid device outputs, for the two rare
+        options the device cut does not cover: external per-object Gaussian label
+        constraints, which modify lnlike over the whole grid before the cut
+        (fitting.py:1995-2009), and CDF thresholding (`wt_thresh=None`, fitting.py:992-998),
+        whose selection comes in ascending-lnprob order."""
         res = eng.loglike_batch(data, err, mask, par, perr, params)
         recs = []
         for s in range(data.shape[0]):
             lnl = res["lnl"][s].copy()
-            for k in lnprior_ext.keys():
+            for k in (lnprior_ext.keys() if lnprior_ext is not None else ()):
                 mean, std = lnprior_ext[k][offset + s]
                 if np.isfinite(mean) and std > 0:
                     chi2e = (self.models_labels[k] - mean) ** 2 / std ** 2
@@ -1413,7 +1430,13 @@ class BruteForce(object):
                 lnprob = lnl + scale_parallax_lnprior(
                     res["scale"][s], 1. / np.sqrt(np.abs(icov00)), par[s], perr[s])
             lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
-            sel = np.where(lnprob > np.log(wt_thresh) + np.max(lnprob))[0]
+            if wt_thresh is not None:
+                with np.errstate(all="ignore"):
+                    sel = np.where(lnprob > np.log(wt_thresh) + np.max(lnprob))[0]
+            else:
+                order = np.argsort(lnprob)
+                prob = np.exp(lnprob - logsumexp(lnprob))
+                sel = order[np.cumsum(prob[order]) <= (1. - cdf_thresh)]
             recs.append(dict(sel=sel, lnlike=lnl[sel], chi2=res["chi2"][s][sel],
                              scale=res["scale"][s][sel], av=res["av"][s][sel],
                              rv=res["rv"][s][sel],
@@ -1441,8 +1464,13 @@ class BruteForce(object):
                 dlabels, avlim, rvlim, rstate, apply_av_prior, mem_lim,
                 rec["lnlike"])
             Nsel = len(sel)
-            # position of the final selection inside the first-cut records
-            pos = np.searchsorted(sel0, sel)
+            # position of the final selection inside the first-cut records (which are in
+            # ascending model order, except after CDF thresholding)
+            if len(sel0) > 1 and np.any(sel0[1:] < sel0[:-1]):
+                order = np.argsort(sel0, kind="stable")
+                pos = order[np.searchsorted(sel0[order], sel)]
+            else:
+                pos = np.searchsorted(sel0, sel)
             chi2 = rec["chi2"][pos]
             scales_sel, avs_sel, rvs_sel = (rec["scale"][pos], rec["av"][pos],
                                             rec["rv"][pos])

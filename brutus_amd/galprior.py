@@ -7,14 +7,17 @@ Counterpart of reference `pdf.gal_lnprior` (pdf.py:476-749) and its pieces
 metallicity and age priors mixed by the component membership probabilities.
 
 The pieces are pinned against the reference (tests/golden/galprior_pieces.npz).
-The assembled prior is NOT pinned: the reference converts (l, b, d) to
-Galactocentric (R, Z) through astropy's `Galactocentric` frame, whose defaults
-(Sun-centre distance, solar height, Sgr A* position) depend on the installed
-astropy version and are not the `R_solar`/`Z_solar` the density model itself
-uses.  Here the geometry is self-consistent instead: the Sun sits
-at Galactocentric radius `R_solar`, height `Z_solar`, and l = 0 points at the
-Galactic centre.  Differences to the astropy route are at the per-cent level in
-(R, Z) for kpc-scale distances.
+The reference converts (l, b, d) to Galactocentric (R, Z) through astropy's
+`Galactocentric` frame (pdf.py:631-635); astropy is not installed here, so the
+assembled prior cannot be pinned by running the reference.  Instead the
+frame itself is restated (`frame="astropy"`, the default): astropy >= 4.0's default
+parameter set -- Galactic -> FK5(J2000) -> ICRS rotation, `galcen_coord` ICRS
+(266.4051, -28.936175) deg, `roll` 0 (with astropy's `roll0` = 58.5986320306 deg),
+`galcen_distance` 8.122 kpc, `z_sun` 20.8 pc -- see `astropy_frame`.  Note that, exactly
+as in the reference, the frame's Sun (8.122 kpc, 20.8 pc) is NOT the `R_solar`/`Z_solar`
+= (8.2 kpc, 25 pc) at which the density model is normalised.  `frame="simple"` is the
+self-consistent geometry of earlier versions of this package (Sun at `R_solar`,
+`Z_solar`, l = 0 towards the centre); DESIGN.md quantifies the difference.
 """
 from math import erf, log, sqrt
 
@@ -35,18 +38,82 @@ def _lse(parts):
         acc = acc + np.exp(q - safe)
     return np.log(acc) + safe
 
-__all__ = ["galactic_to_RZ", "logn_disk", "logn_halo", "logp_feh",
-           "logp_age_from_feh", "gal_lnprior"]
+__all__ = ["galactic_to_RZ", "astropy_frame", "simple_frame", "logn_disk", "logn_halo",
+           "logp_feh", "logp_age_from_feh", "gal_lnprior", "gal_lnprior_simple"]
 
 
-def galactic_to_RZ(dists, coord, R_solar=8.2, Z_solar=0.025):
+def _rot(angle, axis):
+    """astropy.coordinates.matrix_utilities.rotation_matrix(angle [rad], axis): the
+    passive rotation (of the frame) about a coordinate axis."""
+    c, s = np.cos(angle), np.sin(angle)
+    if axis == "x":
+        return np.array([[1., 0., 0.], [0., c, s], [0., -s, c]])
+    if axis == "y":
+        return np.array([[c, 0., -s], [0., 1., 0.], [s, 0., c]])
+    return np.array([[c, s, 0.], [-s, c, 0.], [0., 0., 1.]])
+
+
+def astropy_frame(galcen_distance=8.122, z_sun=0.0208, roll=0.,
+                  galcen_ra=266.4051, galcen_dec=-28.936175):
+    """`(M (3, 3), offset (3,))` with  x_galactocentric [kpc] = M @ x_galactic + offset,
+    x_galactic = d (cos b cos l, cos b sin l, sin b): astropy's Galactic -> ICRS ->
+    `Galactocentric` chain with the defaults of astropy >= 4.0 (`galactocentric_frame_
+    defaults` 'v4.0': galcen_distance 8.122 kpc -- GRAVITY 2018 --, z_sun 20.8 pc --
+    Bennett & Bovy 2019 --, galcen_coord ICRS (17h45m37.224s, -28d56m10.23s) -- Reid &
+    Brunthaler 2004 --, roll 0).  Constants as in astropy's sources:
+      builtin_frames/galactic.py         NGP (FK5 J2000) ra 192.8594812065348 deg,
+                                         dec 27.12825118085622 deg, lon0 122.9319185680026 deg
+      builtin_frames/icrs_fk5_transforms.py   eta0 -19.9 mas, xi0 9.1 mas, da0 -22.9 mas
+      builtin_frames/galactocentric.py   roll0 58.5986320306 deg; R = Rx(roll0 - roll)
+                                         Ry(-dec_gc) Rz(ra_gc); H = Ry(-asin(z_sun / d_gc));
+                                         x' = H R x_icrs - H (d_gc, 0, 0)
+    With roll 0 the frame is the Galactic frame shifted to the centre up to ~1.5e-6 rad
+    (that is what roll0 is for); what differs from the `simple` geometry are the Sun's
+    distance and height and the 0.147 deg tilt H."""
+    rad = np.deg2rad
+    fk5_to_gal = (_rot(rad(180. - 122.9319185680026), "z")
+                  @ _rot(rad(90. - 27.12825118085622), "y") @ _rot(rad(192.8594812065348), "z"))
+    mas = np.pi / 180. / 3600e3
+    icrs_to_fk5 = _rot(-22.9 * mas, "z") @ _rot(9.1 * mas, "y") @ _rot(19.9 * mas, "x")
+    gal_to_icrs = icrs_to_fk5.T @ fk5_to_gal.T
+    R = (_rot(rad(58.5986320306 - roll), "x") @ _rot(-rad(galcen_dec), "y")
+         @ _rot(rad(galcen_ra), "z"))
+    H = _rot(-np.arcsin(z_sun / galcen_distance), "y")
+    return H @ R @ gal_to_icrs, -H @ np.array([galcen_distance, 0., 0.])
+
+
+def simple_frame(R_solar=8.2, Z_solar=0.025):
+    """The same pair for the self-consistent geometry: Sun at radius `R_solar`, height
+    `Z_solar`, l = 0 towards the centre, no tilt."""
+    return np.diag([1., 1., 1.]), np.array([-R_solar, 0., Z_solar])
+
+
+_ASTROPY_FRAME = astropy_frame()
+
+
+def _frame(frame, R_solar, Z_solar):
+    if isinstance(frame, str):
+        if frame == "astropy":
+            return _ASTROPY_FRAME
+        if frame == "simple":
+            return simple_frame(R_solar, Z_solar)
+        raise ValueError("frame must be 'astropy', 'simple' or a (matrix, offset) pair")
+    return np.asarray(frame[0], dtype=np.float64), np.asarray(frame[1], dtype=np.float64)
+
+
+def galactic_to_RZ(dists, coord, R_solar=8.2, Z_solar=0.025, frame="astropy"):
     """Heliocentric Galactic (l, b) [deg] and distance [kpc] -> cylindrical
-    Galactocentric radius R and height Z [kpc]."""
+    Galactocentric radius R and height Z [kpc] (reference pdf.py:631-635).  `frame`:
+    "astropy" (the reference's route, see `astropy_frame`), "simple" (Sun at `R_solar`,
+    `Z_solar`) or an explicit `(M, offset)` pair."""
+    M, off = _frame(frame, R_solar, Z_solar)
     ell, b = np.deg2rad(coord[0]), np.deg2rad(coord[1])
     d = np.asarray(dists, dtype=np.float64)
-    x = R_solar - d * np.cos(b) * np.cos(ell)     # towards the Sun from the centre
-    y = d * np.cos(b) * np.sin(ell)
-    z = Z_solar + d * np.sin(b)
+    n = np.array([np.cos(b) * np.cos(ell), np.cos(b) * np.sin(ell), np.sin(b)])
+    u = M @ n                                   # direction of the sightline in the frame
+    x = off[0] + d * u[0]
+    y = off[1] + d * u[1]
+    z = off[2] + d * u[2]
     return np.hypot(x, y), z
 
 
@@ -103,14 +170,16 @@ def gal_lnprior(dists, coord, labels=None, R_solar=8.2, Z_solar=0.025,
                 feh_halo=-1.6, feh_halo_sigma=0.5,
                 max_age=13.8, min_age=0., feh_age_ctr=-0.5, feh_age_scale=0.5,
                 nsigma_from_max_age=2., max_sigma=4., min_sigma=1.,
-                return_components=False):
+                return_components=False, frame="astropy"):
     """ln prior over distance (and, through `labels['feh']` / `labels['loga']`,
     metallicity and age) for a sightline `coord = (l, b)` in degrees.  Same
-    signature, defaults and component model as reference pdf.py:476-749."""
+    signature, defaults and component model as reference pdf.py:476-749; `frame`
+    (extension, trailing keyword) selects the Galactocentric geometry, by default the
+    reference's astropy route (`galactic_to_RZ`)."""
     dists = np.asarray(dists, dtype=np.float64)
     with np.errstate(all="ignore"):
         volume = 2. * np.log(dists + 1e-300)
-        R, Z = galactic_to_RZ(dists, coord, R_solar=R_solar, Z_solar=Z_solar)
+        R, Z = galactic_to_RZ(dists, coord, R_solar=R_solar, Z_solar=Z_solar, frame=frame)
         comp = [
             logn_disk(R, Z, R_solar, Z_solar, R_thin, Z_thin, Rs_thin) + volume,
             logn_disk(R, Z, R_solar, Z_solar, R_thick, Z_thick, Rs_thick)
@@ -155,7 +224,7 @@ def device_params(**kw):
              f_halo=0.005, feh_thin=-0.2, feh_thin_sigma=0.3, feh_thick=-0.7,
              feh_thick_sigma=0.4, feh_halo=-1.6, feh_halo_sigma=0.5,
              max_age=13.8, min_age=0., feh_age_ctr=-0.5, feh_age_scale=0.5,
-             nsigma_from_max_age=2., max_sigma=4., min_sigma=1.)
+             nsigma_from_max_age=2., max_sigma=4., min_sigma=1., frame="astropy")
     d.update(kw)
     means = (d["feh_thin"], d["feh_thick"], d["feh_halo"])
     out = {k: d[k] for k in ("R_solar", "Z_solar", "R_thin", "Z_thin", "Rs_thin",
@@ -175,6 +244,9 @@ def device_params(**kw):
         asg.append(sig)
         aln.append(log(sig / 2.) + log(erf(hi / sqrt(2.)) - erf(lo / sqrt(2.))))
     out["age_mean"], out["age_sigma"], out["age_lnnorm"] = tuple(am), tuple(asg), tuple(aln)
+    M, off = _frame(d["frame"], d["R_solar"], d["Z_solar"])
+    out["frame_mat"] = tuple(float(x) for x in np.asarray(M).ravel())
+    out["frame_off"] = tuple(float(x) for x in off)
     return out
 
 
@@ -183,3 +255,14 @@ def device_params(**kw):
 gal_lnprior.broadcasts_labels = True
 #: marks the hook as the built-in model the device `lnpost` implements
 gal_lnprior.device_params = device_params
+
+
+def gal_lnprior_simple(dists, coord, labels=None, **kw):
+    """`gal_lnprior` with the self-consistent `simple` geometry (Sun at `R_solar`,
+    `Z_solar`); also runs on the device."""
+    kw.setdefault("frame", "simple")
+    return gal_lnprior(dists, coord, labels=labels, **kw)
+
+
+gal_lnprior_simple.broadcasts_labels = True
+gal_lnprior_simple.device_params = lambda **kw: device_params(**dict(dict(frame="simple"), **kw))

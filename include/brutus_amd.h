@@ -93,7 +93,10 @@ size_t brutus_workspace_bytes(int64_t nmodel, int nfilt, int nstar);
  * outputs, each plane (nstar, nmodel) float64; d_icov is (6, nstar, nmodel)
  * holding the unique entries [00, 01, 02, 11, 12, 22] of icov_sar
  * (fitting.py:563-574).  d_ndim (nstar,) int32.  h_k1/h_k2 (optional, host,
- * (nstar,) int32) receive the number of magnitude sweeps / flux iterations. */
+ * (nstar,) int32) receive the number of magnitude sweeps / flux iterations.
+ * d_av_init / d_rv_init (optional, (nmodel,) float64): per-model starting values of the
+ * magnitude phase, `av_init` / `rv_init` of fitting.py:697-703, shared by the stars of the
+ * batch; NULL = the prior means av_gauss[0] / rv_gauss[0] (the reference's default). */
 int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                          int nstar, const double *d_flux, const double *d_err,
                          const uint8_t *d_mask, const double *d_parallax,
@@ -102,7 +105,8 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                          size_t workspace_bytes, double *d_lnl, double *d_chi2,
                          double *d_scale, double *d_av, double *d_rv,
                          double *d_icov, int32_t *d_ndim, int32_t *h_k1,
-                         int32_t *h_k2, void *stream);
+                         int32_t *h_k2, const double *d_av_init,
+                         const double *d_rv_init, void *stream);
 
 /* The fit() hot path: loglike + lnpost's parallax clip + first wt_thresh cut
  * (fitting.py:976-991), emitting only the selected models as INDEXED RECORDS:
@@ -135,7 +139,7 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
  * Everything of fitting.lnpost after the first cut (fitting.py:1000-1107) and
  * the resampling tail of BruteForce._fit (fitting.py:2021-2061), for the
  * built-in priors: static lnprior + the Galactic model of pdf.gal_lnprior
- * (pdf.py:476-749; geometry as in brutus_amd/galprior.py) + the parallax
+ * (pdf.py:476-749; Galactocentric frame passed in, see frame_mat) + the parallax
  * likelihood.  Random numbers follow brutus_amd/rng.py (PhiloxRandomState):
  * normal j / uniform q are functions of (seed, j) / (seed, q), so the result is
  * what the reference produces when it is handed that object as `rstate`.
@@ -170,6 +174,11 @@ typedef struct brutus_post_params {
     double Rs_halo, q_halo_ctr, q_halo_inf, r_q_halo, eta_halo, f_halo;
     double feh_mean[3], feh_sigma[3];
     double age_mean[3], age_sigma[3], age_lnnorm[3], min_age, max_age;
+    /* Galactic -> Galactocentric frame of the prior (reference pdf.py:631-635 goes through
+     * astropy's `Galactocentric`): x_gc [kpc] = frame_mat (row-major 3x3) @ d (cos b cos l,
+     * cos b sin l, sin b) + frame_off; R = hypot(x, y), Z = z.  brutus_amd/galprior.py
+     * (`astropy_frame`, `simple_frame`) builds the two frames the host knows. */
+    double frame_mat[9], frame_off[3];
 } brutus_post_params;
 
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc);

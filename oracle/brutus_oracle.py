@@ -362,7 +362,7 @@ def loglike(data, data_err, data_mask, mag_coeffs,
             rvlim=(1., 8.), rv_gauss=(3.32, 0.18),
             dim_prior=True, ltol=3e-2, ltol_subthresh=1e-2, init_thresh=5e-3,
             parallax=None, parallax_err=None, return_vals=False, trace=None,
-            max_sweeps=100000):
+            max_sweeps=100000, av_init=None, rv_init=None):
     """fitting.py:579-820 (`loglike`).  `mag_coeffs` may be float32 or float64;
     float32 values are promoted to float64 before any arithmetic.
 
@@ -375,8 +375,12 @@ def loglike(data, data_err, data_mask, mag_coeffs,
     data = np.asarray(data, dtype=np.float64)
     data_err = np.asarray(data_err, dtype=np.float64)
     Nmodels = mag_coeffs.shape[0]
-    av_init = np.zeros(Nmodels) + av_gauss[0]
-    rv_init = np.zeros(Nmodels) + rv_gauss[0]
+    if av_init is None:                                      # fitting.py:697-703
+        av_init = np.zeros(Nmodels) + av_gauss[0]
+    if rv_init is None:
+        rv_init = np.zeros(Nmodels) + rv_gauss[0]
+    av_init = np.array(av_init, dtype=np.float64)
+    rv_init = np.array(rv_init, dtype=np.float64)
 
     mask = clean_mask(data, data_err, data_mask)
     Ndim = int(np.sum(mask))
@@ -465,10 +469,11 @@ def lnpost(results, parallax=None, parallax_err=None, coord=None,
            lngalprior=None, lndustprior=None, dustfile=None, dlabels=None,
            avlim=(0., 20.), rvlim=(1., 8.), rstate=None,
            apply_av_prior=True, mem_lim=8000.):
-    """fitting.py:934-1107 (`lnpost`), `wt_thresh` branch.  `lngalprior` must
-    be supplied (the reference's default hook needs astropy: unpinned)."""
-    if wt_thresh is None:
-        raise NotImplementedError("CDF thresholding (SURVEY B5) not restated")
+    """fitting.py:934-1107 (`lnpost`), both thresholding branches (`wt_thresh=None`:
+    CDF thresholding exactly as the reference does it, ascending sort and all).
+    `lngalprior` must be supplied (the reference's default hook needs astropy: unpinned)."""
+    if wt_thresh is None and cdf_thresh is None:             # fitting.py:935-936
+        wt_thresh = -np.inf
     if lngalprior is None:
         raise ValueError("oracle needs an explicit `lngalprior` hook")
     if coord is None:
@@ -492,8 +497,14 @@ def lnpost(results, parallax=None, parallax_err=None, coord=None,
         if parallax is None or parallax_err is None:
             lnlike = lnprob
 
-        lwt_min = np.log(wt_thresh) + np.max(lnprob)         # :988-991
-        sel = np.where(lnprob > lwt_min)[0]
+        if wt_thresh is not None:
+            lwt_min = np.log(wt_thresh) + np.max(lnprob)     # :988-991
+            sel = np.where(lnprob > lwt_min)[0]
+        else:                                                # :992-998
+            idx_sort = np.argsort(lnprob)
+            prob = np.exp(lnprob - logsumexp(lnprob))
+            cdf = np.cumsum(prob[idx_sort])
+            sel = idx_sort[cdf <= (1. - cdf_thresh)]
 
         lnp = lnlike[sel]                                    # :1000-1010
         lnp = lnp + lnprior[sel]
@@ -503,8 +514,14 @@ def lnpost(results, parallax=None, parallax_err=None, coord=None,
         if apply_av_prior:
             lnp = lnp + lndustprior(dist, coord, avs[sel], dustfile=dustfile)
 
-        lwt_min = np.log(wt_thresh) + np.max(lnp)            # :1013-1016
-        sel = sel[np.where(lnp > lwt_min)[0]]
+        if wt_thresh is not None:
+            lwt_min = np.log(wt_thresh) + np.max(lnp)        # :1013-1016
+            sel = sel[np.where(lnp > lwt_min)[0]]
+        else:                                                # :1017-1022
+            idx_sort = np.argsort(lnp)
+            prob = np.exp(lnp - logsumexp(lnp))
+            cdf = np.cumsum(prob[idx_sort])
+            sel = sel[idx_sort[cdf <= (1. - cdf_thresh)]]
         lnp = lnlike[sel] + lnprior[sel]                     # :1023
         scale, av, rv = scales[sel], avs[sel], rvs[sel]
         icov_sar = np.array(icovs_sar[sel])
@@ -608,7 +625,7 @@ def fit_star(data, data_err, data_mask, models, lnprior, labels, coord,
              Nmc_prior=50, avlim=(0., 20.), av_gauss=None, rvlim=(1., 8.),
              rv_gauss=(3.32, 0.18), wt_thresh=1e-3, Ndraws=250,
              dim_prior=True, ltol=3e-2, ltol_subthresh=1e-2,
-             init_thresh=5e-3, mem_lim=8000., return_distreds=True):
+             init_thresh=5e-3, mem_lim=8000., return_distreds=True, cdf_thresh=2e-3):
     """One iteration of the star loop of `BruteForce._fit`
     (fitting.py:1980-2065), after `_setup`.  `av_gauss=None` with
     `lndustprior=None` follows fitting.py:1396-1398 (flat prior (0, 1e6))."""
@@ -627,19 +644,19 @@ def fit_star(data, data_err, data_mask, models, lnprior, labels, coord,
                        lngalprior, lndustprior=lndustprior, Nmc_prior=Nmc_prior,
                        avlim=avlim, rvlim=rvlim, wt_thresh=wt_thresh, Ndraws=Ndraws,
                        mem_lim=mem_lim, return_distreds=return_distreds,
-                       apply_av_prior=apply_av_prior)
+                       apply_av_prior=apply_av_prior, cdf_thresh=cdf_thresh)
 
 
 def finish_star(results, lnprior, labels, coord, parallax, parallax_err, rstate,
                 lngalprior, lndustprior=None, Nmc_prior=50, avlim=(0., 20.),
                 rvlim=(1., 8.), wt_thresh=1e-3, Ndraws=250, mem_lim=8000.,
-                return_distreds=True, apply_av_prior=False):
+                return_distreds=True, apply_av_prior=False, cdf_thresh=2e-3):
     """`lnpost` + the resampling tail of the star loop (fitting.py:2010-2065) from
     full-grid `loglike` results."""
     lnlike, Ndim, chi2, scales, avs, rvs, icovs = results
     sel, cov_sar, lnprob, dists, reds, dreds, logwts = lnpost(
         results, parallax=parallax, parallax_err=parallax_err, coord=coord,
-        Nmc_prior=Nmc_prior, lnprior=lnprior, wt_thresh=wt_thresh,
+        Nmc_prior=Nmc_prior, lnprior=lnprior, wt_thresh=wt_thresh, cdf_thresh=cdf_thresh,
         lngalprior=lngalprior, lndustprior=lndustprior, dlabels=labels,
         avlim=avlim, rvlim=rvlim, rstate=rstate,
         apply_av_prior=apply_av_prior, mem_lim=mem_lim)

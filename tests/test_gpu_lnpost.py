@@ -60,16 +60,18 @@ def test_device_galprior_matches_host():
     lab = np.zeros(n, dtype=[("feh", "f8"), ("loga", "f8")])
     lab["feh"] = rng.uniform(-3, 0.6, n)
     lab["loga"] = rng.uniform(7.5, 10.2, n)
-    for coord in ((204.7, -19.2), (0., 90.), (33., 2.)):
-        t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
-        out = torch.empty(n, dtype=torch.float64, device="cuda")
-        td, tc, tf, tl = t(d), t(np.array(coord)), t(lab["feh"]), t(lab["loga"])
-        _lib.check(L.brutus_debug_galprior(_post_params(), n, td.data_ptr(),
-                                           tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
-                                           out.data_ptr(), None))
-        torch.cuda.synchronize()
-        ref = gal_lnprior(d, coord, labels=lab)
-        assert relerr(ref, out.cpu().numpy()) < 1e-12
+    # both Galactocentric frames: the reference's astropy route (default) and the simple one
+    for frame in ("astropy", "simple"):
+        for coord in ((204.7, -19.2), (0., 90.), (33., 2.), (0.02, -0.01)):
+            t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+            out = torch.empty(n, dtype=torch.float64, device="cuda")
+            td, tc, tf, tl = t(d), t(np.array(coord)), t(lab["feh"]), t(lab["loga"])
+            _lib.check(L.brutus_debug_galprior(_post_params(frame=frame), n, td.data_ptr(),
+                                               tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
+                                               out.data_ptr(), None))
+            torch.cuda.synchronize()
+            ref = gal_lnprior(d, coord, labels=lab, frame=frame)
+            assert relerr(ref, out.cpu().numpy()) < 1e-12, (frame, coord)
 
 
 def _setup(nmodel=6000, nstar=9, seed=31):

@@ -132,6 +132,54 @@ def test_fit_matches_reference_golden():
             assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
 
 
+def test_loglike_init_arrays_vs_reference_golden():
+    """`loglike(av_init=, rv_init=)`: per-model starting values of the magnitude phase
+    (reference fitting.py:697-707) on the HIP path against the reference's output."""
+    from brutus_amd import fitting
+    z = np.load(os.path.join(GOLDEN, "init_loglike.npz"))
+    for tag, kw in (("both", dict(av_init=z["av_init"], rv_init=z["rv_init"])),
+                    ("av", dict(av_init=z["av_init"]))):
+        got = fitting.loglike(z["flux"], z["err"], z["mask"], z["models"],
+                              parallax=float(z["parallax"]), parallax_err=float(z["parallax_err"]),
+                              return_vals=True, **kw)
+        ref = tuple(int(z[tag + "_Ndim"]) if n == "Ndim" else z["%s_%s" % (tag, n)]
+                    for n in "lnl Ndim chi2 scale av rv icov".split())
+        _cmp_loglike(got, ref, "init " + tag)
+    with pytest.raises(ValueError):
+        fitting.loglike(z["flux"], z["err"], z["mask"], z["models"], av_init=z["av_init"][:5])
+
+
+def test_fit_cdf_thresholding_vs_reference_golden():
+    """`_fit(wt_thresh=None)`: CDF thresholding exactly as the reference does it (ascending
+    sort: it drops the most probable models and hands the rest on in sort order;
+    fitting.py:992-998, 1017-1022), incl. the `Nsel_max` clip -- resampled indices
+    bit-exact against the reference's own run, floats <= 1e-5."""
+    from brutus_amd import fitting, synth
+    z = np.load(os.path.join(GOLDEN, "fit_cdf.npz"))
+    models, labels, lmask = synth.make_grid(int(z["grid_nmodel"]), int(z["grid_nfilt"]),
+                                            seed=int(z["grid_seed"]))
+    BF = fitting.BruteForce(models, labels, lmask)
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(z["flux"])):
+        sl = slice(i, i + 1)
+        out = next(BF._fit(z["flux"][sl], z["err"][sl], z["mask"][sl], parallax=z["parallax"][sl],
+                           parallax_err=z["parallax_err"][sl], Nmc_prior=12, lnprior=z["lnprior"],
+                           lngalprior=galprior, data_coords=z["coords"][sl], wt_thresh=None,
+                           cdf_thresh=2e-3, rstate=np.random.RandomState(int(z["seed0"]) + i),
+                           Ndraws=40, mem_lim=float(z["mem_lim"][i])))
+        assert np.array_equal(out[0], z["sidxs"][i]), "star %d indices" % i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-5, (i, n, relerr(z[n][i], got))
+    # a batch of several objects on one shared stream takes the same route
+    rs = np.random.RandomState(3)
+    outs = list(BF._fit(z["flux"], z["err"], z["mask"], parallax=z["parallax"],
+                        parallax_err=z["parallax_err"], Nmc_prior=12, lnprior=z["lnprior"],
+                        lngalprior=galprior, data_coords=z["coords"], wt_thresh=None,
+                        cdf_thresh=2e-3, rstate=rs, Ndraws=40))
+    assert len(outs) == len(z["flux"])
+
+
 def test_fit_batched_equals_one_by_one():
     """One sequential RandomState over a batch == the reference's star loop."""
     from brutus_amd import fitting, synth

@@ -130,3 +130,39 @@ def test_fit_with_philox_rstate_matches_reference():
         for n, got in zip(names[1:], out[1:]):
             assert relerr(z[n][i], got) < 1e-8, (i, n)
     assert (rs.n_normal, rs.n_uniform) == (int(z["n_normal"]), int(z["n_uniform"]))
+
+
+def test_loglike_with_init_arrays_matches_reference():
+    """Per-model `av_init` / `rv_init` (reference fitting.py:697-707)."""
+    z = np.load(os.path.join(GOLDEN, "init_loglike.npz"))
+    for tag, kw in (("both", dict(av_init=z["av_init"], rv_init=z["rv_init"])),
+                    ("av", dict(av_init=z["av_init"]))):
+        out = O.loglike(z["flux"], z["err"], z["mask"], z["models"], parallax=float(z["parallax"]),
+                        parallax_err=float(z["parallax_err"]), return_vals=True, **kw)
+        assert out[1] == int(z[tag + "_Ndim"])
+        for name, got in zip("lnl Ndim chi2 scale av rv icov".split(), out):
+            if name != "Ndim":
+                assert relerr(z["%s_%s" % (tag, name)], got) < TOL, (tag, name)
+    # ... and the starting point matters: the default start gives other numbers
+    dflt = O.loglike(z["flux"], z["err"], z["mask"], z["models"], parallax=float(z["parallax"]),
+                     parallax_err=float(z["parallax_err"]), return_vals=True)
+    assert relerr(z["both_av"], dflt[4]) > 1e-6
+
+
+def test_fit_star_cdf_thresholding_matches_reference():
+    """`wt_thresh=None`: CDF thresholding as the reference does it (ascending sort: the
+    most probable models are dropped, the rest handed on in sort order; fitting.py:992-998,
+    1017-1022), with and without the `Nsel_max` clip."""
+    z = np.load(os.path.join(GOLDEN, "fit_cdf.npz"))
+    models, labels, lmask = synth.make_grid(int(z["grid_nmodel"]), int(z["grid_nfilt"]),
+                                            seed=int(z["grid_seed"]))
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    for i in range(len(z["flux"])):
+        out = O.fit_star(z["flux"][i], z["err"][i], z["mask"][i], models, z["lnprior"], labels,
+                         z["coords"][i], z["parallax"][i], z["parallax_err"][i],
+                         np.random.RandomState(int(z["seed0"]) + i), galprior, Nmc_prior=12,
+                         Ndraws=40, wt_thresh=None, cdf_thresh=2e-3, mem_lim=float(z["mem_lim"][i]))
+        assert np.array_equal(out[0], z["sidxs"][i]), i
+        for n, got in zip(names[1:], out[1:]):
+            assert relerr(z[n][i], got) < 1e-9, (i, n)

@@ -179,6 +179,66 @@ def gen_fit():
         seed0=1000, **{k: np.array(v) for k, v in res.items()})
 
 
+def gen_loglike_init():
+    """`loglike` with per-model `av_init` / `rv_init` arrays (reference
+    fitting.py:697-707): a different starting point changes the number of sweeps and,
+    through the sweep count, the converged values of every model."""
+    rng = np.random.RandomState(77)
+    models, _, _ = synth.make_grid(1024, 8, seed=24)
+    f, e = star_from_model(models, rng.randint(1024), 1.1, 3.4, 1.3, 0.04, rng)
+    m = np.ones(8, dtype=bool)
+    av_init = rng.uniform(0., 2.5, 1024)
+    rv_init = rng.uniform(2.2, 4.6, 1024)
+    out = {}
+    for tag, kw in (("both", dict(av_init=av_init.copy(), rv_init=rv_init.copy())),
+                    ("av", dict(av_init=av_init.copy()))):
+        r = F.loglike(f.copy(), e.copy(), m.copy(), models.astype(np.float64), parallax=0.8,
+                      parallax_err=0.1, return_vals=True, **kw)
+        for n, v in zip("lnl Ndim chi2 scale av rv icov".split(), r):
+            out["%s_%s" % (tag, n)] = np.asarray(v)
+    np.savez_compressed(os.path.join(OUT, "init_loglike.npz"), models=models, flux=f, err=e,
+                        mask=m, parallax=0.8, parallax_err=0.1, av_init=av_init,
+                        rv_init=rv_init, **out)
+    print("loglike with av_init / rv_init done")
+
+
+def gen_fit_cdf():
+    """`_fit` with `wt_thresh=None`: CDF thresholding (reference fitting.py:992-998,
+    1017-1022) -- ascending sort, so the most probable models are dropped and the rest is
+    handed on in sort order.  Two objects with the default `mem_lim`, two with
+    one small enough for the `Nsel_max` clip (fitting.py:1029-1036) to act."""
+    models, labels, lmask = synth.make_grid(1500, 6, seed=33)
+    st = synth.make_stars(models, 4, seed=9)
+    st['parallax'][1] = np.nan
+    st['parallax_err'][1] = np.nan
+    BF = F.BruteForce(models.astype(np.float64), labels, lmask)
+    sp = BF._setup(st['flux'].copy(), st['err'].copy(), st['mask'].copy(), None,
+                   data_coords=st['coords'], lngalprior=galprior, parallax=st['parallax'],
+                   parallax_err=st['parallax_err'])
+    lnprior = sp[5]
+    res = {}
+    names = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds "
+             "dreds logwts").split()
+    mem = [8000., 8000., 4., 4.]
+    for i in range(4):
+        sl = slice(i, i + 1)
+        gen = BF._fit(st['flux'][sl].copy(), st['err'][sl].copy(), st['mask'][sl].copy(),
+                      parallax=st['parallax'][sl], parallax_err=st['parallax_err'][sl],
+                      Nmc_prior=12, lnprior=lnprior.copy(), lngalprior=galprior,
+                      data_coords=st['coords'][sl], wt_thresh=None, cdf_thresh=2e-3,
+                      rstate=np.random.RandomState(500 + i), Ndraws=40, mem_lim=mem[i])
+        r = next(gen)
+        for n, v in zip(names, r):
+            res.setdefault(n, []).append(np.asarray(v))
+        print("cdf fit star", i, "levid", r[7], "chi2min", r[8], "distinct models",
+              len(set(r[0].tolist())))
+    np.savez_compressed(
+        os.path.join(OUT, "fit_cdf.npz"), grid_nmodel=1500, grid_nfilt=6, grid_seed=33,
+        flux=st['flux'], err=st['err'], mask=st['mask'], parallax=st['parallax'],
+        parallax_err=st['parallax_err'], coords=st['coords'], lnprior=lnprior, seed0=500,
+        mem_lim=np.array(mem), **{k: np.array(v) for k, v in res.items()})
+
+
 def gen_helpers():
     rng = np.random.RandomState(5)
     A = rng.normal(size=(64, 3, 3))
@@ -514,6 +574,10 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
                              "cluster"]
+    if "init" in which:
+        gen_loglike_init()
+    if "cdf" in which:
+        gen_fit_cdf()
     if "ps1" in which:
         gen_ps1()
     if "dust" in which:
