@@ -68,6 +68,9 @@ def parse():
                          "leg reported beside the metric (0 = skip all end-to-end legs); "
                          "rank 0, N=1 only")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-survey-grid", action="store_true",
+                    help="skip the third block: the main configuration on SURVEY 8(d)'s own "
+                         "grid generator (synth.make_grid, random model order)")
     return ap.parse_args()
 
 
@@ -79,13 +82,23 @@ def cpu_baseline(config, nmodel, nfilt, budget_s):
     import subprocess
     cmd = [sys.executable, "-m", "oracle.cpu_bench", "--config", str(config),
            "--nmodel", str(nmodel), "--nfilt", str(nfilt), "--seconds", str(budget_s)]
-    try:
-        out = subprocess.run(cmd, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+
+    def run(extra):
+        out = subprocess.run(cmd + extra, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE,
                              timeout=max(120., 10 * budget_s), check=True)
         return json.loads(out.stdout.decode().strip().splitlines()[-1])
+    try:
+        res = run([])            # all cores (up to 128 worker processes)
     except Exception as e:          # the GPU numbers stay valid without it
         return {"value": None, "unit": "stars/s", "cores": 0, "kind": "port",
                 "sample": "cpu baseline failed: %r" % (e,)}
+    try:
+        # ... and ONE core: a few stars on an otherwise idle host
+        res["single_core"] = run(["--single-stars", "4"])
+    except Exception as e:
+        res["single_core"] = {"value": None, "sample": "failed: %r" % (e,)}
+    res.setdefault("host_cores", os.cpu_count())
+    return res
 
 
 def end_to_end(models, grid, stars, n, kw, with_par):
@@ -339,6 +352,14 @@ WORKLOADS = {
     2: "configs[1]: 750k-model x 12-band grid, Av-only solve (rvlim=(3.32,3.32)), no parallax",
     3: "configs[2]: 750k-model x 12-band grid, Av+Rv free, parallax prior",
 }
+# the two synthetic grid generators (brutus_amd/synth.py).  BASELINE.json's configs name a
+# "MIST grid": lattice-ordered in (mini, eep, feh) like the real grid files -> `mist_like`,
+# the headline; SURVEY 8(d) spells out a generator with models in RANDOM order -> `survey8d`,
+# reported as a third block (no index locality: the worst case for the list kernels).
+GRIDS = {
+    "mist_like": "synth.make_mist_like_grid (lattice-ordered like the MIST grid files)",
+    "survey8d": "synth.make_grid (SURVEY 8(d) generator: random model order)",
+}
 
 # algorithmic bytes of one kernel launch: what the kernel has to
 # move at the very least for the work it is given.  g = grid bytes per star (108 MB at
@@ -395,15 +416,17 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
                                 stars["parallax_err"][sl] if with_par else None))
     # record buffers sized once, before the clock starts (grow=False: a batch that does not
     # fit fails the run instead of silently repeating work inside the timed region)
+    # record buffers sized before the clock starts: generously here, by the warm-up steps
+    # where that is not enough; a growth inside the timed region (= a batch done twice)
+    # fails the run instead of passing as a slow step
     cap = max(32 << 20, int(SB * nmodel * 0.62))
-    rec_bufs = [engines[j]._record_buffers(cap) for j in range(NS)]
+    for en in engines:
+        en._rec_bufs = en._record_buffers(cap)
     streams = [torch.cuda.Stream(device=dev) for _ in range(NS)]
 
     def one(i, j=0):
         f, e, m, p, pe, hp = subs[i % len(subs)]
-        out = engines[j].fit_batch_device(f, e, m, p, pe, hp, params, buffers=rec_bufs[j],
-                                          grow=False)
-        return out
+        return engines[j].fit_batch_device(f, e, m, p, pe, hp, params)
 
     def run(n_sub, first=0):
         """n_sub consecutive sub-batches, dealt round-robin to NS host threads, each
@@ -436,11 +459,16 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         torch.cuda.synchronize()
 
     run(max(args.warmup * nsub, NS if args.warmup else 0))
+    if any(en.regrown for en in engines):       # buffers grew: once more, now at full size
+        run(NS)
     fence()
+    grown = [en.regrown for en in engines]
     t0 = time.perf_counter()
     out = run(len(subs))              # exactly `steps` steps (this rank's share of them)
     fence()
     dt = time.perf_counter() - t0
+    if [en.regrown for en in engines] != grown:
+        raise SystemExit("record buffers grew inside the timed region: timing invalid")
     nsel_total = int(out[0].counts[0])
     if world > 1:
         t = torch.tensor([dt], dtype=torch.float64, device=dev)
@@ -448,7 +476,8 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         dt = float(t.item())
     total_stars = nstars_job if strong else world * nstars_job
     res = {"value": total_stars / dt, "ms_per_step": dt / args.steps * 1e3,
-           "stars_timed_per_rank": mine, "selected_models_last_sub_batch": nsel_total}
+           "stars_timed_per_rank": mine, "selected_models_last_sub_batch": nsel_total,
+           "selected_fraction": nsel_total / float(int(subs[(len(subs) - 1)][0].shape[0]) * nmodel)}
 
     # ---- per-kernel durations (HIP events on the launch stream), after the timed
     # region and strictly sequential: with two streams the kernels of two sub-batches
@@ -474,12 +503,12 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
         res["kernels_ms"] = {k: float(np.mean(v)) for k, v in ktimes.items()}
         res["kernel_sub_batch"] = int(subs[0][0].shape[0])
         res["kernel_counts"] = [float(x) for x in np.mean(nsel_k, axis=0)]
-    del engines, rec_bufs, subs
+    del engines, subs
     torch.cuda.empty_cache()
     return res
 
 
-def roofline_of(res, args, config, world):
+def roofline_of(res, args, config, world, with_traffic=True):
     """SURVEY 8(d) / BASELINE.md section 4: achieved = stars/s x B_star (one float32
     read of the grid per star = 108.0 MB at 750k x 12) against the 8 TB/s HBM peak,
     for the WHOLE step.  The per-kernel entries carry each kernel's own algorithmic
@@ -502,13 +531,14 @@ def roofline_of(res, args, config, world):
                 ab = alg(SB, g, pairs, res["kernel_counts"])
                 e.update(bound="f64 VALU issue" if name.startswith("k_fflux") else "hbm",
                          algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
-            e["traffic"] = measured_traffic(name, SB, config)    # None for grouped timer entries
+            e["traffic"] = measured_traffic(name, SB, config) if with_traffic else None
             kern[name] = e
         rl["kernels"] = kern
         dom = max(res["kernels_ms"], key=res["kernels_ms"].get)
         rl["dominant_kernel"] = dom
         rl["sum_of_kernels_ms_per_sub_batch"] = float(sum(res["kernels_ms"].values()))
-        traffic = measured_traffic("__total__", SB, config)
+        # (the PMC table was taken on the mist_like grid: no traffic figure for another grid)
+        traffic = measured_traffic("__total__", SB, config) if with_traffic else None
         if traffic:
             # PMC bytes of every kernel of one sub-batch call, scaled to one step
             rl["traffic"] = traffic * (float(args.batch) / SB)
@@ -566,6 +596,18 @@ def main():
     if not args.single_config:
         res_other = run_config(other_cfg, args, L, grid, models, dev, world, rank, dist, torch)
 
+    # the same configuration on the grid SURVEY 8(d) specifies (random model order)
+    res_8d = None
+    if not args.no_survey_grid:
+        m8, _, _ = synth.make_grid(nmodel, nfilt)
+        g8 = fitting.DeviceGrid(m8, device=dev) if rank == 0 or world == 1 else None
+        if world > 1:
+            from brutus_amd import parallel
+            g8 = parallel.broadcast_grid(g8 if rank == 0 else None, nmodel, nfilt, dev, src=0)
+        res_8d = run_config(main_cfg, args, L, g8, m8, dev, world, rank, dist, torch)
+        del g8, m8
+        torch.cuda.empty_cache()
+
     # measured on this box beside the 8 TB/s spec figure: the guide's reference stream
     # (device copy, 16 B per lane; MI355X_MICROARCH.md quotes 6.29 TB/s for it)
     stream_gbs = None
@@ -590,8 +632,10 @@ def main():
             dist.destroy_process_group()
         return
 
-    def cfg_block(cfg, r):
-        return {"workload": WORKLOADS[cfg], "nmodel": nmodel, "nfilt": nfilt,
+    def cfg_block(cfg, r, grid_name="mist_like"):
+        return {"workload": WORKLOADS[cfg] + "; grid = " + GRIDS[grid_name],
+                "grid_generator": grid_name, "selected_fraction": r["selected_fraction"],
+                "nmodel": nmodel, "nfilt": nfilt,
                 "stars_per_step": args.batch, "sub_batch": args.sub_batch,
                 "distinct_stars_timed_per_rank": r["stars_timed_per_rank"],
                 "timed_region": "brutus_fit_batch: device-resident star vectors -> "
@@ -617,6 +661,11 @@ def main():
             "value": res_other["value"], "unit": "stars/s", "ms_per_step": res_other["ms_per_step"],
             "config": cfg_block(other_cfg, res_other),
             "roofline": roofline_of(res_other, args, other_cfg, world)}
+    if res_8d is not None:
+        line["survey8d_grid"] = {
+            "value": res_8d["value"], "unit": "stars/s", "ms_per_step": res_8d["ms_per_step"],
+            "config": cfg_block(main_cfg, res_8d, "survey8d"),
+            "roofline": roofline_of(res_8d, args, main_cfg, world, with_traffic=False)}
     if world == 1 and args.e2e_stars > 0:
         kw = dict(rvlim=(3.32, 3.32)) if main_cfg == 2 else dict()
         line["fit_end_to_end"] = end_to_end(models, grid, None, args.e2e_stars, kw, main_cfg == 3)

@@ -52,10 +52,22 @@ def main():
     ap.add_argument("--nfilt", type=int, default=12)
     ap.add_argument("--seconds", type=float, default=20.)
     ap.add_argument("--procs", type=int, default=0)
+    ap.add_argument("--single-stars", type=int, default=0,
+                    help="instead of the pool: this many stars one after the other in THIS "
+                         "process, one thread (the single-core figure)")
     a = ap.parse_args()
     procs = a.procs or max(1, min(os.cpu_count() or 1, 128))
     # the grid is built once in the parent and inherited by fork (copy-on-write)
     _init(a.nmodel, a.nfilt, a.config)
+    if a.single_stars > 0:
+        t0 = time.time()
+        per = [_work(i) for i in range(a.single_stars)]
+        dt = time.time() - t0
+        print(json.dumps({"value": a.single_stars / dt, "unit": "stars/s", "cores": 1, "kind": "port",
+                          "sample": "%d stars x %d models x %d bands in %.1f s, one process, one "
+                                    "thread (C restatement oracle/loglike_ref.c; %.2f s per star)"
+                                    % (a.single_stars, a.nmodel, a.nfilt, dt, float(np.mean(per)))}))
+        return
     ctx = mp.get_context("fork")
     with ctx.Pool(procs) as pool:
         t0 = time.time()
@@ -65,6 +77,7 @@ def main():
             n += procs
         dt = time.time() - t0
     print(json.dumps({"value": n / dt, "unit": "stars/s", "cores": procs, "kind": "port",
+                      "host_cores": os.cpu_count(),
                       "sample": "%d stars x %d models x %d bands in %.1f s (C restatement "
                                 "oracle/loglike_ref.c, %d worker processes, one serial star "
                                 "each; mean %.2f s per star per core)"
