@@ -68,6 +68,8 @@ def parse():
                          "leg reported beside the metric (0 = skip all end-to-end legs); "
                          "rank 0, N=1 only")
     ap.add_argument("--no-kernel-timing", action="store_true")
+    ap.add_argument("--no-cluster", action="store_true",
+                    help="skip the cluster-mode block (BASELINE configs[4]) of the default line")
     ap.add_argument("--no-survey-grid", action="store_true",
                     help="skip the third block: the main configuration on SURVEY 8(d)'s own "
                          "grid generator (synth.make_grid, random model order)")
@@ -228,7 +230,7 @@ def _init_pg(dist, rank, world, dev):
         dist.init_process_group(backend, rank=rank, world_size=world)
 
 
-def bench_cluster(args):
+def bench_cluster(args, emit=True):
     """BASELINE configs[4]: one `isochrone_loglike` evaluation = 5 000 objects x
     12 bands against 15 mass-fraction slices x 2 000 EEP points (SURVEY 8d,
     config 5).  A step is one whole call (host unpacking + isochrone table +
@@ -244,7 +246,7 @@ def bench_cluster(args):
     local_rank = _local_device(local_rank)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 and emit:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         _init_pg(dist, rank, world, dev)
     L = _lib.lib()
@@ -342,10 +344,11 @@ def bench_cluster(args):
                                 "cores": 1, "kind": "port",
                                 "sample": "oracle numpy restatement on %d of the %d objects "
                                           "(%.1f s), scaled to a full evaluation" % (sub, nobj, dc)}
-    if rank == 0:
+    if rank == 0 and emit:
         print(json.dumps(line))
-    if world > 1:
+    if world > 1 and emit:
         dist.destroy_process_group()
+    return line
 
 
 WORKLOADS = {
@@ -671,6 +674,15 @@ def main():
         line["fit_end_to_end"] = end_to_end(models, grid, None, args.e2e_stars, kw, main_cfg == 3)
     if world == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(main_cfg, nmodel, nfilt, args.cpu_seconds)
+    if world == 1 and not args.no_cluster:
+        # BASELINE configs[4] (cluster mode) rides along: < 1 s, so that the driver's own
+        # run times it too (`python bench.py --config 5` prints the same block as a line)
+        ca = argparse.Namespace(**vars(args))
+        ca.steps, ca.warmup, ca.cpu_seconds = 200, 20, 0.
+        try:
+            line["cluster_mode"] = bench_cluster(ca, emit=False)
+        except Exception as e:          # never at the expense of the headline line
+            line["cluster_mode"] = {"value": None, "error": repr(e)}
     print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()
