@@ -10,6 +10,7 @@ marginalisation over mass and mass fraction (cluster.py:379-407) -- runs in the
 HIP kernel `k_cluster` through `brutus_cluster_lnl`.
 """
 import collections
+import threading
 import warnings
 
 import numpy as np
@@ -28,6 +29,9 @@ _DEFAULT_SMF = (0., 0.2, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8,
 _DATA_CACHE = collections.OrderedDict()
 _TABLE_CACHE = collections.OrderedDict()
 _DATA_CACHE_MAX, _TABLE_CACHE_MAX = 4, 16
+# The cached entries own device / page-locked buffers that a call fills and reads: one
+# evaluation at a time (a sampler's chains on one GPU take turns anyway).
+_LOCK = threading.RLock()
 
 
 def clear_caches():
@@ -82,6 +86,18 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
                       eep_binary_max=480., smf_grid=None, eep_grid=None,
                       parallax=None, parallax_err=None, cluster_prob=0.95,
                       dim_prior=True, return_lnls=False, device=None, cache=True):
+    """See `_isochrone_loglike`; calls are serialised (the caches own the buffers a call
+    works in)."""
+    with _LOCK:
+        return _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets,
+                                  corr_params, mini_bound, eep_binary_max, smf_grid, eep_grid,
+                                  parallax, parallax_err, cluster_prob, dim_prior, return_lnls,
+                                  device, cache)
+
+
+def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, corr_params,
+                       mini_bound, eep_binary_max, smf_grid, eep_grid, parallax, parallax_err,
+                       cluster_prob, dim_prior, return_lnls, device, cache):
     """ln-likelihood of a co-eval stellar population.  Arguments, defaults and
     return value follow reference cluster.py:23-168: `theta` packs
     `(feh, loga, av, rv, dist[pc], fout)`, then per-band multiplicative offsets
@@ -92,8 +108,11 @@ def isochrone_loglike(theta, isochrone, phot, err, cluster_params='free',
     with `params['mini']` the initial-mass grid.
 
     Extensions: `device`; `cache` (default True) keeps the per-dataset terms and the
-    isochrone point tables of recent calls (`clear_caches()` drops them; the plug-in is
-    assumed deterministic).  A plug-in that also offers
+    isochrone point tables of recent calls (`clear_caches()` drops them).  A cached point
+    table is keyed by the plug-in object, its `cache_token` attribute (if any) and every
+    argument it was asked with: the plug-in is assumed deterministic, and one that is
+    MODIFIED IN PLACE must change its `cache_token` (or the caller clears the caches / passes
+    `cache=False`).  A plug-in that also offers
     `get_seds_grid(smf_grid=, ...same keywords...[, out=]) -> (seds (Nsmf, Neep, Nbands), mini)`
     is asked once per call instead of once per mass fraction (with `out=`, it fills the
     page-locked buffer the device copy starts from)."""
@@ -211,8 +230,13 @@ class _Dataset(object):
 def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
     from scipy.stats import chi2 as chisquare
     from .fitting import _torch
+    from .fitting import _torch as _t
+    torch_ = _t()
+    # (the RESOLVED device: `device=None` follows the current device of each call)
+    dev_key = str(torch_.device(device if device is not None
+                                else "cuda:%d" % torch_.cuda.current_device()))
     key = (_fingerprint(phot), _fingerprint(err), _fingerprint(parallax),
-           _fingerprint(parallax_err), bool(dim_prior), str(device))
+           _fingerprint(parallax_err), bool(dim_prior), dev_key)
     if cache:
         ds = _lru_get(_DATA_CACHE, key)
         if ds is not None:
@@ -296,7 +320,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     (cluster.py:336-366).  The plug-in's magnitudes go to the device as they are;
     `brutus_cluster_points` turns them into fluxes and drops the all-NaN points."""
     from .fitting import _stream_ptr
-    key = (id(isochrone), feh, loga, av, rv, dist,
+    key = (id(isochrone), getattr(isochrone, "cache_token", None), feh, loga, av, rv, dist,
            None if corr_coef is None else tuple(corr_coef), smf_grid.tobytes(),
            eep_grid.tobytes(), mini_bound, eep_binary_max, str(dev))
     if cache:

@@ -15,6 +15,9 @@ namespace {
 // lnl_o = logsumexp_c (lnl + lnw_c).  One lane = one object (its bands in
 // VGPRs), isochrone points are workgroup-uniform (LDS broadcasts); the point axis is
 // split over blockIdx.y and merged by k_cluster_merge (online logsumexp).
+// The sum runs in the linear domain: exp(lnl + lnw) = e^c0 w chi2^(k/2 - 1) e^(-chi2/2),
+// and k is an integer, so the power is a square root and up to four multiplications
+// instead of a logarithm; only e^(-chi2/2) is tracked against a running maximum.
 constexpr int CL_T = 256;      // objects per workgroup: four waves share one staged sub-slice
 
 template <int NB>
@@ -34,7 +37,7 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     const int p0 = blockIdx.y * pts_per_block;
-    const int p1 = min(npts, p0 + pts_per_block);
+    const int p1_ = min(npts, p0 + pts_per_block);
     const int o = blockIdx.x * CL_T + threadIdx.x;
     const bool live = o < nobj;
     const int oo = live ? o : 0;
@@ -46,11 +49,16 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     }
     const double cp = chi2_p[oo], ln0 = lnorm[oo];
     const double k = (double)ndim[oo];
-    const double c0 = -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.);
-    const double c1 = k / 2. - 1.;
+    // scipy.stats.chi2.logpdf(chi2, k) = c0 + (k/2 - 1) ln chi2 - chi2/2 (cluster.py:389),
+    // or -(chi2 + lnorm)/2 without the dimensionality prior: power n2 / 2 of chi2, n2 = k - 2
+    const double c0 = dim_prior ? -(k / 2.) * 0.69314718055994530942 - lgamma(k / 2.) : -0.5 * ln0;
+    const int n2 = dim_prior ? ndim[oo] - 2 : 0;
+    const bool odd = n2 & 1, neg = n2 < 0;
+    const int mp = neg ? 0 : n2 >> 1;                         // whole powers of chi2
+    const bool p1 = mp & 1, p2 = mp & 2, p4 = mp & 4, p8 = mp & 8;
     double m = -INFINITY, ssum = 0.;
-    for (int q0 = p0; q0 < p1; q0 += SUB) {
-        const int np = min(SUB, p1 - q0);
+    for (int q0 = p0; q0 < p1_; q0 += SUB) {
+        const int np = min(SUB, p1_ - q0);
         __syncthreads();                                   // previous sub-slice fully consumed
         for (int c = threadIdx.x; c < np; c += CL_T) {
             const double *src = pts_flux + (int64_t)(q0 + c) * nb;
@@ -60,7 +68,7 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
                 hole = hole || (v != v);
                 s_pts[c * STRIDE + b] = v;
             }
-            s_pts[c * STRIDE + NB] = pts_lnw[q0 + c];
+            s_pts[c * STRIDE + NB] = exp(pts_lnw[q0 + c]);       // weight (0 for a dropped point)
             s_pts[c * STRIDE + NB + 1] = hole ? 1. : 0.;
         }
         __syncthreads();
@@ -88,22 +96,27 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
                 }
             }
             chi2 += cp;
-            double lnl;
-            if (dim_prior)   // scipy.stats.chi2.logpdf(chi2, k) (cluster.py:389)
-                lnl = c0 + (c1 == 0. ? 0. : c1 * fast_log_r(chi2)) - chi2 / 2.;
-            else
-                lnl = -0.5 * (chi2 + ln0);
-            if (!isfinite(lnl)) lnl = -INFINITY;             // cluster.py:394
-            // online logsumexp, one exponential per point
-            const double x = lnl + f[NB];
+            // w chi2^(n2 / 2)
+            double sq, rsq;
+            fast_sqrt_rsqrt(chi2, sq, rsq);
+            double T = f[NB] * (odd ? (neg ? rsq : sq) : 1.);
+            const double c2 = chi2 * chi2, c4 = c2 * c2;
+            T = p1 ? T * chi2 : T;
+            T = p2 ? T * c2 : T;
+            T = p4 ? T * c4 : T;
+            T = p8 ? T * (c4 * c4) : T;
+            // a non-finite or vanishing term contributes nothing (cluster.py:394)
+            const bool fin = T > 0. && T < INFINITY;
+            // online sum against the running maximum of -chi2/2, one exponential per point
+            const double x = -0.5 * chi2;
             const double dx = x - m;
             const double e = fast_exp_bf(-fabs(dx), s_tbl);
-            const bool up = dx > 0.;
-            const bool fin = x > -INFINITY;
-            ssum = up ? fma(ssum, e, 1.) : (fin ? ssum + e : ssum);
+            const bool up = fin && dx > 0.;
+            ssum = up ? fma(ssum, e, T) : (fin ? fma(T, e, ssum) : ssum);
             m = up ? x : m;
         }
     }
+    m += c0;          // (-inf stays -inf: no point with a finite term)
     if (live) {
         part_m[(int64_t)blockIdx.y * nobj + o] = m;
         part_s[(int64_t)blockIdx.y * nobj + o] = ssum;

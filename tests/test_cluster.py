@@ -138,6 +138,19 @@ def test_batched_plugin_hook_and_caches_change_nothing():
     phot2[5, 3] *= 1.5
     b = cluster.isochrone_loglike(THETA, iso, phot2, err, **kw)
     assert a[1][5] != b[1][5] and np.array_equal(np.delete(a[1], 5), np.delete(b[1], 5))
+    # a plug-in changed in place announces it through `cache_token`
+    class Shifted(NoHook):
+        shift = 0.
+
+        def get_seds(self, **kw):
+            seds, p1, p2 = self.iso.get_seds(**kw)
+            return seds + self.shift, p1, p2
+    plug = Shifted(iso)
+    v0 = cluster.isochrone_loglike(THETA, plug, phot, err, **kw)
+    plug.shift, plug.cache_token = 0.05, 1
+    v1 = cluster.isochrone_loglike(THETA, plug, phot, err, **kw)
+    v1_ref = cluster.isochrone_loglike(THETA, plug, phot, err, cache=False, **kw)
+    assert abs(v1[0] - v0[0]) > 1e-3 and relerr(v1_ref[1], v1[1]) < 1e-12
 
 
 def test_cache_keys_follow_content_not_identity():
