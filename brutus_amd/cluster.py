@@ -357,6 +357,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
         if mags is not h_mags:
             h_mags[...] = mags
         stage.d_mags.copy_(stage.h_mags, non_blocking=True)
+        late = eep_grid > eep_binary_max                    # evolved stars: first slice only
         if mini.ndim == 1:      # one mass grid for all slices: 2 000 logarithms, not 30 000
             gmini = np.gradient(mini)
             lng = np.where(gmini > 0., np.log(gmini), -np.inf)
@@ -366,7 +367,6 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
             gmini = np.gradient(mini, axis=1)
             keep = gmini > 0.
             lnw = np.where(keep, np.log(gmini) + np.log(grad_smf)[:, None], -np.inf)
-        late = eep_grid > eep_binary_max                    # evolved stars: first slice only
         keep[1:, late] = False
         lnw[1:, late] = -np.inf
     tab = None
@@ -377,8 +377,14 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
         if stage.src is None or not np.array_equal(stage.src, src):
             stage.src, stage.t_src = src, up(src, np.int32)     # the kept rows rarely change
         t_src = stage.t_src
-        t_flux = torch.empty((src.size, Nbands), dtype=torch.float64, device=dev)
-        t_lnw = torch.empty(src.size, dtype=torch.float64, device=dev)
+        if cache:      # a cached table keeps its tensors; without the cache one pair is reused
+            t_flux = torch.empty((src.size, Nbands), dtype=torch.float64, device=dev)
+            t_lnw = torch.empty(src.size, dtype=torch.float64, device=dev)
+        else:
+            if getattr(stage, "t_flux", None) is None:
+                stage.t_flux = torch.empty((nsmf * neep, Nbands), dtype=torch.float64, device=dev)
+                stage.t_lnw = torch.empty(nsmf * neep, dtype=torch.float64, device=dev)
+            t_flux, t_lnw = stage.t_flux[:src.size], stage.t_lnw[:src.size]
         _lib.check(L.brutus_cluster_points(src.size, Nbands, t_src.data_ptr(),
                                            stage.d_mags.data_ptr(), stage.d_lnw.data_ptr(),
                                            t_flux.data_ptr(), t_lnw.data_ptr(),
