@@ -97,6 +97,9 @@ def _lib():
         "H5Tget_array_dims2": (C.c_int, [hid_t, C.POINTER(hsize_t)]),
         "H5Tget_super": (hid_t, [hid_t]),
         "H5free_memory": (herr_t, [C.c_void_p]),
+        "H5Pcreate": (hid_t, [hid_t]),
+        "H5Pset_obj_track_times": (herr_t, [hid_t, C.c_uint]),
+        "H5Pclose": (herr_t, [hid_t]),
         "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]),
         "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
         "H5Gclose": (herr_t, [hid_t]),
@@ -110,6 +113,11 @@ def _lib():
         fn.argtypes = args
     L.H5open()
     L.H5Eset_auto2(0, None, None)   # we raise Python exceptions instead
+    # dataset creation properties: no object timestamps (h5py's default `track_times=False`,
+    # i.e. what the reference's files look like; it also makes two runs byte-identical)
+    L._dcpl = L.H5Pcreate(hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value)
+    if L._dcpl < 0 or L.H5Pset_obj_track_times(L._dcpl, 0) < 0:
+        L._dcpl = H5P_DEFAULT
     _h5 = L
     return L
 
@@ -240,7 +248,7 @@ class _File(object):
         dims = (hsize_t * len(shape))(*shape)
         sid = _check(L.H5Screate_simple(len(shape), dims, None), "H5Screate_simple")
         did = _check(L.H5Dcreate2(self.fid, name.encode(), tid, sid, H5P_DEFAULT,
-                                  H5P_DEFAULT, H5P_DEFAULT), "H5Dcreate2 " + name)
+                                  L._dcpl, H5P_DEFAULT), "H5Dcreate2 " + name)
         if data.size:
             _check(L.H5Dwrite(did, tid, H5S_ALL, H5S_ALL, H5P_DEFAULT,
                               data.ctypes.data_as(C.c_void_p)), "H5Dwrite " + name)
@@ -256,7 +264,7 @@ class _File(object):
         dims = (hsize_t * len(shape))(*shape)
         sid = _check(L.H5Screate_simple(len(shape), dims, None), "H5Screate_simple")
         did = _check(L.H5Dcreate2(self.fid, name.encode(), tid, sid, H5P_DEFAULT,
-                                  H5P_DEFAULT, H5P_DEFAULT), "H5Dcreate2 " + name)
+                                  L._dcpl, H5P_DEFAULT), "H5Dcreate2 " + name)
         L.H5Sclose(sid)
         self._dsets[name] = (did, tid, close, tuple(shape), dt)
         blk = np.full((min(block_rows, shape[0]),) + tuple(shape[1:]), fill, dtype=dt)
@@ -443,15 +451,25 @@ class ResultsFile(object):
                 lay[k] = (nd, "float32", 1, 9 + j)
         return lay
 
+    @classmethod
+    def row_dtype(cls, Ndraws, save_dar_draws):
+        """(structured dtype of ONE object's row -- every dataset's slice, in the file's own
+        dtypes --, [(dataset, position in the yielded tuple)]): the packed form in which
+        `parallel.fit_sharded` ships finished rows between ranks."""
+        self = cls.__new__(cls)
+        self.Ndraws, self.save_dar_draws = Ndraws, save_dar_draws
+        lay = self._layout()
+        return (np.dtype([(k, dt, rs) for k, (rs, dt, _, _) in lay.items()]),
+                [(k, pos) for k, (_, _, _, pos) in lay.items()])
+
     def __init__(self, path, Ndata, Ndraws, data_labels, save_dar_draws,
-                 running_io=True, flush_every=256):
+                 running_io=True, flush_every=256, async_io=True):
         self.file = _File(path, "w-")
         self.Ndata, self.Ndraws = Ndata, Ndraws
         self.running_io = running_io
         self.flush_every = max(1, int(flush_every))
         self.save_dar_draws = save_dar_draws
         self.layout = self._layout()
-        self._pend = {}
         self.arrays = None
         if data_labels is not None:
             self.file.create_dataset("labels", np.asarray(data_labels))
@@ -459,9 +477,98 @@ class ResultsFile(object):
             for k, (rs, dt, fill, _) in self.layout.items():
                 self.file.create_filled(k, (Ndata,) + rs, dt, fill)
             self.file.flush()
+            self._start_writer(async_io)
         else:
             self.arrays = {k: np.full((Ndata,) + rs, fill, dtype=dt)
                            for k, (rs, dt, fill, _) in self.layout.items()}
+
+    # -- staging ring + writer thread ------------------------------------------------------
+    # Finished rows are written IN PLACE into one of a few preallocated blocks (one array of
+    # `flush_every` rows per dataset, in the file's dtypes: nothing is allocated per row);
+    # a full block is handed to a background thread that turns it into hyperslab writes
+    # (libhdf5 is the thread-safe build and ctypes drops the GIL around its calls) while the
+    # caller fills the next one.  The caller only ever waits when ALL blocks are in flight,
+    # i.e. when the disk is slower than the fit.
+    NBLOCKS = 3
+
+    class _Block(object):
+        def __init__(self, layout, cap):
+            self.arr = {k: np.empty((cap,) + rs, dtype=dt) for k, (rs, dt, _, _) in layout.items()}
+            self.rows = np.empty(cap, dtype=np.int64)
+            self.n = 0
+
+    def _start_writer(self, async_io=True):
+        import queue
+        import threading
+        self._err = None
+        self._cur = None
+        self._free = queue.Queue()
+        self._full = queue.Queue(maxsize=self.NBLOCKS + 4)    # back-pressure on write_block
+        self._nblk = 0                  # blocks are allocated when first needed
+        self._async = bool(async_io)
+        self._thread = None
+        if self._async:
+            self._thread = threading.Thread(target=self._writer_loop, name="brutus-h5-writer",
+                                            daemon=True)
+            self._thread.start()
+
+    def _writer_loop(self):
+        while True:
+            job = self._full.get()
+            if job is None:
+                return
+            try:
+                if self._err is None:
+                    self._write_job(job)
+            except BaseException as e:          # surfaces at the next write_row / close
+                self._err = e
+            finally:
+                if isinstance(job, ResultsFile._Block):
+                    job.n = 0
+                    self._free.put(job)
+                self._full.task_done()
+
+    def _write_job(self, job):
+        if isinstance(job, ResultsFile._Block):
+            n = job.n
+            rows = job.rows[:n]
+            if n and np.all(rows[1:] == rows[:-1] + 1):      # the usual case: one ascending run
+                for k in self.layout:
+                    self.file.write_rows(k, int(rows[0]), job.arr[k][:n])
+            elif n:
+                order = np.argsort(rows, kind="stable")
+                srt = rows[order]
+                cuts = np.flatnonzero(srt[1:] != srt[:-1] + 1) + 1
+                for a, b in zip(np.r_[0, cuts], np.r_[cuts, n]):
+                    for k in self.layout:
+                        self.file.write_rows(k, int(srt[a]), job.arr[k][order[a:b]])
+        else:                                   # (first row, {dataset: rows}) from write_block
+            start, blocks = job
+            for k in self.layout:
+                self.file.write_rows(k, start, blocks[k])
+        self.file.flush()
+
+    def _check_err(self):
+        if getattr(self, "_err", None) is not None:
+            e, self._err = self._err, None
+            raise e
+
+    def _next_block(self):
+        if self._nblk < self.NBLOCKS and self._free.empty():
+            self._nblk += 1
+            return ResultsFile._Block(self.layout, self.flush_every)
+        return self._free.get()                 # waits for the writer only when all are in flight
+
+    def _submit(self, job):
+        if self._async:
+            self._full.put(job)
+        else:
+            try:
+                self._write_job(job)
+            finally:
+                if isinstance(job, ResultsFile._Block):
+                    job.n = 0
+                    self._free.put(job)
 
     @classmethod
     def resume(cls, path, Ndata, Ndraws, save_dar_draws, flush_every=256):
@@ -474,8 +581,8 @@ class ResultsFile(object):
         self.running_io, self.flush_every = True, max(1, int(flush_every))
         self.save_dar_draws = save_dar_draws
         self.layout = self._layout()
-        self._pend = {}
         self.arrays = None
+        self._start_writer(True)
         try:
             first = None
             for k in self.layout:
@@ -492,44 +599,62 @@ class ResultsFile(object):
         return self
 
     def write_row(self, i, results):
+        """Row `i` <- one tuple of `BruteForce._fit` (mapping of reference
+        fitting.py:1735-1748)."""
         if self.arrays is not None:            # running_io=False: everything in RAM
             with np.errstate(over="ignore"):
                 for k, (_, _, _, pos) in self.layout.items():
                     self.arrays[k][i] = results[pos]
             return
-        row = {}
+        self._check_err()
+        blk = self._cur
+        if blk is None:
+            blk = self._cur = self._next_block()
+        n = blk.n
         with np.errstate(over="ignore"):   # -1e300 (out-of-bounds draw) -> -inf in f32, as h5py does
-            for k, (rs, dt, _, pos) in self.layout.items():
-                v = np.empty(rs, dtype=dt)
-                v[...] = results[pos]
-                row[k] = v
-        self._pend[int(i)] = row
-        if len(self._pend) >= self.flush_every:
-            self._flush_rows()
+            for k, (_, _, _, pos) in self.layout.items():
+                blk.arr[k][n] = results[pos]
+        blk.rows[n] = i
+        blk.n = n + 1
+        if blk.n >= self.flush_every:
+            self._cur = None
+            self._submit(blk)
 
-    def _flush_rows(self):
-        if not self._pend:
+    def write_block(self, start, blocks):
+        """Rows `start ..` <- `blocks[name]` (n, ...) arrays already in the layout's shapes
+        (any float / int dtype; e.g. the packed rows a rank hands over in `fit_sharded`).
+        The arrays belong to the writer from here on."""
+        if self.arrays is not None:
+            with np.errstate(over="ignore"):
+                for k in self.layout:
+                    self.arrays[k][start:start + len(blocks[k])] = blocks[k]
             return
-        idx = sorted(self._pend)
-        # contiguous runs of row numbers -> one hyperslab write per dataset and run
-        runs, a = [], 0
-        for j in range(1, len(idx) + 1):
-            if j == len(idx) or idx[j] != idx[j - 1] + 1:
-                runs.append((a, j))
-                a = j
-        for a, b in runs:
-            for k in self.layout:
-                block = np.stack([self._pend[i][k] for i in idx[a:b]])
-                self.file.write_rows(k, idx[a], block)
-        self._pend.clear()
-        self.file.flush()
+        self._check_err()
+        self._submit((int(start), blocks))
+
+    def flush(self):
+        """Hand the partly filled block over and wait until everything is on disk."""
+        if self.arrays is not None:
+            return
+        if self._cur is not None and self._cur.n:
+            blk, self._cur = self._cur, None
+            self._submit(blk)
+        if self._async:
+            self._full.join()
+        self._check_err()
 
     def close(self):
         if self.file is None:
             return
         try:
             if self.arrays is None:
-                self._flush_rows()
+                try:
+                    self.flush()
+                finally:
+                    if self._thread is not None:
+                        self._full.put(None)
+                        self._thread.join()
+                        self._thread = None
             else:
                 for k, v in self.arrays.items():
                     self.file.create_dataset(k, v)

@@ -80,14 +80,18 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
 
     Every rank fits the contiguous shard `shard_range(Ndata, rank, world)` on
     its own GPU (no collective on the data path).  The rows go to rank 0 in
-    bounded pieces: in round k every rank hands over its next `chunk` objects
-    (`gather_object` of at most `chunk` rows per rank), rank 0 writes them at
-    their catalogue positions -- row `lo_r + k * chunk + j`, the mapping of
-    reference fitting.py:1734-1748 -- through the buffered `ResultsFile`, and
-    nothing else is kept: no rank ever holds more than `chunk` finished rows,
-    rank 0 no more than `world * chunk` (+ the writer's `flush_every`), whatever
-    the catalogue size.  With `running_io=True` (default) the file on disk is
-    current up to the last flush, so a crash loses at most one round.
+    bounded pieces: in round k every rank packs its next `chunk` objects into ONE
+    fixed-size byte block -- a structured array with the file's own dtypes
+    (`h5io.ResultsFile.row_dtype`), 18 KB per object at the defaults -- and the blocks
+    are gathered on rank 0 over a gloo SIDE GROUP (`dist.new_group(backend="gloo")`:
+    host memory to host memory; nothing is pickled and nothing passes through RCCL,
+    whose default group would stage pickled bytes in device buffers).  Rank 0 hands the
+    blocks to the asynchronous `ResultsFile` writer at their catalogue positions -- row
+    `lo_r + k * chunk + j`, the mapping of reference fitting.py:1734-1748 -- and nothing
+    else is kept: no rank ever holds more than `chunk` finished rows, rank 0 no more
+    than a few rounds of `world * chunk`, whatever the catalogue size.  With
+    `running_io=True` (default) the file on disk is current up to the last flush, so a
+    crash loses at most the rounds in flight.
 
     Object `i` draws from its own stream keyed `seed0 + i`, so the file is
     identical for any number of ranks (the reference's single sequential
@@ -149,28 +153,47 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         rstate_per_object="philox" if rng == "philox" else None, **fkw)
     bounds = [shard_range(Ndata, r, world) for r in range(world)]
     nround = (max(b - a for a, b in bounds) + chunk - 1) // chunk
+    import torch
     out = None
     if rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
                                data_labels, save_dar_draws,
                                running_io=running_io)
+    rowdt, positions = h5io.ResultsFile.row_dtype(Ndraws, save_dar_draws)
+    side = dist.new_group(backend="gloo") if world > 1 else None     # host-to-host hand-off
+    nbytes = 8 + chunk * rowdt.itemsize
     try:
         for k in range(nround):
-            mine = []
-            for _ in range(chunk):          # this rank's next piece (may be empty)
-                try:
-                    mine.append(next(gen))
-                except StopIteration:
-                    break
-            parts = [None] * world if rank == 0 else None
-            dist.gather_object(mine, parts, dst=0)
-            del mine
+            # this rank's next piece (may be empty), packed: [count i64][chunk rows]
+            block = np.zeros(nbytes, dtype=np.uint8)
+            rows = block[8:].view(rowdt)
+            n = 0
+            with np.errstate(over="ignore"):
+                for n in range(chunk + 1):
+                    if n == chunk:
+                        break
+                    try:
+                        res = next(gen)
+                    except StopIteration:
+                        break
+                    for name, pos in positions:
+                        rows[name][n] = res[pos]
+            block[:8].view(np.int64)[0] = n
+            if world == 1:
+                parts = [block]
+            else:
+                mine = torch.from_numpy(block)
+                got = ([torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
+                       if rank == 0 else None)
+                dist.gather(mine, got, dst=0, group=side)
+                parts = [g.numpy() for g in got] if rank == 0 else ()
             if rank == 0:
                 for r, part in enumerate(parts):
-                    base = bounds[r][0] + k * chunk
-                    for j, row in enumerate(part):
-                        out.write_row(base + j, row)
-                del parts
+                    cnt = int(part[:8].view(np.int64)[0])
+                    if cnt:
+                        prow = part[8:].view(rowdt)[:cnt]
+                        out.write_block(bounds[r][0] + k * chunk,
+                                        {name: prow[name] for name, _ in positions})
     finally:
         if hasattr(gen, "close"):
             gen.close()                     # shuts the scan-ahead helper thread down
