@@ -272,7 +272,12 @@ def photometric_offsets(phot, err, mask, models, idxs, reds, dreds, dists,
     `device` (not in the reference): a torch device (`"cuda"`, `"cuda:0"`) runs
     the SEDs, the leave-one-out weights and the bootstrap rounds in the HIP
     library (`brutus_offsets_weights`, `brutus_offsets_bootstrap`); `rstate` is
-    consumed exactly as on the host, so the same draws are made."""
+    consumed exactly as on the host (same uniforms, same `searchsorted` rule).  The
+    cumulative weights a uniform is looked up in are built differently, though: a
+    block-parallel scan of `exp(lnl - max)` on the device, a sequential `cumsum` of
+    `exp(lnl - logsumexp)` on the host, equal to a few ulp -- so a draw can differ where a
+    uniform falls within rounding of a cdf step (statistically equivalent; measured
+    agreement of the resulting offsets: 1e-11)."""
     import sys
     if device is not None:
         return _photometric_offsets_device(
@@ -387,6 +392,10 @@ def _photometric_offsets_device(phot, err, mask, models, idxs, reds, dreds, dist
     models = np.asarray(models)
     if models.ndim != 3 or models.shape[1] != Nfilt or models.shape[2] != 3:
         raise ValueError("models must have shape (Nmodel, Nfilt, 3)")
+    idxs = np.asarray(idxs)
+    if idxs.size and (idxs.min() < -models.shape[0] or idxs.max() >= models.shape[0]):
+        # (numpy's fancy indexing raises on the host path; the kernel would clamp)
+        raise IndexError("model index out of range for a grid of %d models" % models.shape[0])
     if models.dtype != np.float32:
         # the kernels read the float32 coefficients of `load_models` (utils.py:588-591)
         m32 = models.astype(np.float32)
