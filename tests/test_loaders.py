@@ -221,3 +221,92 @@ def test_photometric_offsets_vectorised_equals_call_by_call_form():
                                       rstate=np.random.RandomState(3))
         for x, y in zip(a, b):
             assert np.array_equal(x, y), dp
+
+
+def _rows(n, ndraws, seed=0):
+    rng = np.random.RandomState(seed)
+    out = []
+    for i in range(n):
+        v = rng.normal(size=ndraws)
+        out.append((rng.randint(0, 1000, ndraws), v, v + 1, v + 2, rng.normal(size=(ndraws, 3, 3)),
+                    6 + i % 3, v - 5, float(i), 2.5 * i, v * 2, v * 3, v * 4,
+                    np.where(v > 1, -1e300, v)))       # -1e300 -> -inf in float32, like h5py
+    return out
+
+
+def test_results_writer_async_equals_sync_any_row_order(tmp_path):
+    """The background writer (ring of preallocated blocks filled in place) writes the file
+    a synchronous writer does, byte for byte -- rows arriving in catalogue order, in a
+    scrambled order (sharded / resumed runs) and as whole blocks -- and `h5dump -H` shows the
+    reference's layout."""
+    import filecmp
+    import subprocess
+    from brutus_amd import h5io
+    n, nd = 1000, 7
+    rows = _rows(n, nd)
+    lab = np.arange(n)
+    paths = []
+    for tag, async_io, order in (("sync", False, np.arange(n)), ("async", True, np.arange(n)),
+                                 ("scrambled", True, np.random.RandomState(1).permutation(n))):
+        p = str(tmp_path / (tag + ".h5"))
+        rf = h5io.ResultsFile(p, n, nd, lab, True, flush_every=64, async_io=async_io)
+        for i in order:
+            rf.write_row(int(i), rows[i])
+        rf.close()
+        paths.append(p)
+    # packed blocks (parallel.fit_sharded's hand-off) through write_block
+    rowdt, positions = h5io.ResultsFile.row_dtype(nd, True)
+    p = str(tmp_path / "blocks.h5")
+    rf = h5io.ResultsFile(p, n, nd, lab, True, flush_every=64)
+    for a in range(0, n, 128):
+        blk = np.zeros(min(128, n - a), dtype=rowdt)
+        with np.errstate(over="ignore"):
+            for j in range(len(blk)):
+                for name, pos in positions:
+                    blk[name][j] = rows[a + j][pos]
+        rf.write_block(a, {name: blk[name] for name, _ in positions})
+    rf.close()
+    paths.append(p)
+    for q in paths[1:]:
+        assert filecmp.cmp(paths[0], q, shallow=False), q
+    assert np.array_equal(h5io.read_dataset(paths[1], "obj_log_evid"), np.arange(n, dtype=np.float32))
+    assert np.isneginf(h5io.read_dataset(paths[1], "samps_logp")).any()
+    h5dump = "/opt/conda/bin/h5dump"
+    if os.path.exists(h5dump):
+        hdr = subprocess.run([h5dump, "-H", paths[1]], stdout=subprocess.PIPE).stdout.decode()
+        for name, shape in (("model_idx", "( %d, %d )" % (n, nd)), ("ml_cov_sar", "( %d, %d, 3, 3 )" % (n, nd)),
+                            ("obj_Nbands", "( %d )" % n)):
+            assert 'DATASET "%s"' % name in hdr and shape in hdr
+        assert "H5T_STD_I32LE" in hdr and "H5T_IEEE_F32LE" in hdr and "H5T_STD_I16LE" in hdr
+
+
+def test_results_writer_reports_errors_of_the_background_thread(tmp_path):
+    """A failure inside the writer thread surfaces at the next call of the fit loop, it is
+    not swallowed."""
+    from brutus_amd import h5io
+    p = str(tmp_path / "err.h5")
+    rf = h5io.ResultsFile(p, 10, 3, None, False, flush_every=2)
+    rows = _rows(10, 3)
+    rf.write_row(0, rows[0])
+    rf.file.write_rows = lambda *a, **k: (_ for _ in ()).throw(OSError("disk full"))
+    rf.write_row(1, rows[1])            # hands a block to the writer, which fails
+    with pytest.raises(OSError):
+        rf.flush()
+    rf.file.close()
+    rf.file = None
+
+
+def test_los_tables_pad_shorter_profiles():
+    """Per-batch line-of-sight tables: profiles of different lengths are padded by their
+    last node, which leaves numpy.interp (and the device's interpolation) unchanged."""
+    from brutus_amd import pdf
+    prof = {0: (np.array([0.1, 1., 3.]), np.array([0.1, 0.5, 0.9]), np.array([0.1, 0.1, 0.2])),
+            1: (np.array([0.2, 2.]), np.array([0.3, np.nan]), np.array([0.1, 0.1]))}
+    q = lambda c: prof[int(c[0])]
+    los, ok = pdf.los_tables(q, np.array([[0., 0.], [1., 0.]]))
+    assert los.shape == (2, 3, 3) and ok.tolist() == [1, 0]
+    assert np.array_equal(los[1, 0], [0.2, 2., 2.])
+    d = np.linspace(0.05, 5., 50)
+    assert np.array_equal(np.interp(d, los[0, 0], los[0, 1]), np.interp(d, *prof[0][:2]))
+    with pytest.raises(ValueError):
+        pdf.los_tables(lambda c: (np.array([1.]), np.array([1.]), np.array([1.])), np.zeros((1, 2)))
