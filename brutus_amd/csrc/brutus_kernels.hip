@@ -1189,8 +1189,8 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
     }
 #undef BRUTUS_CL
     tm.end();
-    hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + 255) / 256), dim3(256), 0, st, nobj, nchunk, pm,
-                       ps, d_lnl);
+    hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + CM_O - 1) / CM_O), dim3(CM_O * CM_J), 0, st, nobj,
+                       nchunk, pm, ps, d_lnl);
     HIP_TRY(hipGetLastError());
     tm.collect();
     return 0;
