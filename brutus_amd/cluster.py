@@ -230,8 +230,10 @@ class _Dataset(object):
 def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
     from scipy.stats import chi2 as chisquare
     from .fitting import _torch
-    from .fitting import _torch as _t
-    torch_ = _t()
+    # the reference's data check comes before anything touches the device (cluster.py:296)
+    if np.any(np.sum(np.isfinite(phot) & np.isfinite(err), axis=1) == 0):
+        raise ValueError("At least one object has no valid data entries!")
+    torch_ = _torch()
     # (the RESOLVED device: `device=None` follows the current device of each call)
     dev_key = str(torch_.device(device if device is not None
                                 else "cuda:%d" % torch_.cuda.current_device()))
@@ -245,9 +247,7 @@ def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
     ds = _Dataset()
     ds.phot_mask = np.isfinite(phot) & np.isfinite(err)
     phot_n = np.sum(ds.phot_mask, axis=1)
-    if np.any(phot_n == 0):
-        raise ValueError("At least one object has no valid data entries!")
-    torch = _torch()
+    torch = torch_
     L = _lib.lib()
     dev = ds.dev = torch.device(device if device is not None
                                 else "cuda:%d" % torch.cuda.current_device())
