@@ -196,6 +196,16 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         mbar *= inv_nf;
 #pragma unroll
         for (int j = 0; j < NB; ++j) mc[j] -= mbar;
+        // per-tile products the star loop would otherwise redo for every star (pinned Rv):
+        // R^2 for sum w R^2, and the centred magnitudes pre-multiplied by -0.4 log2(10)
+        float R2[RVF ? NB : 1], mcC[RVF ? NB : 1];
+        if constexpr (RVF) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                R2[j] = R[j] * R[j];
+                mcC[j] = C10 * mc[j];
+            }
+        }
 #pragma unroll
         for (int g = 0; g < G; ++g) {
             if (g >= ng) break;
@@ -211,9 +221,9 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 for (int j = 0; j < NB; ++j) {
                     const float w = sp.w[j];
                     const float y = sp.gc[j] - mc[j];
-                    const float Rw = R[j] * w, yw = y * w;
-                    uR += Rw;
-                    RR = fmaf(R[j], Rw, RR);
+                    const float yw = y * w;
+                    uR = fmaf(R[j], w, uR);
+                    RR = fmaf(R2[j], w, RR);
                     yR = fmaf(R[j], yw, yR);
                     uy += yw;
                     yy = fmaf(y, yw, yy);
@@ -325,7 +335,7 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 den = 0.f;
 #pragma unroll
                 for (int j = 0; j < NB; ++j) {
-                    const float e = __builtin_amdgcn_exp2f(C10 * fmaf(av, R[j], mc[j]));
+                    const float e = __builtin_amdgcn_exp2f(fmaf(C10 * av, R[j], mcC[j]));
                     const float fw = e * sp.iv[j];
                     num = fmaf(sp.dd[j], fw, num);
                     den = fmaf(e, fw, den);
