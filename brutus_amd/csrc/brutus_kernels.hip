@@ -1825,6 +1825,21 @@ int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals
     return 0;
 }
 
+namespace zig_host {
+#define ZIG_TABLE_QUAL static const
+#include "zig_table.inc"
+#undef ZIG_TABLE_QUAL
+}   // namespace zig_host
+
+int brutus_debug_zig_table(double *h_x, double *h_y, int n) {
+    if (!h_x || !h_y || n != zig_host::ZIG_N + 1) return fail(BRUTUS_EINVAL, "bad arguments");
+    for (int k = 0; k < n; ++k) {
+        h_x[k] = zig_host::kZigX[k];
+        h_y[k] = zig_host::kZigY[k];
+    }
+    return 0;
+}
+
 int brutus_debug_galprior(const brutus_post_params *params, int n, const double *d_dist,
                           const double *d_coord, const double *d_feh, const double *d_loga,
                           double *d_out, void *stream) {

@@ -9,7 +9,7 @@ namespace {
 // ===========================================================================
 // lnpost on the device (fitting.py:1000-1107 and the tail of _fit, :2021-2061)
 // for the built-in priors, with the counter-based random stream specified in
-// brutus_amd/rng.py (Philox4x32-7 + polar normals): any deviate is a pure
+// brutus_amd/rng.py (Philox4x32-7 + ziggurat normals): any deviate is a pure
 // function of (seed, index), so every selected model of every object is
 // integrated in parallel and the result still equals, deviate for deviate, a
 // sequential run of the reference with that `rstate` object.
@@ -17,6 +17,10 @@ namespace {
 struct Philox4 {
     uint32_t w[4];
 };
+
+#define ZIG_TABLE_QUAL __device__ const
+#include "zig_table.inc"      // ZIG_N, kZigX[ZIG_N + 1], kZigY[ZIG_N + 1]
+#undef ZIG_TABLE_QUAL
 
 __device__ __forceinline__ Philox4 philox4x32_7(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3,
                                                 uint32_t k0, uint32_t k1) {
@@ -46,46 +50,76 @@ __device__ __forceinline__ double u53(uint32_t a, uint32_t b) {
 
 // q-th uniform of the uniform stream (rng.py: philox_uniform)
 __device__ __forceinline__ double rng_uniform(uint64_t seed, uint64_t q) {
-    const Philox4 o = philox4x32_7((uint32_t)q, (uint32_t)(q >> 32), 0u, 1u, (uint32_t)seed,
-                                   (uint32_t)(seed >> 32));
+    const Philox4 o = philox4x32_7((uint32_t)q, (uint32_t)(q >> 32), 0u, 1u /* STREAM_UNIFORM */,
+                                   (uint32_t)seed, (uint32_t)(seed >> 32));
     return u53(o.w[0], o.w[1]);
 }
 
-// candidate `retry` of pair p of the normal stream (rng.py: philox_normal);
-// true if the polar method accepts it
-__device__ __forceinline__ bool rng_polar_candidate(uint64_t seed, uint64_t p, uint32_t retry,
-                                                    double &x1, double &x2) {
-#pragma clang fp contract(off)   // r2 must round like numpy's x1*x1 + x2*x2 (accept/reject!)
-    const Philox4 o = philox4x32_7((uint32_t)p, (uint32_t)(p >> 32), retry, 0u, (uint32_t)seed,
-                                   (uint32_t)(seed >> 32));
-    x1 = 2.0 * u53(o.w[0], o.w[1]) - 1.0;
-    x2 = 2.0 * u53(o.w[2], o.w[3]) - 1.0;
-    const double r2 = x1 * x1 + x2 * x2;
-    return r2 < 1.0 && r2 > 0.0;
+// ---- normal stream (rng.py: philox_normal): ziggurat, 1024 layers, two normals per call ----
+constexpr uint32_t STREAM_NORMAL = 0u, STREAM_UNIFORM = 1u, STREAM_RETRY = 2u, STREAM_TAIL = 3u;
+
+// 64 random bits -> layer i, sign and x = u X[i]; true inside the layer's rectangle (99.57 %:
+// the normal is then +-x).  One multiplication: host and device round alike, the decision is
+// bit-exact.  `X` is kZigX or an LDS copy of it (stage_zig_table).
+__device__ __forceinline__ bool zig_try(uint32_t a, uint32_t b, const double *__restrict__ X,
+                                        double &x, int &i, bool &neg) {
+    i = (int)(b & (uint32_t)(ZIG_N - 1));
+    neg = (b >> 10) & 1u;
+    const double u = ldexp((double)a * 2097152.0 + (double)(b >> 11), -53);     // exact
+    x = u * X[i];
+    return x < X[i + 1];
 }
-// the two normals of an accepted candidate
-__device__ __forceinline__ void rng_polar_finish(double x1, double x2, double &z0, double &z1) {
-#pragma clang fp contract(off)
-    const double r2 = x1 * x1 + x2 * x2;
-    // rng.py: f = sqrt(-2 ln(r2) / r2).  ln, the divide and the root are the ~1 ulp
-    // Newton forms (the accept / reject decision above is what must be exact): the
-    // normals agree with numpy's to a few ulp at a third of the IEEE sequences' cost.
-    const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));
-    z0 = f * x1;
-    z1 = f * x2;
+__device__ __forceinline__ Philox4 philox_at(uint64_t seed, uint64_t idx, uint32_t c2, uint32_t stream) {
+    return philox4x32_7((uint32_t)idx, (uint32_t)(idx >> 32), c2, stream, (uint32_t)seed,
+                        (uint32_t)(seed >> 32));
 }
-// pair p of the normal stream: z0 = normal 2p, z1 = normal 2p+1
-__device__ __forceinline__ void rng_normal_pair(uint64_t seed, uint64_t p, double &z0, double &z1) {
-    // The retry loop only draws candidates (lanes of a wave retry in lockstep:
-    // ~3.5 rounds for 64 lanes at 21 % rejection); ln / sqrt / divide run once.
-    double x1, x2;
-    for (uint32_t retry = 0; !rng_polar_candidate(seed, p, retry, x1, x2); ++retry) {}
-    rng_polar_finish(x1, x2, z0, z1);
+// normal j whose attempt 0 (layer i, x, sign) fell outside the rectangle: wedge test or tail,
+// further attempts (rng.py).  0.43 % of the normals come here; ocml's exp / log.
+__device__ __forceinline__ double zig_slow(uint64_t seed, uint64_t j, double x, int i, bool neg) {
+#pragma clang fp contract(off)     // Y[i] + u2 (Y[i+1] - Y[i]) rounds like numpy's
+    for (uint32_t r = 0;; ++r) {
+        const Philox4 v = philox_at(seed, j, r, STREAM_RETRY);
+        if (r > 0 && zig_try(v.w[0], v.w[1], kZigX, x, i, neg)) break;
+        if (i == 0) {
+            const double R = kZigX[1];
+            for (uint32_t k = 0;; ++k) {
+                const Philox4 t = philox_at(seed, j, (r << 16) | k, STREAM_TAIL);
+                const double xt = -log(1.0 - u53(t.w[0], t.w[1])) / R;
+                const double yt = -log(1.0 - u53(t.w[2], t.w[3]));
+                if (yt + yt > xt * xt) {
+                    x = R + xt;
+                    break;
+                }
+            }
+            break;
+        }
+        const double u2 = u53(v.w[2], v.w[3]);
+        const double yl = kZigY[i] + u2 * (kZigY[i + 1] - kZigY[i]);
+        if (yl < exp(-0.5 * x * x)) break;
+    }
+    return neg ? -x : x;
+}
+// the two normals 2q, 2q + 1 of call q
+__device__ __forceinline__ void rng_normal_call(uint64_t seed, uint64_t q, const double *__restrict__ X,
+                                                double &z0, double &z1) {
+    const Philox4 o = philox_at(seed, q, 0u, STREAM_NORMAL);
+    double x0, x1;
+    int i0, i1;
+    bool n0, n1;
+    const bool f0 = zig_try(o.w[0], o.w[1], X, x0, i0, n0), f1 = zig_try(o.w[2], o.w[3], X, x1, i1, n1);
+    z0 = n0 ? -x0 : x0;
+    z1 = n1 ? -x1 : x1;
+    if (!f0) z0 = zig_slow(seed, 2 * q, x0, i0, n0);
+    if (!f1) z1 = zig_slow(seed, 2 * q + 1, x1, i1, n1);
 }
 __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t j) {
     double z0, z1;
-    rng_normal_pair(seed, j >> 1, z0, z1);
+    rng_normal_call(seed, j >> 1, kZigX, z0, z1);
     return (j & 1) ? z1 : z0;
+}
+// copy kZigX to LDS (ZIG_N + 1 doubles); follow with __syncthreads()
+__device__ __forceinline__ void stage_zig_table(double *lds_x) {
+    for (int k = threadIdx.x; k <= ZIG_N; k += blockDim.x) lds_x[k] = kZigX[k];
 }
 
 struct PostParams {     // mirrors brutus_post_params
@@ -465,7 +499,7 @@ k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const int32_t 
     }
 }
 
-// Sequential reader of normals j0, j0+1, ...: each Philox pair is generated once.
+// Sequential reader of normals j0, j0+1, ...: each Philox call is evaluated once.
 struct NormalReader {
     uint64_t seed, p;
     double z0, z1;
@@ -481,7 +515,7 @@ struct NormalReader {
         if (zs) return zs[j];
         const uint64_t q = j >> 1;
         if (!have || q != p) {
-            rng_normal_pair(seed, q, z0, z1);
+            rng_normal_call(seed, q, kZigX, z0, z1);
             p = q;
             have = true;
         }
@@ -532,22 +566,24 @@ __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (
     return v;
 }
 
-// rows (polar pairs) of a k_post_mc staging slot: the 3 nmc normals of a record
-// span at most 3 nmc / 2 + 1 pairs
+// rows (Philox calls = pairs of normals) of a k_post_mc staging slot: the 3 nmc normals of a
+// record span at most 3 nmc / 2 + 1 calls
 __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2; }
 
 // P4: Monte Carlo prior integral of every kept record (fitting.py:1068-1105)
 // and chi2min (fitting.py:2025-2034).  One lane per record.
 //
 // The 3 nmc normals of a record are one contiguous run of the stream, i.e.
-// ~3 nmc / 2 polar pairs.  A lane first walks its pairs with its own retry
-// counter and stores the two normals of each accepted candidate in its column
-// of `zs` (lane-interleaved rows of double2; 16-byte stores: the staging is
-// bound by L2 write requests, lanes drift apart in row) -- a
-// wave then spends ~1/0.785 Philox rounds per pair instead of the ~3.7 it takes
-// until all 64 lanes of a lockstep retry loop have accepted -- and afterwards
-// integrates, reading three normals per sample.
-//
+// ~3 nmc / 2 Philox calls of two normals each.  A lane first walks its calls: 99.57 % of
+// the normals are the ziggurat's rectangle case (a table look-up in LDS, one
+// multiplication, one comparison); a call with a normal outside is noted in the lane's
+// pending list (LDS, MC_PEND rows per lane) and redone by the slow path afterwards, so
+// that the wedge / tail code runs max-over-lanes(pending) ~ 3 times per 64 records and
+// not whenever one of 64 lanes needs it (every third call).  The two normals of a call
+// go to the lane's column of `zs` as one 16-byte store (lane-interleaved rows of
+// double2); afterwards the lane integrates, reading three normals per sample.
+constexpr int MC_PEND = 8;
+
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
           const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
@@ -561,7 +597,10 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
     __shared__ unsigned int s_item;
+    __shared__ double s_zx[ZIG_N + 1];
+    __shared__ unsigned short s_pend[MC_PEND][TILE];
     stage_exp_table(s_tbl);
+    stage_zig_table(s_zx);
     double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
     for (;;) {
         __syncthreads();
@@ -596,21 +635,30 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     if (live)
                         for (uint64_t p = p_lo; p <= p_hi; ++p) col[(int64_t)(p - p_lo) * TILE] = zsrc[p];
                 } else {
-                    const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
-                    uint64_t p = live ? p_lo : p_hi + 1;
-                    uint32_t retry = 0;
-                    while (p <= p_hi) {
-                        double x1, x2;
-                        if (rng_polar_candidate(seed, p, retry, x1, x2)) {
-                            double z0, z1;
-                            rng_polar_finish(x1, x2, z0, z1);
-                            col[(int64_t)(p - p_lo) * TILE] = make_double2(z0, z1);
-                            ++p;
-                            retry = 0;
+                    const int nrow = live ? (int)(((j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1) - p_lo) + 1 : 0;
+                    // both normals of row `row` by the full algorithm (slow path where needed)
+                    auto redo = [&](int row) {
+                        double z0, z1;
+                        rng_normal_call(seed, p_lo + (uint64_t)row, s_zx, z0, z1);
+                        col[(int64_t)row * TILE] = make_double2(z0, z1);
+                    };
+                    int npend = 0;
+                    for (int row = 0; row < nrow; ++row) {
+                        const Philox4 w4 = philox_at(seed, p_lo + (uint64_t)row, 0u, STREAM_NORMAL);
+                        double x0, x1;
+                        int i0, i1;
+                        bool n0, n1;
+                        const bool f0 = zig_try(w4.w[0], w4.w[1], s_zx, x0, i0, n0),
+                                   f1 = zig_try(w4.w[2], w4.w[3], s_zx, x1, i1, n1);
+                        if (f0 && f1) {
+                            col[(int64_t)row * TILE] = make_double2(n0 ? -x0 : x0, n1 ? -x1 : x1);
+                        } else if (npend < MC_PEND) {
+                            s_pend[npend++][threadIdx.x] = (unsigned short)row;
                         } else {
-                            ++retry;
+                            redo(row);
                         }
                     }
+                    while (npend > 0) redo((int)s_pend[--npend][threadIdx.x]);
                 }
                 if (live) {
                     const int64_t r = sel_off[s] + rp.src[o];

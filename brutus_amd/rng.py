@@ -8,12 +8,20 @@ provides the `normal`, `choice` and `random_sample` methods the reference
 calls, so the *reference itself* runs unchanged with it) whose j-th normal and
 q-th uniform are pure functions of `(seed, j)` / `(seed, q)`:
 
-    Philox4x32-7, key = the 64-bit seed, counter = (index lo, index hi, retry, stream)
+    Philox4x32-7, key = the 64-bit seed, counter = (index lo, index hi, attempt, stream)
     uniform   u = ((w0 >> 5) * 2**26 + (w1 >> 6)) / 2**53       (numpy's 53-bit recipe)
-    normals   pair p = j >> 1: Marsaglia polar method on (u1, u2) of counter
-              (p, retry), retry = 0, 1, ... until 0 < x1^2 + x2^2 < 1;
-              normal j is f*x1 (j even) or f*x2 (j odd), f = sqrt(-2 ln(r2) / r2);
-              r2 = x1*x1 + x2*x2 rounded without fused multiply-add
+    normal j  ziggurat with 1024 layers (table `_zigtab`, written by tools/gen_zig_table.py)
+              on 64 random bits (a, b):
+                  i = b & 1023, sign = bit 10 of b, u = (a * 2**21 + (b >> 11)) / 2**53,
+                  x = u * X[i];  x < X[i + 1] -> the normal is +-x          (99.57 %)
+              attempt 0 takes (a, b) = words (0, 1) [j even] or (2, 3) [j odd] of the call
+              with counter (j >> 1, 0, stream 0) -- two normals per Philox call; a later
+              attempt r takes words (0, 1) of the call (j, r, stream 2).  Outside the
+              rectangle: layer 0 is the tail x > R (Marsaglia: xt = -ln(1 - u1) / R,
+              yt = -ln(1 - u2) with the two uniforms of the call (j, r << 16 | k, stream 3),
+              k = 0, 1, ... until 2 yt > xt**2, the normal is +-(R + xt)); any other layer
+              is the wedge test Y[i] + u2 (Y[i+1] - Y[i]) < exp(-x**2 / 2) with u2 from
+              words (2, 3) of the call (j, r, stream 2), and on failure attempt r + 1.
 
 Because any deviate can be computed without the ones before it, the device can
 evaluate the Monte Carlo integral of every selected model of every object in
@@ -23,13 +31,15 @@ This file is the specification of that stream.
 """
 import numpy as np
 
+from ._zigtab import X as ZIG_X, Y as ZIG_Y, ZIG_N
+
 __all__ = ["PhiloxRandomState", "philox4x32", "philox_uniform", "philox_normal"]
 
 _M0, _M1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57)
 _W0, _W1 = np.uint64(0x9E3779B9), np.uint64(0xBB67AE85)
 _MASK = np.uint64(0xFFFFFFFF)
 ROUNDS = 7
-STREAM_NORMAL, STREAM_UNIFORM = 0, 1
+STREAM_NORMAL, STREAM_UNIFORM, STREAM_RETRY, STREAM_TAIL = 0, 1, 2, 3
 
 
 def philox4x32(c0, c1, c2, c3, k0, k1, rounds=ROUNDS):
@@ -62,28 +72,71 @@ def philox_uniform(seed, index):
     return _u53(o[0], o[1])
 
 
+def _philox_at(seed, lo64, c2, stream):
+    seed = np.uint64(seed)
+    return philox4x32(lo64 & _MASK, lo64 >> np.uint64(32), c2, np.full_like(lo64, stream),
+                      seed & _MASK, seed >> np.uint64(32))
+
+
+def _zig_try(a, b):
+    """(x, layer, negative, inside the layer's rectangle) from 64 random bits."""
+    i = (b & np.uint64(ZIG_N - 1)).astype(np.int64)
+    neg = ((b >> np.uint64(10)) & np.uint64(1)).astype(bool)
+    u = ((a * np.uint64(2097152) + (b >> np.uint64(11))).astype(np.float64)) / 9007199254740992.0
+    x = u * ZIG_X[i]
+    return x, i, neg, x < ZIG_X[i + 1]
+
+
 def philox_normal(seed, index):
     """Standard normal deviates number `index` (array) of the normal stream."""
     idx = np.asarray(index, dtype=np.uint64).ravel()
-    seed = np.uint64(seed)
-    pair, which = idx >> np.uint64(1), (idx & np.uint64(1)).astype(bool)
     out = np.empty(idx.shape, dtype=np.float64)
+    if idx.size == 0:
+        return out.reshape(np.shape(index))
+    odd = (idx & np.uint64(1)).astype(bool)
+    o = _philox_at(seed, idx >> np.uint64(1), np.zeros_like(idx), STREAM_NORMAL)
+    a, b = np.where(odd, o[2], o[0]), np.where(odd, o[3], o[1])
     todo = np.arange(idx.size)
-    retry = 0
-    while todo.size:
-        p = pair[todo]
-        o = philox4x32(p & _MASK, p >> np.uint64(32), np.full_like(p, retry),
-                       np.full_like(p, STREAM_NORMAL), seed & _MASK, seed >> np.uint64(32))
-        x1 = 2.0 * _u53(o[0], o[1]) - 1.0
-        x2 = 2.0 * _u53(o[2], o[3]) - 1.0
-        r2 = x1 * x1 + x2 * x2
-        ok = (r2 < 1.0) & (r2 > 0.0)
+    attempt = 0
+    R = ZIG_X[1]
+    while True:
+        x, i, neg, fast = _zig_try(a, b)
+        out[todo[fast]] = np.where(neg[fast], -x[fast], x[fast])
+        rest = ~fast
+        if not rest.any():
+            break
+        todo, x, i, neg = todo[rest], x[rest], i[rest], neg[rest]
+        j = idx[todo]
+        v = _philox_at(seed, j, np.full_like(j, attempt), STREAM_RETRY)
+        done = np.zeros(todo.size, dtype=bool)
+        # wedge of layers 1 .. N-1
+        wd = i > 0
+        u2 = _u53(v[2], v[3])
         with np.errstate(all="ignore"):
-            f = np.sqrt(-2.0 * np.log(r2[ok]) / r2[ok])
-        sel = todo[ok]
-        out[sel] = np.where(which[sel], f * x2[ok], f * x1[ok])
-        todo = todo[~ok]
-        retry += 1
+            ok = wd & (ZIG_Y[i] + u2 * (ZIG_Y[np.minimum(i + 1, ZIG_N)] - ZIG_Y[i]) < np.exp(-0.5 * x * x))
+        out[todo[ok]] = np.where(neg[ok], -x[ok], x[ok])
+        done |= ok
+        # tail beyond R (layer 0)
+        tl = np.nonzero(~wd)[0]
+        k = 0
+        while tl.size:
+            jt = j[tl]
+            t = _philox_at(seed, jt, np.full_like(jt, (attempt << 16) | k), STREAM_TAIL)
+            xt = -np.log(1.0 - _u53(t[0], t[1])) / R
+            yt = -np.log(1.0 - _u53(t[2], t[3]))
+            acc = yt + yt > xt * xt
+            hit = tl[acc]
+            out[todo[hit]] = np.where(neg[hit], -(R + xt[acc]), R + xt[acc])
+            done[hit] = True
+            tl = tl[~acc]
+            k += 1
+        if done.all():
+            break
+        todo = todo[~done]
+        attempt += 1
+        j = idx[todo]
+        v = _philox_at(seed, j, np.full_like(j, attempt), STREAM_RETRY)
+        a, b = v[0], v[1]
     return out.reshape(np.shape(index))
 
 

@@ -22,6 +22,10 @@ int brutus_debug_mt_stream(int nobj, int nstream, uint32_t *h_states,
 /* Test hooks for the two building blocks above. */
 int brutus_debug_rng(uint64_t seed, uint64_t start, int64_t n, double *d_normals,
                      double *d_uniforms, void *stream);
+/* The ziggurat layer table of the normal stream as compiled into the library (host
+ * copy of brutus_amd/csrc/zig_table.inc; n must be 1025): tests compare it with
+ * brutus_amd/_zigtab.py.  Needs no GPU. */
+int brutus_debug_zig_table(double *h_x, double *h_y, int n);
 int brutus_debug_galprior(const brutus_post_params *params, int n,
                           const double *d_dist, const double *d_coord,
                           const double *d_feh, const double *d_loga, double *d_out,

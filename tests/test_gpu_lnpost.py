@@ -15,8 +15,10 @@ def test_device_rng_matches_specification():
     from brutus_amd import _lib
     from brutus_amd.rng import philox_normal, philox_uniform
     L = _lib.lib()
+    from brutus_amd.rng import ZIG_X
+    slow = 0
     for seed, start in ((0, 0), (12345, 7), (2 ** 63 + 11, 2 ** 33 + 5)):
-        n = 20001
+        n = 400001
         z = torch.empty(n, dtype=torch.float64, device="cuda")
         u = torch.empty(n, dtype=torch.float64, device="cuda")
         _lib.check(L.brutus_debug_rng(seed, start, n, z.data_ptr(), u.data_ptr(), None))
@@ -24,16 +26,17 @@ def test_device_rng_matches_specification():
         idx = np.arange(start, start + n, dtype=np.uint64)
         assert np.array_equal(u.cpu().numpy(), philox_uniform(seed, idx))
         zr = philox_normal(seed, idx)
-        # same accept/reject decisions (the uniforms are bit-identical, and a
-        # wrong decision would shift a deviate by O(1)); the deviates differ
-        # from numpy's in the last bits: ln, divide and sqrt are ~1 ulp Newton
-        # forms on the device
+        # the rectangle case of the ziggurat (99.57 %) is a table look-up and one
+        # multiplication: bit-equal.  Wedge and tail take exp / ln (ocml vs numpy, last
+        # bits), and a wrong accept / reject decision there would move a deviate by O(1)
         zd = z.cpu().numpy()
         err = np.abs(zd - zr) / np.abs(zr)
-        print("normals: max rel err %.2e, mean %.2e, bit-equal %.3f"
-              % (err.max(), err.mean(), np.mean(zd == zr)))
-        assert err.max() < 2e-15
-        assert err.mean() < 2.5e-16
+        print("normals: max rel err %.2e, bit-equal %.5f, beyond R %d"
+              % (err.max(), np.mean(zd == zr), np.sum(np.abs(zr) > ZIG_X[1])))
+        assert err.max() < 1e-15
+        assert np.mean(zd == zr) > 0.999
+        slow += int(np.sum(np.abs(zr) > ZIG_X[1]))
+    assert slow > 20          # the tail loop was exercised (2 Phi(-R) = 5.4e-5 per normal)
 
 
 def _post_params(**kw):
@@ -92,7 +95,14 @@ NAMES = ("sidxs scales avs rvs cov Ndim lnprob levid chi2min dists reds dreds "
 def _compare(dev, ref, tag):
     assert np.array_equal(dev[0], ref[0]), "%s: resampled indices" % (tag,)
     for n, a, b in zip(NAMES[1:], ref[1:], dev[1:]):
-        assert relerr(a, b) < 1e-8, (tag, n, relerr(a, b))
+        if n in ("reds", "dreds"):
+            # a drawn Av / Rv is a0 + L z: a sum of O(1) terms that may land near zero, so the
+            # error is measured against the size of the terms (the array's largest value)
+            a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+            err = float(np.max(np.abs(a - b)) / np.max(np.abs(a))) if a.size else 0.
+        else:
+            err = relerr(a, b)
+        assert err < 1e-8, (tag, n, err)
 
 
 def test_device_lnpost_shared_stream_vs_oracle():
