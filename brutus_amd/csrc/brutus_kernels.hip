@@ -1877,7 +1877,7 @@ int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream) 
 }
 
 int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n, void *stream) {
-    if (!d_x || !d_y || n <= 0 || which < 0 || which > 2) return fail(BRUTUS_EINVAL, "bad arguments");
+    if (!d_x || !d_y || n <= 0 || which < 0 || which > 9) return fail(BRUTUS_EINVAL, "bad arguments");
     hipLaunchKernelGGL(k_debug_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                        (hipStream_t)stream, which, d_x, d_y, n);
     HIP_TRY(hipGetLastError());

@@ -145,9 +145,13 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &sq, double &rs
     h = fma(h, r, h);
     g = fma(fma(-g, g, x), h, g);
     g = fma(fma(-g, g, x), h, g);
-    h = fma(fma(-h, g, 0.5), h, h);        // h -> 1 / (2 sqrt x)
+    // 1 / sqrt x = 1 / g by Newton, y <- y + y (1 - y g): after the coupled step h is good to
+    // 2^-24 (the hardware seed to 2^-12.5), two steps give <= 1 ulp
+    double y2 = h + h;
+    y2 = fma(y2, fma(-y2, g, 1.), y2);
+    y2 = fma(y2, fma(-y2, g, 1.), y2);
     sq = x == 0. ? 0. : g;
-    rsq = 2. * h;
+    rsq = y2;
 }
 __device__ __forceinline__ double fast_sqrt(double x) {
     double g, h;
@@ -170,6 +174,24 @@ __device__ __forceinline__ double fast_exp_bf(double x, const double *__restrict
     const int ni = __double2loint(ns);
     const double v = ldexp(tbl[ni & 63] * pl, ni >> 6);
     return x > -745. ? v : (x == x ? 0. : x);
+}
+// fast_exp_bf for a finite argument: no selects for NaN / -inf, an argument below -745 gives
+// the same denormal as -745 (5e-324, not 0).  For the Galactic prior's components, where a
+// non-finite argument only arises from a sample that is out of bounds and discarded anyway.
+__device__ __forceinline__ double fast_exp_fin(double x, const double *__restrict__ tbl) {
+    const double xc = fmax(x, -745.);
+    const double ns = fma(xc, 92.332482616893657, 6755399441055744.0);   // 1.5 * 2^52 shift
+    const double n = ns - 6755399441055744.0;
+    double r = fma(-n, 0.01083042469326756, xc);
+    r = fma(-n, 2.9815858269852933e-12, r);
+    double pl = 8.3333333333333332e-03;
+    pl = fma(pl, r, 4.1666666666666664e-02);
+    pl = fma(pl, r, 1.6666666666666666e-01);
+    pl = fma(pl, r, 0.5);
+    pl = fma(pl, r, 1.0);
+    pl = fma(pl, r, 1.0);
+    const int ni = __double2loint(ns);
+    return ldexp(tbl[ni & 63] * pl, ni >> 6);
 }
 // fast_log with the reciprocal above (a few ulp)
 __device__ __forceinline__ double fast_log_r(double x) {
@@ -196,6 +218,29 @@ __device__ __forceinline__ double fast_log_r(double x) {
     const double ed = (double)e;
     const double v = fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
     return x > 0. ? (x < INFINITY ? v : x) : (x == 0. ? -INFINITY : nan(""));
+}
+// fast_log_r for a normal-range positive argument (no selects for 0 / inf / negative / NaN)
+__device__ __forceinline__ double fast_log_pos(double x) {
+    int e;
+    double m = frexp(x, &e);
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? 2. * m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.) * fast_rcp(m + 1.);
+    const double z = s * s;
+    double pl = 1. / 21.;
+    pl = fma(pl, z, 1. / 19.);
+    pl = fma(pl, z, 1. / 17.);
+    pl = fma(pl, z, 1. / 15.);
+    pl = fma(pl, z, 1. / 13.);
+    pl = fma(pl, z, 1. / 11.);
+    pl = fma(pl, z, 1. / 9.);
+    pl = fma(pl, z, 1. / 7.);
+    pl = fma(pl, z, 1. / 5.);
+    pl = fma(pl, z, 1. / 3.);
+    const double lm = fma(2. * s * z, pl, 2. * s);
+    const double ed = (double)e;
+    return fma(ed, 6.93147180369123816490e-01, fma(ed, 1.90821492927058770002e-10, lm));
 }
 
 }  // namespace

@@ -527,7 +527,21 @@ __global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__
 __global__ void k_debug_math(int which, const double *__restrict__ x, double *__restrict__ y,
                              int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) y[i] = which == 1 ? fast_exp(x[i]) : which == 2 ? fast_log(x[i]) : fast_exp10(x[i]);
+    if (i >= n) return;
+    const double v = x[i];
+    double sq, rsq;
+    switch (which) {
+    case 1: y[i] = fast_exp(v); break;
+    case 2: y[i] = fast_log(v); break;
+    case 3: y[i] = fast_sqrt(v); break;
+    case 4: fast_sqrt_rsqrt(v, sq, rsq); y[i] = rsq; break;
+    case 5: y[i] = fast_rcp(v); break;
+    case 6: y[i] = fast_exp_fin(v, kExp2Tbl); break;
+    case 7: y[i] = fast_log_pos(v); break;
+    case 8: y[i] = fast_log_r(v); break;
+    case 9: y[i] = fast_exp_bf(v, kExp2Tbl); break;
+    default: y[i] = fast_exp10(v);
+    }
 }
 
 __global__ void k_set_i32(int32_t *p, int n, int32_t v) {

@@ -247,15 +247,15 @@ __device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const Star
     const double Rt = fast_sqrt(R2 + pp.Rs_thin2);
     const double Rk = pp.Rs_thick2 == pp.Rs_thin2 ? Rt : fast_sqrt(R2 + pp.Rs_thick2);
     // thin / thick disk: exp(-(R - R_sun)/R_c - (|Z| - |Z_sun|)/Z_c [+ ln f] - lnK)
-    const double T0 = fast_exp_bf(pp.c0_thin - (Rt * pp.inv_R_thin + dZ * pp.inv_Z_thin), tbl);
-    const double T1 = fast_exp_bf(pp.c0_thick - (Rk * pp.inv_R_thick + dZ * pp.inv_Z_thick), tbl);
+    const double T0 = fast_exp_fin(pp.c0_thin - (Rt * pp.inv_R_thin + dZ * pp.inv_Z_thin), tbl);
+    const double T1 = fast_exp_fin(pp.c0_thick - (Rk * pp.inv_R_thick + dZ * pp.inv_Z_thick), tbl);
     // halo: f (reff / reff_sun)^-eta, reff^2 = R^2 + (Z/q)^2 + Rs^2, q(r) (pdf.py:341-365)
     const double q = pp.q_halo_inf -
                      (pp.q_halo_inf - pp.q_halo_ctr) *
-                         fast_exp_bf(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
+                         fast_exp_fin(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
     const double zq = Z * fast_rcp(q);
-    const double T2 = fast_exp_bf(
-        pp.c0_halo - 0.5 * pp.eta_halo * fast_log_r((R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2), tbl);
+    const double T2 = fast_exp_fin(
+        pp.c0_halo - 0.5 * pp.eta_halo * fast_log_pos((R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2), tbl);
     double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
     if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
     if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];

@@ -42,8 +42,10 @@ int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
 int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes,
                             void *stream);
 
-/* Test hooks: y[i] = the kernels' own 10^x / e^x / ln x for n inputs
- * (which = 0, 1, 2 in brutus_debug_math). */
+/* Test hooks: y[i] = the kernels' own elementary functions for n inputs.  `which` in
+ * brutus_debug_math: 0 10^x, 1 e^x, 2 ln x (the general forms); 3 sqrt x, 4 1/sqrt x, 5 1/x
+ * (hardware seed + Newton); 6 e^x for finite x, 7 ln x for normal positive x (the
+ * select-free forms of the Galactic prior), 8 / 9 the branch-free ln x / e^x. */
 int brutus_debug_exp10(const double *d_x, double *d_y, int64_t n, void *stream);
 int brutus_debug_math(int which, const double *d_x, double *d_y, int64_t n,
                       void *stream);

@@ -739,3 +739,33 @@ def test_device_exp_and_log_accuracy():
         ok = np.isfinite(r) & (r != 0)
         assert np.max(np.abs(y[ok] - r[ok]) / np.abs(r[ok])) < 4.5e-16, which
         assert np.array_equal(y[~ok], r[~ok]), which
+
+
+def test_device_newton_and_select_free_forms_accuracy():
+    """sqrt, 1/sqrt, 1/x from the hardware seed plus Newton steps, and the select-free e^x /
+    ln x of the Galactic prior (brutus_debug_math 3..9): <= 2 ulp on normal-range arguments."""
+    import torch
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(2)
+    pos = np.concatenate([10. ** rng.uniform(-280., 280., 200000), rng.uniform(0.25, 4., 200000),
+                          [1., 2., 4., 0.25, 1e-20, 3.32]])
+    ex = np.concatenate([rng.uniform(-60., 5., 200000), rng.uniform(-700., 700., 20000), [0., 1., -1.]])
+    worst = {}
+    for which, x, ref in ((3, pos, np.sqrt), (4, pos, lambda v: 1. / np.sqrt(v)),
+                          (5, pos, lambda v: 1. / v), (6, ex, np.exp), (7, pos, np.log),
+                          (8, pos, np.log), (9, ex, np.exp)):
+        tx = torch.from_numpy(x).cuda()
+        ty = torch.empty_like(tx)
+        _lib.check(L.brutus_debug_math(which, tx.data_ptr(), ty.data_ptr(), x.size, None))
+        torch.cuda.synchronize()
+        y, r = ty.cpu().numpy(), ref(x)
+        err = np.abs(y - r) / np.abs(np.where(r == 0, 1., r))
+        print(which, "max rel err %.2e" % err.max())
+        worst[which] = err.max()
+    assert all(v < 4.5e-16 for v in worst.values()), worst
+    # sqrt(0) = 0 exactly (the zero select of fast_sqrt)
+    tx = torch.zeros(4, dtype=torch.float64, device="cuda")
+    ty = torch.ones_like(tx)
+    _lib.check(L.brutus_debug_math(3, tx.data_ptr(), ty.data_ptr(), 4, None))
+    assert np.array_equal(ty.cpu().numpy(), np.zeros(4))
