@@ -140,7 +140,8 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
  * the resampling tail of BruteForce._fit (fitting.py:2021-2061), for the
  * built-in priors: static lnprior + the Galactic model of pdf.gal_lnprior
  * (pdf.py:476-749; Galactocentric frame passed in, see frame_mat) + the parallax
- * likelihood.  Random numbers follow brutus_amd/rng.py (PhiloxRandomState):
+ * likelihood.  Random numbers follow brutus_amd/rng.py (PhiloxRandomState:
+ * Philox4x32-7; 53-bit uniforms; normals by a 1024-layer ziggurat, two per call):
  * normal j / uniform q are functions of (seed, j) / (seed, q), so the result is
  * what the reference produces when it is handed that object as `rstate`.
  *
