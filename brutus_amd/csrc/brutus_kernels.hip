@@ -1419,6 +1419,13 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     const double qs = pp.q_halo_inf -
                       (pp.q_halo_inf - pp.q_halo_ctr) * exp(1. - sqrt(Rs2 + Zs * Zs + rq2) / pp.r_q_halo);
     pp.inv_reff_solar2 = 1. / (Rs2 + (Zs / qs) * (Zs / qs) + pp.Rs_halo * pp.Rs_halo);
+    for (int c = 0; c < 3; ++c) {
+        const double s2 = pp.feh_sigma[c] * pp.feh_sigma[c];
+        pp.feh_nh_isig2[c] = -0.5 / s2;
+        pp.feh_c0[c] = -0.5 * log(2. * M_PI * s2);
+        pp.age_isig[c] = 1. / pp.age_sigma[c];
+        pp.age_c0[c] = -0.91893853320467274178 - pp.age_lnnorm[c];
+    }
     pp.inv_R_thin = 1. / pp.R_thin;
     pp.inv_Z_thin = 1. / pp.Z_thin;
     pp.inv_R_thick = 1. / pp.R_thick;

@@ -137,8 +137,10 @@ struct PostParams {     // mirrors brutus_post_params
     double inv_R_thin, inv_Z_thin, inv_R_thick, inv_Z_thick, inv_r_q;
     double Rs_thin2, Rs_thick2, Rs_halo2, rq2, abs_Z_solar;
     double lnK, c0_thin, c0_thick, c0_halo;      // component constants relative to lnK
+    // label_terms: -1 / (2 sigma^2), -ln(2 pi sigma^2) / 2; 1 / sigma_age, -ln(2 pi) / 2 - lnnorm
+    double feh_nh_isig2[3], feh_c0[3], age_isig[3], age_c0[3];
 };
-constexpr int POST_DERIVED = 17;
+constexpr int POST_DERIVED = 29;
 
 // stream key and uniform base of object s: one shared sequential stream, or
 // (per_object) an own stream keyed seed + object index
@@ -205,24 +207,26 @@ __device__ __forceinline__ double lse3(double a, double b, double c) {
 }
 
 // per-model metallicity / age densities of the three components (pdf.py:380-473),
-// as plain (not log) values: e^F_c, e^A_c
+// as plain (not log) values: e^F_c, e^A_c.  Table + polynomial forms (<= 2 ulp) with the
+// per-component constants from fill_post_params: ~130 instructions instead of ~400 with
+// ocml's exp / log / exp10 -- k_post_lnp1 spends half its time here, and k_post_mc_arr
+// evaluates it on the eight lanes of a record.
 __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, double loga,
-                                            double (&Fc)[3], double (&Ac)[3]) {
+                                            double (&Fc)[3], double (&Ac)[3],
+                                            const double *__restrict__ tbl = kExp2Tbl) {
+    const double age = pp.has_loga ? fast_exp10(loga - 9., tbl) : 0.;       // Gyr
+    const bool age_out = age < pp.min_age || age > pp.max_age;
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
         Fc[c] = 1.;
         Ac[c] = 1.;
         if (pp.has_feh) {
             const double d = pp.feh_mean[c] - feh;
-            Fc[c] = exp(-0.5 * (d * d / (pp.feh_sigma[c] * pp.feh_sigma[c]) +
-                                log(2. * M_PI * pp.feh_sigma[c] * pp.feh_sigma[c])));
+            Fc[c] = fast_exp_fin(fma(d * d, pp.feh_nh_isig2[c], pp.feh_c0[c]), tbl);
         }
         if (pp.has_loga) {
-            const double age = exp10(loga) / 1e9;
-            const double xi = (age - pp.age_mean[c]) / pp.age_sigma[c];
-            Ac[c] = (age < pp.min_age || age > pp.max_age)
-                        ? 0.
-                        : exp(-0.91893853320467274178 - 0.5 * xi * xi - pp.age_lnnorm[c]);
+            const double xi = (age - pp.age_mean[c]) * pp.age_isig[c];
+            Ac[c] = age_out ? 0. : fast_exp_fin(fma(-0.5 * xi, xi, pp.age_c0[c]), tbl);
         }
     }
 }
@@ -319,7 +323,7 @@ k_post_lnp1(PostParams pp, int64_t cap, const int32_t *__restrict__ sel_idx, con
         if (r < b) {
             const int64_t i = sel_idx[r], vs = rec_slot[r];       // vs: slot of the record's values
             double Fc[3], Ac[3];
-            label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+            label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac, s_tbl);
             const double scale = sel_vals[2 * cap + vs];
             const double dist = 1. / sqrt(scale);
             double v = sel_vals[vs] + lnprior[i] + gal_lnprior_dev(pp, g, dist, Fc, Ac, s_tbl);
@@ -664,7 +668,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     const int64_t r = sel_off[s] + rp.src[o];
                     const int64_t i = sel_idx[r], vs = rec_slot[r];
                     double Fc[3], Ac[3], L[6];
-                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac, s_tbl);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
                     const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs],
@@ -778,7 +782,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                     const int64_t r = sel_off[s] + rp.src[o];
                     const int64_t i = sel_idx[r], vs = rec_slot[r];
                     double Fc[3], Ac[3], L[6];
-                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+                    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac, s_tbl);
 #pragma unroll
                     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
                     const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs],
@@ -1018,7 +1022,7 @@ k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int
     if (!pp.return_distreds) return;
     // second stage (fitting.py:2049-2057): pick one of the record's nmc samples
     double Fc[3], Ac[3], L[6];
-    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac);
+    label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac, s_tbl);
 #pragma unroll
     for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
     const uint64_t nb = zarr ? 0ull : nbase[s];
