@@ -1649,10 +1649,13 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 const int nitem = PCH * ng;
                 HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
                 static const int use_arr = env_int("BRUTUS_POST_MC_ARR", 1);
+                static const int arr_persistent = env_int("BRUTUS_POST_MC_ARR_PERSISTENT", 0);
                 if (use_arr && pp.nmc <= MCA_NMC)
-                    hipLaunchKernelGGL(k_post_mc_arr, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk,
+                    hipLaunchKernelGGL(k_post_mc_arr,
+                                       dim3(arr_persistent ? (nitem < MC_SLOTS ? nitem : MC_SLOTS) : nitem), blk,
                                        sizeof(double) * (TILE / 64) * MCA_R * 3 * pp.nmc,
-                                       st, pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
+                                       st, pp, capacity, PCH * s0, PCH * s1,
+                                       arr_persistent ? w.mc_counter : (unsigned int *)nullptr,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx, d_rec_slot,
                                        d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
                                        d_loga, w.rp, w.part_max, w.part_chi2);

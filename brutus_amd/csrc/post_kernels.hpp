@@ -757,9 +757,12 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
     double *const zt = s_z + (size_t)w * MCA_R * run;
     for (;;) {
         __syncthreads();
-        if (threadIdx.x == 0) s_item = (unsigned int)item_base + atomicAdd(counter, 1u);
+        // counter == nullptr: one item per workgroup (grid = number of items).  Short
+        // workgroups instead of persistent ones let the kernels of the next batch's
+        // high-priority stream in between (BruteForce's two-phase pipeline).
+        if (counter && threadIdx.x == 0) s_item = (unsigned int)item_base + atomicAdd(counter, 1u);
         __syncthreads();
-        const unsigned int item = s_item;
+        const unsigned int item = counter ? s_item : (unsigned int)item_base + blockIdx.x;
         if (item >= (unsigned int)nitem) break;
         const int s = (int)(item / PCH), c = (int)(item % PCH);
         int64_t a, b;
@@ -853,6 +856,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
         }
         block_max_store(mx, slot, part_max + (int64_t)s * PCH + c);
         block_max_store(cmin, slot, part_chi2 + (int64_t)s * PCH + c);
+        if (!counter) break;
     }
 }
 
