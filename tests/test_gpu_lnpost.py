@@ -476,3 +476,31 @@ def test_device_lnpost_with_los_dust_prior_vs_oracle():
     finally:
         fitting._Engine.post_batch_device = orig
         fitting._Engine.post_numpy_begin = orig_begin
+
+
+def test_device_lnpost_more_than_64_samples_per_model_both_streams():
+    """Nmc_prior = 70 > 64: the numpy stream leaves the 8 records x 8 sample groups kernel
+    (`k_post_mc_arr`, nmc <= 64) for the lane-per-record one reading the normals from
+    memory, and the counter-based stream walks 105 Philox calls per record; odd and even
+    run alignments (70 * 3 = 210 normals per record, batches of 4)."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nstar=6, seed=61)
+    BF.batch_size = 4
+    for mk in (lambda: PhiloxRandomState(70), lambda: np.random.RandomState(70)):
+        rs, ro = mk(), mk()
+        dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                           parallax_err=st["parallax_err"], Nmc_prior=70, lnprior=lnprior,
+                           lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=40,
+                           rstate=rs))
+        for i in range(len(dev)):
+            ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                             labels, st["coords"][i], st["parallax"][i],
+                             st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=70, Ndraws=40)
+            _compare(dev[i], ref, ("nmc70", i))
+        if isinstance(rs, PhiloxRandomState):
+            assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+        else:
+            assert rs.get_state()[2] == ro.get_state()[2]
+            assert np.array_equal(rs.get_state()[1], ro.get_state()[1])
