@@ -1394,6 +1394,12 @@ int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep,
     const unsigned kb = (unsigned)((keep + 255) / 256);
     // permute every per-record array through the (now free) lnp1-sized scratch
     double *tmp = w.lnp1;
+    if (14 * keep <= cap) {          // all planes at once: two launches instead of 28
+        hipLaunchKernelGGL(k_clip_gather, dim3(kb), dim3(256), 0, st, w.rp, cap, a, w.sort_perm, keep, tmp);
+        hipLaunchKernelGGL(k_clip_store, dim3(kb), dim3(256), 0, st, w.rp, cap, a, keep, tmp);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     auto permute64 = [&](double *arr) -> int {
         hipLaunchKernelGGL(k_gather<double>, dim3(kb), dim3(256), 0, st, tmp, arr + a, w.sort_perm, keep);
         HIP_TRY(hipMemcpyAsync(arr + a, tmp, 8 * (size_t)keep, hipMemcpyDeviceToDevice, st));

@@ -1075,6 +1075,36 @@ __global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
     if (i < n) dst[i] = src[perm[i]];
 }
 
+// Nsel_max clip: the kept records of one object, best first.  k_clip_gather pulls lnp, the six
+// covariance and the six Cholesky planes and the source index through `perm` into a dense
+// scratch (13 planes of `keep` doubles + `keep` ints), k_clip_store writes them back in place.
+__global__ void k_clip_gather(RecPost rp, int64_t cap, int64_t a, const int32_t *__restrict__ perm,
+                              int64_t keep, double *__restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= keep) return;
+    const int64_t j = a + perm[i];
+    tmp[i] = rp.lnp[j];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        tmp[(1 + q) * keep + i] = rp.cov[(int64_t)q * cap + j];
+        tmp[(7 + q) * keep + i] = rp.chol[(int64_t)q * cap + j];
+    }
+    reinterpret_cast<int32_t *>(tmp + 13 * keep)[i] = rp.src[j];
+}
+__global__ void k_clip_store(RecPost rp, int64_t cap, int64_t a, int64_t keep,
+                             const double *__restrict__ tmp) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= keep) return;
+    const int64_t j = a + i;
+    rp.lnp[j] = tmp[i];
+#pragma unroll
+    for (int q = 0; q < 6; ++q) {
+        rp.cov[(int64_t)q * cap + j] = tmp[(1 + q) * keep + i];
+        rp.chol[(int64_t)q * cap + j] = tmp[(7 + q) * keep + i];
+    }
+    rp.src[j] = reinterpret_cast<const int32_t *>(tmp + 13 * keep)[i];
+}
+
 // direction of the sightline (l, b) [rad] in the Galactocentric frame of `pp`
 __device__ __forceinline__ void sightline(const PostParams &pp, double l, double b, StarGeom &g) {
     const double n0 = cos(b) * cos(l), n1 = cos(b) * sin(l), n2 = sin(b);
