@@ -665,6 +665,8 @@ size_t mt_scratch_bytes(const std::vector<MtPlanStream> &ps, int nobj_total) {
     b += ((size_t)T / MT_SB + ns + 1) * 8 + 256;     // pre
     b += ns * 128 + 4096;                            // per-stream arrays
     b += (size_t)nobj_total * sizeof(MtObj) + 256;
+    b += ((size_t)K + nobj_total) * 16 + 512;        // segment lists (k_mt_segments)
+    b += (size_t)nobj_total * 24 + 1024 + (ns + 1) * 8;
     return b;
 }
 
@@ -706,15 +708,28 @@ struct MtEmitLaunch {
     double *Z;
     int nuni;
     double *U, *endgauss;
+    int uni_only;        // the normals were written by pass 1: only the uniform slots are left
+    ZMap zm;             // ... and this is how the consumers find them (zm.zloc == nullptr: flat Z)
+    // k_mt_segments (runs with the emit: the consumers' half of the call)
+    int nstream, nobj;
+    const double *gauss0;
+    const int64_t *subbase;
 };
 std::mutex g_emit_mu;
 std::map<const void *, MtEmitLaunch> g_emit;      // key: the scratch base
 
 void launch_mt_emit(const MtEmitLaunch &e, hipStream_t st, Timer &tm) {
     tm.begin("k_mt_emit");
+    if (e.uni_only)
+        hipLaunchKernelGGL(k_mt_segments, dim3((unsigned)e.nobj), dim3(64), 0, st, e.nstream, e.seg, e.nnorm,
+                           e.gauss0, e.subs, e.subbase, e.bitbase, e.sblo, e.bits, e.pre, e.objs,
+                           e.zm.zloc, const_cast<int64_t *>(e.zm.seg_pair0),
+                           const_cast<int64_t *>(e.zm.seg_addr), const_cast<int64_t *>(e.zm.seg_lo),
+                           const_cast<int32_t *>(e.zm.nseg), const_cast<double *>(e.zm.cached),
+                           const_cast<int32_t *>(e.zm.c));
     hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)e.Ktot), dim3(MT_PT), 0, st, e.Ktot, e.subs, e.win,
                        e.bits, e.bitbase, e.sblo, e.pre, e.seg, e.objs, e.nnorm, e.zoff, e.Z, e.nuni,
-                       e.U, e.endgauss);
+                       e.U, e.endgauss, e.uni_only);
     tm.end();
 }
 
@@ -722,7 +737,8 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
                      const std::vector<int> &pos0, const std::vector<int64_t> &nnorm,
                      const int32_t *d_seg, const int64_t *d_nnorm, const int64_t *d_zoff, double *d_Z,
                      int nuni, double *d_U, char *scratch, size_t scratch_bytes, int nobj_total,
-                     hipStream_t st, Timer &tm, bool defer_emit) {
+                     hipStream_t st, Timer &tm, bool defer_emit, double2 *d_zloc, size_t zloc_pairs,
+                     MtEmitLaunch *out) {
     if (nuni & 1) return 1;                      // slot grid needs an even number of uniforms
     std::vector<uint32_t> polys;
     {
@@ -749,6 +765,8 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         Ttot += p.T;
     }
     if (mt_scratch_bytes(ps, nobj_total) > scratch_bytes) return 1;
+    // one walk: pass 1 also writes the accepted candidates' normals (16 bytes per slot)
+    const bool mapped = d_zloc && (size_t)Ttot <= zloc_pairs;
     // ---- carve ---------------------------------------------------------------------
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -773,12 +791,20 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     int64_t *d_skip = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_skipc = (int64_t *)take(8 * (size_t)nstream);
     MtObj *d_objs = (MtObj *)take((size_t)nobj_total * sizeof(MtObj));
+    int64_t *d_segp0 = (int64_t *)take(8 * ((size_t)Ktot + nobj_total));
+    int64_t *d_sega = (int64_t *)take(8 * ((size_t)Ktot + nobj_total));
+    int64_t *d_seglo = (int64_t *)take(8 * (size_t)nobj_total);
+    int32_t *d_nseg = (int32_t *)take(4 * (size_t)nobj_total);
+    double *d_cached = (double *)take(8 * (size_t)nobj_total);
+    int32_t *d_cflag = (int32_t *)take(4 * (size_t)nobj_total);
+    double *d_gauss0 = (double *)take(8 * (size_t)nstream);
     // chains
     std::vector<int64_t> c2s, c2d;
     std::vector<int32_t> c2n;
     std::vector<std::vector<int64_t>> r1s(16), r1d(16);      // chains of first-level round r
     std::vector<MtSub> subs(Ktot);
-    std::vector<int64_t> hbase(nstream), hbit(nstream), hsblo(nstream + 1), hT(nstream);
+    std::vector<int64_t> hbase(nstream + 1), hbit(nstream), hsblo(nstream + 1), hT(nstream);
+    hbase[nstream] = Ktot;
     for (int g = 0; g < nstream; ++g) {
         const MtPlanStream &p = ps[g];
         hbase[g] = p.base;
@@ -829,7 +855,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     const size_t plan0 = off;
     uint32_t *d_polys = (uint32_t *)take(polys.size() * 4);
     MtSub *d_subs = (MtSub *)take((size_t)Ktot * sizeof(MtSub));
-    int64_t *d_base = (int64_t *)take(8 * (size_t)nstream);
+    int64_t *d_base = (int64_t *)take(8 * ((size_t)nstream + 1));
     int64_t *d_bitbase = (int64_t *)take(8 * (size_t)nstream);
     int64_t *d_sblo = (int64_t *)take(8 * ((size_t)nstream + 1));
     int64_t *d_tslots = (int64_t *)take(8 * (size_t)nstream);
@@ -844,7 +870,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     auto at = [&](const void *d) { return hp + ((const char *)d - (scratch + plan0)); };
     memcpy(at(d_polys), polys.data(), polys.size() * 4);
     memcpy(at(d_subs), subs.data(), sizeof(MtSub) * (size_t)Ktot);
-    memcpy(at(d_base), hbase.data(), 8 * (size_t)nstream);
+    memcpy(at(d_base), hbase.data(), 8 * ((size_t)nstream + 1));
     memcpy(at(d_bitbase), hbit.data(), 8 * (size_t)nstream);
     memcpy(at(d_sblo), hsblo.data(), 8 * ((size_t)nstream + 1));
     memcpy(at(d_tslots), hT.data(), 8 * (size_t)nstream);
@@ -892,14 +918,19 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     tm.end();
     // ---- pass 1, prefix, boundaries ----------------------------------------------------------
     tm.begin("k_mt_bits");
-    hipLaunchKernelGGL(k_mt_bits, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs, d_win, d_bits);
+    if (mapped)
+        hipLaunchKernelGGL(k_mt_bits<true>, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs,
+                           d_win, d_bits, d_zloc);
+    else
+        hipLaunchKernelGGL(k_mt_bits<false>, dim3((unsigned)Ktot), dim3(MT_PT), 0, st, (int)Ktot, d_subs,
+                           d_win, d_bits, (double2 *)nullptr);
     tm.end();
     tm.begin("k_mt_resolve");
     hipLaunchKernelGGL(k_mt_sbcount, dim3((unsigned)((nsb + 3) / 4)), dim3(256), 0, st, nsb, d_bits, d_cnt);
     hipLaunchKernelGGL(k_mt_sbscan, dim3(nstream), dim3(1024), 0, st, d_sblo, d_cnt, d_pre);
     hipLaunchKernelGGL(k_mt_resolve, dim3(nstream), dim3(64), 0, st, d_seg, d_nnorm, nuni, d_states,
-                       d_bitbase, d_sblo, d_tslots, d_bits, d_pre, d_zoff, d_Z, d_objs, d_endslot,
-                       d_endhasg, d_endnew, d_fail);
+                       d_bitbase, d_sblo, d_tslots, d_bits, d_pre, d_zoff, mapped ? (double *)nullptr : d_Z,
+                       d_objs, d_endslot, d_endhasg, d_endnew, d_fail, d_gauss0);
     tm.end();
     // (the plan's page-locked mirror is free again once the stream has passed the copy; it
     // doubles as the landing zone of [fail | end slots], which are adjacent on the device)
@@ -933,8 +964,11 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
     hipLaunchKernelGGL(k_mt_advance, dim3(nstream), dim3(MT_PT), 0, st, nstream, d_win, d_widx, d_skip,
                        d_skipc, d_endhasg, d_endnew, d_endgauss, d_states);
     // ---- pass 2 -----------------------------------------------------------------------------
-    const MtEmitLaunch el{(int)Ktot, d_subs, d_win, d_bits, d_bitbase, d_sblo, d_pre, d_seg, d_objs,
-                          d_nnorm, d_zoff, d_Z, nuni, d_U, d_endgauss};
+    MtEmitLaunch el{(int)Ktot, d_subs, d_win, d_bits, d_bitbase, d_sblo, d_pre, d_seg, d_objs,
+                    d_nnorm, d_zoff, d_Z, nuni, d_U, d_endgauss, mapped ? 1 : 0, ZMap{},
+                    nstream, seg[nstream] - seg[0], d_gauss0, d_base};
+    if (mapped) el.zm = ZMap{d_zloc, d_segp0, d_sega, d_seglo, d_nseg, d_cached, d_cflag};
+    if (out) *out = el;
     if (defer_emit) {
         std::lock_guard<std::mutex> lk(g_emit_mu);
         g_emit[(const void *)scratch] = el;
@@ -952,17 +986,21 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
 int mt_walk(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states, std::vector<int> &pos0,
             const std::vector<int64_t> &nnorm, const int32_t *d_seg, const int64_t *d_nnorm,
             const int64_t *d_zoff, double *d_Z, int nuni, double *d_U, char *scratch,
-            size_t scratch_bytes, int nobj_total, hipStream_t st, Timer &tm, bool defer_emit = false) {
+            size_t scratch_bytes, int nobj_total, hipStream_t st, Timer &tm, bool defer_emit = false,
+            double2 *d_zloc = nullptr, size_t zloc_pairs = 0, MtEmitLaunch *out = nullptr) {
     int rc = 1;
+    if (out) *out = MtEmitLaunch{};
     if (scratch) {
         std::lock_guard<std::mutex> lk(g_emit_mu);
         g_emit.erase((const void *)scratch);
     }
     if (env_int("BRUTUS_MT_PARALLEL", 1) && scratch)
         rc = mt_walk_parallel(nstream, seg, d_states, pos0, nnorm, d_seg, d_nnorm, d_zoff, d_Z, nuni,
-                              d_U, scratch, scratch_bytes, nobj_total, st, tm, defer_emit);
+                              d_U, scratch, scratch_bytes, nobj_total, st, tm, defer_emit, d_zloc,
+                              zloc_pairs, out);
     if (rc < 0) return rc;
     if (rc == 1) {
+        if (out) *out = MtEmitLaunch{};           // flat normals from the sequential walker
         tm.begin("k_mt_stream");
         hipLaunchKernelGGL(k_mt_stream, dim3(nstream), dim3(MT_NT), 0, st, nstream, d_seg, d_states,
                            d_nnorm, d_zoff, d_Z, nuni, d_U);
@@ -1552,7 +1590,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
         hipLaunchKernelGGL(k_post_draw, gdraw, dim3(64), 0, st, pp, 0, (const double *)nullptr,
                            (const int64_t *)nullptr, (const double *)nullptr, capacity, d_sel_idx, d_rec_slot,
                            d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh,
-                           d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals);
+                           d_loga, w.rp, w.cdf, w.star_out, d_out_idx, d_out_vals, ZMap{});
         tm.end();
     } else {
         // numpy's own stream (mt_kernels.hpp): objects are served in groups whose normals fit
@@ -1613,6 +1651,14 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 for (int q = 0; q <= ng; ++q) seg[q] = s0 + q;
                 d_states = w.mt_states + (size_t)s0 * MT_STATE_WORDS;
             }
+            // One walk over the stream (pass 1 leaves the normals in the buffer as pairs per
+            // sub-stream, 16 bytes per generated slot, read through segment lists) when the
+            // whole call is one group, the 8 x 8 integrator applies and the buffer holds the
+            // slots; otherwise the flat layout of two walks.
+            static const int use_mapped = env_int("BRUTUS_MT_ONE_WALK", 1);
+            static const int use_arr_ = env_int("BRUTUS_POST_MC_ARR", 1);
+            const bool try_mapped = use_mapped && use_arr_ && pp.nmc <= MCA_NMC && s0 == 0 && s1 == nstar;
+            MtEmitLaunch el{};
             if (phase != 2) {
             HIP_TRY(hipMemcpyAsync(w.mt_nnorm, nnorm.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
@@ -1623,7 +1669,8 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 for (int q = 0; q < nseg; ++q) p0[q] = hpos[mt->nstream == 1 ? 0 : s0 + q];
                 if (int rc = mt_walk(nseg, segv, d_states, p0, nnorm, w.mt_seg, w.mt_nnorm, w.mt_zoff, zbase,
                                      nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm,
-                                     phase == 1))
+                                     phase == 1, try_mapped ? (double2 *)zbase : (double2 *)nullptr,
+                                     try_mapped ? zdoubles / 2 : 0, &el))
                     return rc;
                 for (int q = 0; q < nseg; ++q) hpos[mt->nstream == 1 ? 0 : s0 + q] = p0[q];
             }
@@ -1637,7 +1684,6 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 return 0;
             }
             if (phase == 2) {       // the pass phase 1 left for us: normals / uniforms to their places
-                MtEmitLaunch el;
                 bool have = false;
                 {
                     std::lock_guard<std::mutex> lk(g_emit_mu);
@@ -1664,7 +1710,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                                        arr_persistent ? w.mc_counter : (unsigned int *)nullptr,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx, d_rec_slot,
                                        d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
-                                       d_loga, w.rp, w.part_max, w.part_chi2);
+                                       d_loga, w.rp, w.part_max, w.part_chi2, el.zm);
                 else
                     hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
                                        pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
@@ -1687,7 +1733,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                                (const double *)zbase, (const int64_t *)w.mt_zoff,
                                (const double *)w.mt_uni, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp, w.cdf,
-                               w.star_out, d_out_idx, d_out_vals);
+                               w.star_out, d_out_idx, d_out_vals, el.zm);
             tm.end();
             HIP_TRY(hipStreamSynchronize(st));     // the host arrays of this group are reused
             s0 = s1;

@@ -366,32 +366,60 @@ __device__ __forceinline__ double mt_u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-// pass 1: bit of slot q = "x1^2 + x2^2 of its four words is in (0, 1)"
+// pass 1: bit of slot q = "x1^2 + x2^2 of its four words is in (0, 1)".
+// EMIT: the two normals of every accepted candidate are written as well, compacted per
+// sub-stream: the r-th accepted slot of sub-stream g goes to zloc[bit0_g + r] as (f x2, f x1)
+// -- numpy's order of use.  Which object a pair belongs to is known only after the prefix
+// over the whole stream (k_mt_resolve); the consumers then read the pairs where they lie,
+// through the segment lists of k_mt_segments, and the second walk over the stream
+// (k_mt_emit) shrinks to the few sub-streams that hold the objects' uniform slots.
+template <bool EMIT>
 __global__ void __launch_bounds__(MT_PT)
 k_mt_bits(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__ windows,
-          unsigned long long *__restrict__ bitmap) {
+          unsigned long long *__restrict__ bitmap, double2 *__restrict__ zloc) {
 #pragma clang fp contract(off)
     __shared__ uint32_t blk[MT_RB][MT_N];
+    __shared__ int wcnt[2][MT_PT / 64];
     const int g = blockIdx.x;
     if (g >= nsub) return;
     const MtSub sb = subs[g];
     MtWalk wk{blk, 0, 0};
     wk.init(windows + (int64_t)g * MT_N, sb.skip);
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    int64_t lbase = 0;          // accepted candidates of this sub-stream so far
+    int par = 0;                // wcnt is double-buffered: one barrier per step
     for (int64_t q = sb.q0; q < sb.q1; q += MT_PT) {
         const int ns = (int)((sb.q1 - q) < MT_PT ? (sb.q1 - q) : MT_PT);
         wk.ensure(4 * ns);
         bool acc = false;
+        double x1 = 0., x2 = 0., r2 = 1.;
         if (t < ns) {
             uint32_t w[4];
             wk.slot_words(t, w);
-            const double x1 = 2.0 * mt_u53(w[0], w[1]) - 1.0, x2 = 2.0 * mt_u53(w[2], w[3]) - 1.0;
-            const double r2 = x1 * x1 + x2 * x2;
+            x1 = 2.0 * mt_u53(w[0], w[1]) - 1.0;
+            x2 = 2.0 * mt_u53(w[2], w[3]) - 1.0;
+            r2 = x1 * x1 + x2 * x2;
             acc = r2 < 1.0 && r2 != 0.0;
         }
         const unsigned long long bal = __ballot(acc);
         if (lane == 0 && (q - sb.q0) + 64 * wv < sb.q1 - sb.q0)      // words of this sub-stream only
             bitmap[((sb.bit0 + (q - sb.q0)) >> 6) + wv] = bal;
+        if constexpr (EMIT) {
+            if (lane == 0) wcnt[par][wv] = __popcll(bal);
+            lds_barrier();
+            int bef = __popcll(bal & ((1ull << lane) - 1ull)), tot = 0;
+#pragma unroll
+            for (int w2 = 0; w2 < MT_PT / 64; ++w2) {
+                bef += w2 < wv ? wcnt[par][w2] : 0;
+                tot += wcnt[par][w2];
+            }
+            par ^= 1;
+            if (acc) {
+                const double f = fast_sqrt(-2.0 * fast_log_r(r2) * fast_rcp(r2));      // as k_mt_emit
+                zloc[sb.bit0 + lbase + bef] = make_double2(f * x2, f * x1);
+            }
+            lbase += tot;
+        }
         wk.consume(ns);
     }
 }
@@ -444,6 +472,8 @@ struct MtObj {           // per object, written by k_mt_resolve
     int64_t px;          // accepted candidates of the stream before slot x
     int32_t c;           // 1: its first normal is the deviate cached by its predecessor
     int32_t nxt;         // next object of the stream that draws normals (-1: none)
+    int32_t prv;         // previous one (-1: none; the cached deviate then comes with the state)
+    int32_t pad_;
 };
 
 // One workgroup (64 threads) per stream, its objects in order.
@@ -458,7 +488,7 @@ k_mt_resolve(const int32_t *__restrict__ seg_obj0, const int64_t *__restrict__ n
              const unsigned long long *__restrict__ bitmap, const int64_t *__restrict__ pre,
              const int64_t *__restrict__ zoff, double *__restrict__ Z, MtObj *__restrict__ objs,
              int64_t *__restrict__ end_slot, int32_t *__restrict__ end_hasg,
-             int32_t *__restrict__ end_new, int32_t *__restrict__ fail) {
+             int32_t *__restrict__ end_new, int32_t *__restrict__ fail, double *__restrict__ gauss0_out) {
     const int st = blockIdx.x, lane = threadIdx.x;
     const uint32_t *stt = states + (int64_t)st * MT_STATE_WORDS;
     int c = (int)stt[MT_N + 1];
@@ -487,11 +517,12 @@ k_mt_resolve(const int32_t *__restrict__ seg_obj0, const int64_t *__restrict__ n
         ob.x = x;
         ob.c = (n > 0) ? c : 0;
         ob.nxt = -1;
+        ob.prv = n > 0 ? prev_with_normals : -1;
         if (n > 0) {
             if (c && lane == 0) {
                 // the deviate cached before this call: from the incoming state for the first
                 // drawing object, else written by k_mt_emit (the predecessor's last pair)
-                if (prev_with_normals < 0) Z[zoff[o]] = gauss0;
+                if (prev_with_normals < 0 && Z) Z[zoff[o]] = gauss0;     // (Z == nullptr: k_mt_segments)
             }
             if (prev_with_normals >= 0 && lane == 0) objs[prev_with_normals].nxt = o;
             prev_with_normals = o;
@@ -548,9 +579,11 @@ k_mt_resolve(const int32_t *__restrict__ seg_obj0, const int64_t *__restrict__ n
             objs[o].px = ob.px;
             objs[o].c = ob.c;
             objs[o].nxt = -1;
+            objs[o].prv = ob.prv;
         }
     }
     if (lane == 0) {
+        gauss0_out[st] = gauss0;
         end_slot[st] = x;
         end_hasg[st] = c;
         end_new[st] = (c && cnew) ? 1 : 0;
@@ -565,7 +598,8 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
           const int64_t *__restrict__ sb_lo, const int64_t *__restrict__ pre,
           const int32_t *__restrict__ seg_obj0, const MtObj *__restrict__ objs,
           const int64_t *__restrict__ nnorm, const int64_t *__restrict__ zoff,
-          double *__restrict__ Z, int nuni, double *__restrict__ U, double *__restrict__ end_gauss) {
+          double *__restrict__ Z, int nuni, double *__restrict__ U, double *__restrict__ end_gauss,
+          int uni_only) {
 #pragma clang fp contract(off)
     __shared__ uint32_t blk[MT_RB][MT_N];
     __shared__ int wcnt[2][MT_PT / 64];
@@ -585,6 +619,17 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
     MtWalk wk{blk, 0, 0};
     wk.init(windows + (int64_t)g * MT_N, sb.skip);
     if (sb.q0 >= s_bound[2 * no]) return;              // nothing of this sub-stream is consumed
+    if (uni_only) {
+        // the normals were written by pass 1 (k_mt_bits<true>): only a sub-stream that holds
+        // uniform slots (an odd region) is walked again
+        int lo = 0, hi = 2 * no;                       // region of slot q0
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_bound[mid] <= sb.q0) lo = mid; else hi = mid;
+        }
+        const bool any = (lo & 1) || s_bound[lo + 1] < sb.q1;
+        if (!any) return;
+    }
     // accepted candidates of the stream before slot q0 (q0 is a multiple of 64)
     int64_t pcount;
     {
@@ -641,7 +686,7 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
                 }
                 reg = lo;
             }
-            acc = reg >= 0 && accbit && !(reg & 1);
+            acc = reg >= 0 && accbit && !(reg & 1) && !uni_only;
         }
         const unsigned long long bal = __ballot(accbit);
         if (lane == 0) wcnt[par][wv] = __popcll(bal);
@@ -675,6 +720,115 @@ k_mt_emit(int nsub, const MtSub *__restrict__ subs, const uint32_t *__restrict__
         }
         pcount += tot;
         wk.consume(ns);
+    }
+}
+
+// ---- the normals where pass 1 left them -------------------------------------------------
+// Object o's normals are its cached deviate (if c) followed by the pairs of its accepted
+// candidate slots.  Pass 1 stored those per sub-stream; an object therefore reads a short
+// list of segments: segment i covers the object's pairs [pair0_i, pair0_{i+1}) at
+// zloc[addr_i + (pair - pair0_i)].  Lists of at most (sub-streams it touches) entries, at
+// seg_lo[o] = (first sub-stream) + o, which no two objects share.
+struct ZMap {
+    const double2 *zloc;
+    const int64_t *seg_pair0, *seg_addr, *seg_lo;
+    const int32_t *nseg;
+    const double *cached;
+    const int32_t *c;            // 1: normal 0 of the object is cached[o]
+};
+__device__ __forceinline__ double zmap_at(const ZMap &zm, int o, int64_t j) {
+    const int c = zm.c[o];
+    if (j < c) return zm.cached[o];
+    const int64_t pq = j - c, pr = pq >> 1, lo0 = zm.seg_lo[o];
+    int lo = 0, hi = zm.nseg[o];                       // largest i with pair0_i <= pr
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (zm.seg_pair0[lo0 + mid] <= pr) lo = mid; else hi = mid;
+    }
+    const double2 v = zm.zloc[zm.seg_addr[lo0 + lo] + (pr - zm.seg_pair0[lo0 + lo])];
+    return (pq & 1) ? v.y : v.x;
+}
+
+// One workgroup (64 threads) per object (after k_mt_resolve).
+//   sub_base[st]  index of the stream's first sub-stream, sub_base[st + 1] one past its last
+//   gauss0[st]    the deviate cached in the incoming state (k_mt_resolve)
+__global__ void __launch_bounds__(64)
+k_mt_segments(int nstream, const int32_t *__restrict__ seg_obj0, const int64_t *__restrict__ nnorm,
+              const double *__restrict__ gauss0, const MtSub *__restrict__ subs,
+              const int64_t *__restrict__ sub_base, const int64_t *__restrict__ bit_base,
+              const int64_t *__restrict__ sb_lo, const unsigned long long *__restrict__ bitmap,
+              const int64_t *__restrict__ pre, const MtObj *__restrict__ objs,
+              const double2 *__restrict__ zloc, int64_t *__restrict__ seg_pair0,
+              int64_t *__restrict__ seg_addr, int64_t *__restrict__ seg_lo, int32_t *__restrict__ nseg,
+              double *__restrict__ cached, int32_t *__restrict__ cflag) {
+    const int o = seg_obj0[0] + blockIdx.x, lane = threadIdx.x;
+    if (o >= seg_obj0[nstream]) return;
+    int st = 0;                                        // the stream of object o
+    {
+        int lo = 0, hi = nstream;
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (seg_obj0[mid] <= o) lo = mid; else hi = mid;
+        }
+        st = lo;
+    }
+    const unsigned long long *bm = bitmap + (bit_base[st] >> 6);
+    const int64_t *pr = pre + sb_lo[st] + st;
+    const int64_t nsb = sb_lo[st + 1] - sb_lo[st];
+    const int64_t g0 = sub_base[st], g1 = sub_base[st + 1];
+    // accepted candidates of the stream before slot q (wave-cooperative, as in k_mt_resolve)
+    auto before = [&](int64_t q) -> int64_t {
+        const int64_t b = q >> 12;
+        const int w = (int)((q & (MT_SB - 1)) >> 6), bit = (int)(q & 63);
+        int cnt = 0;
+        if (lane < w) cnt = __popcll(bm[b * 64 + lane]);
+        else if (lane == w && bit) cnt = __popcll(bm[b * 64 + lane] & ((1ull << bit) - 1ull));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) cnt += __shfl_xor(cnt, off, 64);
+        return (b < nsb ? pr[b] : pr[nsb]) + cnt;
+    };
+    // sub-stream of the stream that holds slot q: the last one with q0 <= q
+    auto sub_of = [&](int64_t q) -> int64_t {
+        int64_t lo = g0, hi = g1;
+        while (hi - lo > 1) {
+            const int64_t mid = (lo + hi) >> 1;
+            if (subs[mid].q0 <= q) lo = mid; else hi = mid;
+        }
+        return lo;
+    };
+    const MtObj ob = objs[o];
+    const int64_t n = nnorm[o];
+    const int64_t a = n > 0 ? (n - ob.c + 1) >> 1 : 0;       // accepted pairs it consumes
+    int ns = 0;
+    int64_t gx = g0;
+    if (a > 0) {
+        gx = sub_of(ob.x);
+        for (int64_t g = gx; g < g1 && subs[g].q0 < ob.y; ++g, ++ns) {
+            const int64_t sp = before(subs[g].q0);             // accepted before the sub-stream
+            if (lane == 0) {
+                seg_pair0[gx + o + ns] = g == gx ? 0 : sp - ob.px;
+                seg_addr[gx + o + ns] = subs[g].bit0 + (g == gx ? ob.px - sp : 0);
+            }
+        }
+    }
+    double cv = 0.;
+    if (n > 0 && ob.c) {
+        cv = gauss0[st];
+        if (ob.prv >= 0) {
+            // the second normal of the predecessor's last pair: its last accepted slot is
+            // y - 1, rank px + a - 1 of the stream
+            const MtObj pb = objs[ob.prv];
+            const int64_t pa = (nnorm[ob.prv] - pb.c + 1) >> 1;
+            const int64_t g = sub_of(pb.y - 1);
+            const int64_t sp = before(subs[g].q0);
+            cv = zloc[subs[g].bit0 + (pb.px + pa - 1 - sp)].y;
+        }
+    }
+    if (lane == 0) {
+        seg_lo[o] = gx + o;
+        nseg[o] = ns;
+        cached[o] = cv;
+        cflag[o] = n > 0 ? ob.c : 0;
     }
 }
 

@@ -509,13 +509,19 @@ struct NormalReader {
     double z0, z1;
     bool have;
     const double *zs;      // non-null: the object's normals are in memory (k_mt_stream)
-    __device__ __forceinline__ void init(uint64_t seed_, const double *zs_ = nullptr) {
+    const ZMap *zm;        // non-null: ... where pass 1 of the stream walk left them (object `obj`)
+    int obj;
+    __device__ __forceinline__ void init(uint64_t seed_, const double *zs_ = nullptr,
+                                         const ZMap *zm_ = nullptr, int obj_ = 0) {
         seed = seed_;
         have = false;
         p = 0;
         zs = zs_;
+        zm = zm_;
+        obj = obj_;
     }
     __device__ __forceinline__ double at(uint64_t j) {
+        if (zm) return zmap_at(*zm, obj, (int64_t)j);
         if (zs) return zs[j];
         const uint64_t q = j >> 1;
         if (!have || q != p) {
@@ -741,7 +747,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
               const int64_t *__restrict__ nsel, const int32_t *__restrict__ flags,
               const StarGeom *__restrict__ geom, const double *__restrict__ feh,
               const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
-              double *__restrict__ part_chi2) {
+              double *__restrict__ part_chi2, ZMap zm) {
     static_assert(MCA_R * MCA_G == 64, "one wave = records x sample groups");
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
@@ -768,7 +774,14 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
-        const double *const zsrc = zarr + zoff[s];      // the object's normals, numbered from 0
+        // the object's normals, numbered from 0: a flat array, or (zm.zloc) the pairs where
+        // pass 1 of the stream walk left them, through the object's segment list
+        const bool mapped = zm.zloc != nullptr;
+        const double *const zsrc = mapped ? nullptr : zarr + zoff[s];
+        const int c_o = mapped ? zm.c[s] : 0;
+        const int64_t slo = mapped ? zm.seg_lo[s] : 0;
+        const int nsg = mapped ? zm.nseg[s] : 0;
+        int sg = 0;                                     // this wave's segment cursor
         double mx = -INFINITY, cmin = -INFINITY;        // cmin holds -min(chi2)
         if (!flags[s]) {
             for (int64_t ob = a + (int64_t)w * 64; ob < b; ob += TILE) {
@@ -777,7 +790,23 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                     if (o0 >= b) break;                                  // wave-uniform
                     const int nrec = (int)(b - o0 < MCA_R ? b - o0 : MCA_R);
                     const int64_t j0 = (o0 - off2[s]) * run;
-                    for (int k = lane; k < nrec * run; k += 64) zt[k] = zsrc[j0 + k];
+                    if (mapped) {
+                        // (a tile of MCA_R records = 600 pairs spans at most two segments)
+                        const int64_t pf = j0 > c_o ? (j0 - c_o) >> 1 : 0;
+                        while (sg + 1 < nsg && zm.seg_pair0[slo + sg + 1] <= pf) ++sg;
+                        const int64_t p0 = zm.seg_pair0[slo + sg], a0 = zm.seg_addr[slo + sg];
+                        const bool two = sg + 1 < nsg;
+                        const int64_t p1 = two ? zm.seg_pair0[slo + sg + 1] : INT64_MAX;
+                        const int64_t a1 = two ? zm.seg_addr[slo + sg + 1] : 0;
+                        const double *const zd = (const double *)zm.zloc;
+                        for (int k = lane; k < nrec * run; k += 64) {
+                            const int64_t jj = j0 + k, pq = jj - c_o, pr = pq >> 1;
+                            const int64_t ad = pr >= p1 ? a1 + (pr - p1) : a0 + (pr - p0);
+                            zt[k] = jj < c_o ? zm.cached[s] : zd[2 * ad + (pq & 1)];
+                        }
+                    } else {
+                        for (int k = lane; k < nrec * run; k += 64) zt[k] = zsrc[j0 + k];
+                    }
                     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
                     __builtin_amdgcn_wave_barrier();
                     const bool live = rec8 < nrec;
@@ -985,7 +1014,7 @@ k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int
             const StarGeom *__restrict__ geom, const double *__restrict__ feh,
             const double *__restrict__ loga, RecPost rp, const double *__restrict__ cdf,
             const double *__restrict__ star_out, int32_t *__restrict__ out_idx,
-            double *__restrict__ out_vals) {
+            double *__restrict__ out_vals, ZMap zm) {
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
@@ -1034,7 +1063,9 @@ k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int
     double m = -INFINITY;
     bool inb_;
     NormalReader rd[3];
-    rd[0].init(seed, zo); rd[1].init(seed, zo); rd[2].init(seed, zo);
+    const ZMap *zmp = zm.zloc ? &zm : nullptr;      // (zarr is then only a flag: nb = 0)
+    if (zmp) zo = nullptr;
+    rd[0].init(seed, zo, zmp, s); rd[1].init(seed, zo, zmp, s); rd[2].init(seed, zo, zmp, s);
     for (int t = 0; t < pp.nmc; ++t) {
         double d_, a_, r_;
         const double v = mc_sample(pp, rd, g, nb, lo, t, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb_);

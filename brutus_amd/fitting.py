@@ -345,9 +345,11 @@ class _Engine(object):
                 if zb is None:
                     import os
                     # normals of one group of objects; a 128-object batch of the bench
-                    # workload (1.4e5 kept models x 150 normals each) needs ~22 GB + 1/8 scratch
+                    # workload (1.4e5 kept models x 150 normals each) needs ~22 GB as a flat
+                    # array, ~29 GB as the pairs of one stream walk (16 B per generated
+                    # slot), + 1/8 scratch
                     free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
-                    gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.25 * free))))
+                    gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(64., max(1., 0.25 * free))))
                     zb = slot0["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64,
                                                      device=g.device)
                 self._set_dust(dust)          # one-shot context: before EVERY (re)try
@@ -410,8 +412,12 @@ class _Engine(object):
         if ctx.get("ws") is None or ctx["ws"].numel() < nbytes:
             ctx["ws"] = torch.empty(nbytes, dtype=torch.uint8, device=g.device)
         if ctx.get("zbuf") is None:
-            free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
-            gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB", min(48., max(1., 0.2 * free))))
+            # (both slots of the pipeline get the size the first one was given)
+            gb = self.__dict__.get("_zbuf_gb")
+            if gb is None:
+                free = torch.cuda.mem_get_info(g.device)[0] / 2 ** 30
+                gb = self._zbuf_gb = float(os.environ.get("BRUTUS_AMD_ZBUF_GB",
+                                                          min(64., max(1., 0.22 * free))))
             ctx["zbuf"] = torch.empty(int(gb * 2 ** 30) // 8, dtype=torch.float64, device=g.device)
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).to(g.device)
         lnprior, feh, loga = statics
