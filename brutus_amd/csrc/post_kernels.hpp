@@ -708,9 +708,9 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     }
                     // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
                     // sample in bounds the reference yields +inf -> not finite -> -BIG
-                    double lse = pp.lnK + log(acc);
+                    double lse = pp.lnK + fast_log_r(acc);
                     if (g.has_par || g.dust_on) lse += M - (g.has_par ? 0.5 * g.par_lnorm : 0.);
-                    double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
+                    double lnp = ninb > 0 ? rp.lnp[o] + (lse - fast_log_r((double)ninb)) : nan("");
                     if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
                     rp.lnp[o] = lnp;
                     if (lnp > mx) mx = lnp;
@@ -864,9 +864,9 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                     if (live && grp == 0) {
                         // logsumexp(lnp_mc) - ln(#in bounds), fitting.py:1094-1102; with no
                         // sample in bounds the reference yields +inf -> not finite -> -BIG
-                        double lse = pp.lnK + log(acc);
+                        double lse = pp.lnK + fast_log_r(acc);
                         if (g.has_par || g.dust_on) lse += M - (g.has_par ? 0.5 * g.par_lnorm : 0.);
-                        double lnp = ninb > 0 ? rp.lnp[o] + (lse - log((double)ninb)) : nan("");
+                        double lnp = ninb > 0 ? rp.lnp[o] + (lse - fast_log_r((double)ninb)) : nan("");
                         if (!isfinite(lnp)) lnp = -BIG;                       // fitting.py:1103-1105
                         rp.lnp[o] = lnp;
                         if (lnp > mx) mx = lnp;
