@@ -205,7 +205,12 @@ int brutus_post_batch(int nstar, int64_t capacity, const int32_t *d_sel_idx, con
  *                    a stream is sequential by nature: one workgroup walks it
  *   nstream == nstar object s has its own stream (per-object seeds: sharded runs)
  * d_zbuf (zbuf_doubles float64) receives the normals of a group of objects; an object
- * needs 3 * nmc * Nsel + 3 doubles; BRUTUS_ENOMEM if a single object does not fit. */
+ * needs 3 * nmc * Nsel + 3 doubles; BRUTUS_ENOMEM if a single object does not fit.  The
+ * first eighth of the buffer is scratch of the stream walk.  When all objects of the call
+ * fit as one group, nmc <= 64 and the rest of the buffer also holds 16 bytes per generated
+ * slot (about 1.3 x the flat normals), the stream is walked once: the accepted candidates'
+ * normals stay where the walk produced them and the consumers read them through per-object
+ * segment lists; otherwise a second walk writes the flat array.  Same results either way. */
 int brutus_post_batch_numpy(int nstar, int64_t capacity, const int32_t *d_sel_idx, const int32_t *d_rec_slot,
                             const double *d_sel_vals, const int64_t *d_sel_off,
                             const double *d_lnprior, const double *d_feh,
