@@ -98,6 +98,7 @@ SIGNATURES = {
     "brutus_debug_mt_stream": (C.c_int, [_i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp]),
     "brutus_set_mt_jump": (C.c_int, [_vp, _i32, _i64, _i64]),
     "brutus_post_set_dust": (C.c_int, [_vp, _vp, _i32, _dbl, _dbl, _dbl, _dbl]),
+    "brutus_post_set_after_jump": (C.c_int, [_vp, _vp]),
     "brutus_debug_rng": (C.c_int, [_u64, _u64, _i64, _vp, _vp, _vp]),
     "brutus_debug_zig_table": (C.c_int, [_vp, _vp, _i32]),
     "brutus_debug_galprior": (C.c_int, [C.POINTER(PostParams), _i32, _vp, _vp, _vp, _vp,

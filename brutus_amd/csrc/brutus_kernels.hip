@@ -694,6 +694,22 @@ struct PinnedBuf {
 };
 thread_local PinnedBuf g_plan_pin;
 
+// brutus_post_set_after_jump: a caller's hook, fired once from the calling thread when the
+// jump-ahead windows of its next numpy-stream call are complete (the stream is drained
+// first) -- or, if that call takes no jump, at the latest before it returns.
+struct AfterJump {
+    void (*fn)(void *);
+    void *arg;
+};
+thread_local AfterJump g_after_jump{nullptr, nullptr};
+void fire_after_jump(hipStream_t st) {
+    if (!g_after_jump.fn) return;
+    const AfterJump h = g_after_jump;
+    g_after_jump = AfterJump{nullptr, nullptr};
+    (void)hipStreamSynchronize(st);
+    h.fn(h.arg);
+}
+
 // k_mt_emit of a walk whose caller asked for it to be deferred (phase 1 of
 // brutus_post_batch_numpy_phase): everything it reads stays in the caller's buffers.
 struct MtEmitLaunch {
@@ -916,6 +932,7 @@ int mt_walk_parallel(int nstream, const std::vector<int32_t> &seg, uint32_t *d_s
         hipLaunchKernelGGL(k_mt_jump, dim3((unsigned)n2), dim3(MT_NT), jlds, st, d_polys, d_win, d_c2s,
                            d_c2d, (int64_t)1, d_c2n);
     tm.end();
+    fire_after_jump(st);
     // ---- pass 1, prefix, boundaries ----------------------------------------------------------
     tm.begin("k_mt_bits");
     if (mapped)
@@ -1659,6 +1676,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
             static const int use_arr_ = env_int("BRUTUS_POST_MC_ARR", 1);
             const bool try_mapped = use_mapped && use_arr_ && pp.nmc <= MCA_NMC && s0 == 0 && s1 == nstar;
             MtEmitLaunch el{};
+            hipEvent_t uni_event = nullptr;
             if (phase != 2) {
             HIP_TRY(hipMemcpyAsync(w.mt_nnorm, nnorm.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
             HIP_TRY(hipMemcpyAsync(w.mt_zoff, zoff.data(), 8 * (size_t)nstar, hipMemcpyHostToDevice, st));
@@ -1670,8 +1688,11 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 if (int rc = mt_walk(nseg, segv, d_states, p0, nnorm, w.mt_seg, w.mt_nnorm, w.mt_zoff, zbase,
                                      nuni, w.mt_uni, (char *)mt->d_zbuf, zscratch, nstar, st, tm,
                                      phase == 1, try_mapped ? (double2 *)zbase : (double2 *)nullptr,
-                                     try_mapped ? zdoubles / 2 : 0, &el))
+                                     try_mapped ? zdoubles / 2 : 0, &el)) {
+                    fire_after_jump(st);
                     return rc;
+                }
+                fire_after_jump(st);          // (no jump taken: the sequential walker)
                 for (int q = 0; q < nseg; ++q) hpos[mt->nstream == 1 ? 0 : s0 + q] = p0[q];
             }
             }      // phase != 2
@@ -1694,7 +1715,36 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                         have = true;
                     }
                 }
-                if (have) launch_mt_emit(el, st, tm);
+                // The uniform slots (few workgroups, each walking a sub-stream: latency, not
+                // work) go to a side stream beside the Monte Carlo integral; the draws wait
+                // for them.  (With kernel timing on, everything stays on the one stream.)
+                if (have && el.uni_only && !g_timing) {
+                    thread_local hipStream_t side = nullptr;
+                    thread_local hipEvent_t ev_in = nullptr, ev_out = nullptr;
+                    if (!side) {
+                        HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+                        HIP_TRY(hipEventCreateWithFlags(&ev_in, hipEventDisableTiming));
+                        HIP_TRY(hipEventCreateWithFlags(&ev_out, hipEventDisableTiming));
+                    }
+                    HIP_TRY(hipEventRecord(ev_in, st));             // (whatever the caller queued)
+                    HIP_TRY(hipStreamWaitEvent(side, ev_in, 0));
+                    // segment lists on the main stream (the integral needs them) ...
+                    hipLaunchKernelGGL(k_mt_segments, dim3((unsigned)el.nobj), dim3(64), 0, st, el.nstream,
+                                       el.seg, el.nnorm, el.gauss0, el.subs, el.subbase, el.bitbase,
+                                       el.sblo, el.bits, el.pre, el.objs, el.zm.zloc,
+                                       const_cast<int64_t *>(el.zm.seg_pair0),
+                                       const_cast<int64_t *>(el.zm.seg_addr),
+                                       const_cast<int64_t *>(el.zm.seg_lo), const_cast<int32_t *>(el.zm.nseg),
+                                       const_cast<double *>(el.zm.cached), const_cast<int32_t *>(el.zm.c));
+                    // ... the uniforms on the side stream
+                    hipLaunchKernelGGL(k_mt_emit, dim3((unsigned)el.Ktot), dim3(MT_PT), 0, side, el.Ktot,
+                                       el.subs, el.win, el.bits, el.bitbase, el.sblo, el.pre, el.seg,
+                                       el.objs, el.nnorm, el.zoff, el.Z, el.nuni, el.U, el.endgauss, 1);
+                    HIP_TRY(hipEventRecord(ev_out, side));
+                    uni_event = ev_out;
+                } else if (have) {
+                    launch_mt_emit(el, st, tm);
+                }
             }
             tm.begin("k_post_mc");
             {
@@ -1729,6 +1779,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                                w.part_chi2, w.part, w.part_w, w.rp, w.cdf, w.star_out);
             tm.end();
             tm.begin("k_post_draw");
+            if (uni_event) HIP_TRY(hipStreamWaitEvent(st, uni_event, 0));
             hipLaunchKernelGGL(k_post_draw, dim3((pp.ndraws + 63) / 64, ng), dim3(64), 0, st, pp, s0,
                                (const double *)zbase, (const int64_t *)w.mt_zoff,
                                (const double *)w.mt_uni, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
@@ -1802,6 +1853,11 @@ int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_
     return post_batch_impl(nstar, capacity, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, d_lnprior, d_feh, d_loga,
                            d_coords, d_parallax, d_parallax_err, params, d_workspace, workspace_bytes,
                            d_out_idx, d_out_vals, h_star_out, h_flags, nullptr, stream, &mt);
+}
+
+int brutus_post_set_after_jump(void (*fn)(void *), void *arg) {
+    g_after_jump = AfterJump{fn, arg};
+    return 0;
 }
 
 int brutus_post_set_dust(const double *d_los, const int32_t *d_ok, int nd, double offset,

@@ -397,11 +397,13 @@ class _Engine(object):
                                                    int(t_los.shape[2]), 0., 1., 1., 0.2))
 
     def post_numpy_begin(self, slot, rec, nstar, statics, coords,
-                         parallax, parallax_err, pp, np_states, dust=None):
+                         parallax, parallax_err, pp, np_states, dust=None, after_jump=None):
         """Phase 1 of `brutus_post_batch_numpy_phase` in pipeline slot `slot` (own
         workspace, normal buffer and outputs): cuts, covariances, stream walk; `np_states`
         is advanced.  False if the objects do not fit the slot's buffer as one group
-        (nothing consumed: use `post_batch_device`)."""
+        (nothing consumed: use `post_batch_device`).  `after_jump()` is called exactly once
+        from inside the call, when the walk's jump-ahead windows are complete
+        (`brutus_post_set_after_jump`) -- or before this method returns, whatever happens."""
         import os
         torch, L, g = self.torch, self.L, self.grid
         ctxs = self.__dict__.setdefault("_post_slots", {})
@@ -443,7 +445,24 @@ class _Engine(object):
                 np_states.ctypes.data, ctx["zbuf"].data_ptr(), ctx["zbuf"].numel(), phase,
                 _stream_ptr(torch))
         ctx["call"] = call
-        rc = call(1)
+        fired = [after_jump is None]
+        if after_jump is not None:
+            import ctypes as C
+
+            def hook(_arg):
+                if not fired[0]:
+                    fired[0] = True
+                    after_jump()
+            cb = ctx["hook"] = C.CFUNCTYPE(None, C.c_void_p)(hook)      # (kept alive by the slot)
+            L.brutus_post_set_after_jump(C.cast(cb, C.c_void_p), None)
+        try:
+            rc = call(1)
+        finally:
+            if after_jump is not None:
+                L.brutus_post_set_after_jump(None, None)
+                if not fired[0]:
+                    fired[0] = True
+                    after_jump()
         if rc == -2 and b"normal buffer too small" in L.brutus_last_error():
             return False
         _lib.check(rc)
@@ -1260,9 +1279,10 @@ class BruteForce(object):
             if pipelined:
                 finisher = concurrent.futures.ThreadPoolExecutor(max_workers=1)
                 fin_stream = torch.cuda.Stream(device=dev)
-                # phase 1 is a chain of short kernels, small copies and host decisions:
-                # high priority, or each of them queues behind the long phase-2 kernels
-                walk_stream = torch.cuda.Stream(device=dev, priority=-1)
+                # (default priority: the walk's pass 1 is a long kernel, and a high-priority
+                # stream with thousands of workgroups queued starves phase 2 of the previous
+                # batch until it is through -- the two then run one after the other)
+                walk_stream = torch.cuda.Stream(device=dev)
         else:
             engines, streams, pool = (eng, eng), (None, None), None
 
@@ -1322,7 +1342,8 @@ class BruteForce(object):
                     res += (v[:, 13], v[:, 14], v[:, 15], v[:, 16])
                 yield res
 
-        pending = None        # (future of phase 2, row arguments) of the previous batch
+        pending = None        # (future of phase 2, row arguments) of an earlier batch
+        unsub = [None]        # (slot, row arguments) of the batch whose phase 2 is not submitted yet
         try:
             fut = pool.submit(scan, 0) if ahead else None
             for kb, a in enumerate(starts):
@@ -1369,22 +1390,33 @@ class BruteForce(object):
                         dust = (torch.from_numpy(np.ascontiguousarray(los)).to(dev),     # them alive
                                 torch.from_numpy(np.ascontiguousarray(ok)).to(dev))
                     if pipelined:
+                        # Phase 2 of the previous batch is held back until the jump-ahead of
+                        # THIS batch's walk is through (its kernels need whole compute units
+                        # and would starve behind the Monte Carlo integral), then runs beside
+                        # the walk itself.  `pending`: phase 2 submitted; `unsub`: phase 1 done.
+                        if pending is not None:      # (its slot is the one this batch takes)
+                            prev, pargs = pending
+                            pending = None
+                            for row in rows(*(pargs + prev.result() + (0,))):
+                                yield row
+                        sub = []
+
+                        def submit_prev():
+                            if unsub[0] is not None:
+                                slot_, args_ = unsub[0]
+                                unsub[0] = None
+                                sub.append((finisher.submit(finish, slot_), args_))
                         with torch.cuda.stream(walk_stream):
                             began = eng.post_numpy_begin(
                                 kb % 2, rec, S, statics, data_coords[a:b],
-                                parallax[a:b], parallax_err[a:b], pp, np_states, dust=dust)
+                                parallax[a:b], parallax_err[a:b], pp, np_states, dust=dust,
+                                after_jump=submit_prev)
+                        if sub:
+                            pending = sub[0]
                         if began:
                             if np_mode == "shared":   # final already: the walk is done
                                 rstate.set_state(words_to_state(np_states[0]))
-                            job = finisher.submit(finish, kb % 2)
-                            args = (a, S, rec, off, ndim, k1, k2)
-                            if pending is not None:
-                                prev, pargs = pending
-                                pending = (job, args)
-                                for row in rows(*(pargs + prev.result() + (0,))):
-                                    yield row
-                            else:
-                                pending = (job, args)
+                            unsub[0] = (kb % 2, (a, S, rec, off, ndim, k1, k2))
                             continue
                         if pending is not None:      # whole-call form for this batch, in order
                             prev, pargs = pending
@@ -1408,6 +1440,11 @@ class BruteForce(object):
                 prev, pargs = pending
                 pending = None
                 for row in rows(*(pargs + prev.result() + (0,))):
+                    yield row
+            if unsub[0] is not None:
+                slot_, pargs = unsub[0]
+                unsub[0] = None
+                for row in rows(*(pargs + finisher.submit(finish, slot_).result() + (0,))):
                     yield row
         finally:
             if pool is not None:      # also when the caller abandons the generator

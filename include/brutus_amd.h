@@ -240,6 +240,16 @@ int brutus_post_batch_numpy_phase(int nstar, int64_t capacity, const int32_t *d_
                                   int nstream, uint32_t *h_states, double *d_zbuf,
                                   size_t zbuf_doubles, int phase, void *stream);
 
+/* Scheduling hook for callers that pipeline the two phases: `fn(arg)` is called once, on the
+ * calling thread, from inside the NEXT brutus_post_batch_numpy[_phase] call of this thread,
+ * as soon as the jump-ahead windows of its stream walk are complete (the call's stream is
+ * drained first), at the latest before that call returns or fails after its walk.  The
+ * jump-ahead kernels need whole compute units (125 KB of LDS per workgroup) and starve
+ * behind a long kernel of another stream: a caller holds back phase 2 of the previous batch
+ * until the hook fires, and the two then overlap where they can (stream walk: LDS-bound,
+ * Monte Carlo integral: float64-issue-bound).  fn == NULL clears a pending hook. */
+int brutus_post_set_after_jump(void (*fn)(void *), void *arg);
+
 /* Line-of-sight dust prior for the NEXT brutus_post_batch / brutus_post_batch_numpy call
  * of the calling thread (one-shot): the reference's `dust_lnprior` (pdf.py:752-840,
  * Gaussian in Av around the profile interpolated at the distance) with the profile of every
