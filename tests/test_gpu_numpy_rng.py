@@ -359,3 +359,30 @@ def test_one_walk_of_the_stream_equals_two_walks_bit_for_bit(tmp_path):
     for i in range(6):
         nsel = max(nsel, len(np.unique(res["1"]["o%d_0" % i])))
     assert nsel > 10            # (the draws are spread over many models: broad posteriors)
+
+
+def test_pipelined_numpy_fit_can_be_abandoned_and_repeated():
+    """The `_fit` generator of the two-phase numpy-stream pipeline (phase 2 of a batch held back
+    until the next batch's jump-ahead is through) is closed after 1, 9, 17, 33 objects -- in
+    the first batch, at a batch boundary, inside a later batch -- and run again: what it
+    yielded equals the full run, nothing hangs, and a complete run afterwards is identical."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    models, labels, lmask = synth.make_mist_like_grid(60000, 8, seed=3)
+    st = synth.make_stars(models, 40, seed=4)
+    bf = fitting.BruteForce(models, labels, lmask)
+    bf.batch_size = 8
+    lnprior = bf._setup(st["flux"], st["err"], st["mask"], None, data_coords=st["coords"],
+                        lngalprior=gal_lnprior)[5]
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
+              lnprior=lnprior, lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=50)
+    full = list(bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(1), **kw))
+    assert len(full) == 40
+    for stop in (1, 9, 17, 33):
+        g = bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(1), **kw)
+        got = [next(g) for _ in range(stop)]
+        g.close()
+        assert all(np.array_equal(a[0], b[0]) for a, b in zip(got, full)), stop
+    again = list(bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(1), **kw))
+    assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[6], b[6])
+               for a, b in zip(again, full))
