@@ -248,7 +248,7 @@ k_mt_stream(int nseg, const int32_t *__restrict__ seg_obj0, uint32_t *__restrict
 //                 index, uniform slots -> uniforms
 //   k_mt_advance  the generator state after the last consumed word, in numpy's form.
 constexpr int64_t MT_J = 624 * 3360;          // words per sub-stream (mt_jump.npz strides[0])
-constexpr int MT_L1 = 16;                     // sub-streams per first-level window (strides[1] = 16 J)
+constexpr int MT_L1 = 4;                      // sub-streams per first-level window (strides[1] = 4 J)
 constexpr int MT_SB = 4096;                   // slots per superblock
 constexpr int MT_JX = 34 * 624;                // words of X a jump generates (>= 19937 + 625)
 

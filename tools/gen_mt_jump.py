@@ -161,9 +161,11 @@ def main():
     assert phi.bit_length() - 1 == N and (phi & 1)
     print("phi: degree %d, weight %d" % (N, bin(phi).count("1")))
     J = 624 * 3360                      # 2 096 640 words per sub-stream
-    # first-level strides 16 J * 2^r: the first-level windows of a long stream come from a
-    # doubling tree (depth log2 instead of a sequential chain)
-    strides = [J] + [16 * J * 2 ** r for r in range(14)]
+    # first-level strides L1 J * 2^r (L1 = MT_L1 of mt_kernels.hpp): the first-level windows
+    # of a long stream come from a doubling tree (depth log2 instead of a sequential chain),
+    # the L1 - 1 sub-streams behind each of them from a chain of single jumps
+    L1 = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+    strides = [J] + [L1 * J * 2 ** r for r in range(14)]
     polys = []
     for m in strides:
         g = xpow_mod(m - 1, phi, N)
