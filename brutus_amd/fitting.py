@@ -1394,11 +1394,11 @@ class BruteForce(object):
                         # THIS batch's walk is through (its kernels need whole compute units
                         # and would starve behind the Monte Carlo integral), then runs beside
                         # the walk itself.  `pending`: phase 2 submitted; `unsub`: phase 1 done.
-                        if pending is not None:      # (its slot is the one this batch takes)
-                            prev, pargs = pending
-                            pending = None
-                            for row in rows(*(pargs + prev.result() + (0,))):
-                                yield row
+                        ready = None
+                        if pending is not None:      # (its slot is the one this batch takes:
+                            prev, pargs = pending    # wait for it now, hand out its rows later,
+                            pending = None           # while the device is busy again)
+                            ready = pargs + prev.result() + (0,)
                         sub = []
 
                         def submit_prev():
@@ -1417,6 +1417,10 @@ class BruteForce(object):
                             if np_mode == "shared":   # final already: the walk is done
                                 rstate.set_state(words_to_state(np_states[0]))
                             unsub[0] = (kb % 2, (a, S, rec, off, ndim, k1, k2))
+                        if ready is not None:
+                            for row in rows(*ready):
+                                yield row
+                        if began:
                             continue
                         if pending is not None:      # whole-call form for this batch, in order
                             prev, pargs = pending
