@@ -65,7 +65,7 @@ def parse():
                     help="host threads / HIP streams per GPU, each with its own "
                          "workspace, taking the steps round-robin (kernels of "
                          "consecutive batches overlap on the device)")
-    ap.add_argument("--e2e-stars", type=int, default=2048,
+    ap.add_argument("--e2e-stars", type=int, default=4096,
                     help="stars of the sequential-RandomState end-to-end BruteForce.fit() "
                          "leg reported beside the metric (0 = skip all end-to-end legs); "
                          "rank 0, N=1 only")
@@ -153,7 +153,7 @@ def end_to_end(models, grid, stars, n, kw, with_par):
            "note": "BruteForce.fit, one sequential numpy RandomState like the reference "
                    "(Nmc_prior=50, Ndraws=250, HDF5); lnpost on the device, numpy's stream "
                    "reproduced word for word"}
-    n2 = 2048
+    n2 = min(4096, max(n, 1))
     # per-object numpy seeds go through _fit (fit() itself takes one rstate)
     from brutus_amd import h5io
     bf.batch_size = 128
