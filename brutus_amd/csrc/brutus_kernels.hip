@@ -1506,6 +1506,19 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     pp.c0_thin = pp.R_solar * pp.inv_R_thin - pp.lnK;
     pp.c0_thick = pp.R_solar * pp.inv_R_thick + pp.ln_f_thick - pp.lnK;
     pp.c0_halo = pp.ln_f_halo - pp.lnK;
+    // halo_pow (post_kernels.hpp): (1 + r)^-h = sum_n b_n r^n, b_n = b_(n-1) (-h - n + 1) / n.
+    // The table form needs the series' first dropped term below 2^-54 at |r| = 1/256 and
+    // X = reff^2 / reff_sun^2 >= 2^-HALO_E0 for every distance.
+    const double h = 0.5 * pp.eta_halo;
+    double b = 1.;
+    for (int n = 1; n <= 8; ++n) {
+        b *= (-h - (double)n + 1.) / (double)n;
+        if (n <= 7) pp.halo_b[n - 1] = b;
+    }
+    const bool ok = std::isfinite(h) && fabs(b) * ldexp(1., -64) < ldexp(1., -54) &&
+                    pp.Rs_halo2 * pp.inv_reff_solar2 >= ldexp(1., -HALO_E0) && std::isfinite(pp.c0_halo) &&
+                    !getenv("BRUTUS_NO_HALO_TBL");
+    pp.halo_tbl = ok ? 1. : 0.;
 }
 
 size_t brutus_post_workspace_bytes(int nstar, int64_t capacity, int nmc) {

@@ -139,8 +139,11 @@ struct PostParams {     // mirrors brutus_post_params
     double lnK, c0_thin, c0_thick, c0_halo;      // component constants relative to lnK
     // label_terms: -1 / (2 sigma^2), -ln(2 pi sigma^2) / 2; 1 / sigma_age, -ln(2 pi) / 2 - lnnorm
     double feh_nh_isig2[3], feh_c0[3], age_isig[3], age_c0[3];
+    // halo_pow: binomial coefficients of (1 + r)^(-eta/2), r^1 .. r^7; halo_tbl != 0 when the
+    // table form is valid for these parameters (fill_post_params)
+    double halo_b[7], halo_tbl;
 };
-constexpr int POST_DERIVED = 29;
+constexpr int POST_DERIVED = 37;
 
 // stream key and uniform base of object s: one shared sequential stream, or
 // (per_object) an own stream keyed seed + object index
@@ -231,6 +234,45 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
     }
 }
 
+// The halo's power law f (reff / reff_sun)^-eta without a logarithm and an exponential.
+// With X = reff^2 / reff_sun^2 = 2^e c_k (1 + r), c_k = 1 + (k + 1/2) / 128 the centre of the
+// mantissa's k-th 1/128 step and h = eta / 2:
+//   e^c0_halo X^-h = [e^c0_halo 2^(-h e)] [c_k^-h] (1 + r)^-h,   |r| <= 1/256,
+// two table entries and a degree-7 binomial series (next term < 2^-54 for the h that
+// fill_post_params admits): 10 float64 operations and a handful of integer ones instead of
+// the ~50 of fast_exp_fin(c0 - h fast_log_pos(X)); <= 4 ulp.  HALO_E0 bounds X from below
+// (fill_post_params checks Rs_halo^2 / reff_sun^2 >= 2^-HALO_E0; an in-bounds sample has
+// dist <= 1e10 kpc, far inside the 128 exponents tabulated).
+// Table layout (LDS, stage_halo_table): [0, 128) e^c0_halo 2^(-h (i - HALO_E0)), [128, 256) c_k^-h,
+// [256, 384) 1 / c_k.
+constexpr int HALO_E0 = 8, HALO_TBL = 384;
+__device__ __forceinline__ void stage_halo_table(const PostParams &pp, double *ht) {
+    if (pp.halo_tbl == 0.) return;
+    const double h = 0.5 * pp.eta_halo;
+    for (int k = threadIdx.x; k < 128; k += blockDim.x) {
+        const double ic = 1. / (1. + ((double)k + 0.5) * (1. / 128.));
+        ht[256 + k] = ic;
+        ht[128 + k] = pow(ic, h);              // (1 / ic)^-h with the ROUNDED 1 / c_k: consistent with r
+        ht[k] = exp(pp.c0_halo) * pow(2., -h * (double)(k - HALO_E0));
+    }
+}
+__device__ __forceinline__ double halo_pow(const PostParams &pp, double X, const double *__restrict__ ht) {
+    const unsigned hi = (unsigned)__double2hiint(X);
+    const unsigned ie = ((hi >> 20) - (unsigned)(1023 - HALO_E0)) & 127u;
+    const unsigned k = (hi >> 13) & 127u;
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(X));
+    const double r = fma(m, ht[256 + k], -1.);
+    double pl = pp.halo_b[6];
+    pl = fma(pl, r, pp.halo_b[5]);
+    pl = fma(pl, r, pp.halo_b[4]);
+    pl = fma(pl, r, pp.halo_b[3]);
+    pl = fma(pl, r, pp.halo_b[2]);
+    pl = fma(pl, r, pp.halo_b[1]);
+    pl = fma(pl, r, pp.halo_b[0]);
+    pl = fma(pl, r, 1.);
+    return (ht[ie] * ht[128 + k]) * pl;
+}
+
 // gal_lnprior (brutus_amd/galprior.py, reference pdf.py:476-749) at distance d [kpc],
 // as a plain density relative to e^lnK: gal_lnprior = lnK + ln(gal_prior_lin).
 // With T_c = exp(comp_c - lnK) the three log-sum-exps of the reference collapse:
@@ -242,7 +284,8 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
 // Cost per call: 3 exp + 1 log (halo power) + 3 sqrt + 2 reciprocals.
 __device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const StarGeom &g, double d,
                                                 const double (&EF)[3], const double (&EA)[3],
-                                                const double *__restrict__ tbl) {
+                                                const double *__restrict__ tbl,
+                                                const double *__restrict__ ht = nullptr) {
     // Galactocentric position (reference pdf.py:631-635): frame offset + d * direction
     const double x = fma(d, g.ux, pp.frame_off[0]), y = fma(d, g.uy, pp.frame_off[1]),
                  Z = fma(d, g.uz, pp.frame_off[2]);
@@ -258,8 +301,9 @@ __device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const Star
                      (pp.q_halo_inf - pp.q_halo_ctr) *
                          fast_exp_fin(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
     const double zq = Z * fast_rcp(q);
-    const double T2 = fast_exp_fin(
-        pp.c0_halo - 0.5 * pp.eta_halo * fast_log_pos((R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2), tbl);
+    const double X = (R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2;
+    const double T2 = ht ? halo_pow(pp, X, ht)
+                         : fast_exp_fin(pp.c0_halo - 0.5 * pp.eta_halo * fast_log_pos(X), tbl);
     double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
     if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
     if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
@@ -543,13 +587,14 @@ __device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGe
                                               const double (&L)[6], const double (&Fc)[3],
                                               const double (&Ac)[3], const double *__restrict__ tbl,
                                               double &dist, double &a_mc, double &r_mc, bool &inb,
-                                              double &lin, double &epar) {
+                                              double &lin, double &epar,
+                                              const double *__restrict__ ht = nullptr) {
     const double s_mc = s0 + L[0] * z0;
     a_mc = a0 + (L[1] * z0 + L[2] * z1);
     r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
     double par;
     fast_sqrt_rsqrt(s_mc, par, dist);                           // parallax and distance (~1 ulp)
-    lin = gal_prior_lin(pp, g, dist, Fc, Ac, tbl);
+    lin = gal_prior_lin(pp, g, dist, Fc, Ac, tbl, ht);
     const double dp = par - g.par;                              // pdf.py:166-173
     epar = g.has_par ? -0.5 * (dp * dp * g.par_ivar) : 0.;
     if (g.dust_on) epar += dust_lnp(g, dist, a_mc);             // fitting.py:1084-1085
@@ -609,8 +654,11 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     __shared__ unsigned int s_item;
     __shared__ double s_zx[ZIG_N + 1];
     __shared__ unsigned short s_pend[MC_PEND][TILE];
+    __shared__ double s_halo[HALO_TBL];
     stage_exp_table(s_tbl);
     stage_zig_table(s_zx);
+    stage_halo_table(pp, s_halo);
+    const double *const ht = pp.halo_tbl != 0. ? s_halo : nullptr;
     double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
     for (;;) {
         __syncthreads();
@@ -693,7 +741,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                         mc_sample_lin(pp, g, zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
                                       zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
                                       zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)], s0, a0, r0, L, Fc, Ac,
-                                      s_tbl, d_, a_, r_, inb, lin, epar);
+                                      s_tbl, d_, a_, r_, inb, lin, epar, ht);
                         ninb += inb ? 1 : 0;
                         if (g.has_par || g.dust_on) {
                             const double dM = epar - M;
@@ -756,7 +804,10 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
     extern __shared__ double s_z[];       // (TILE / 64) tiles of MCA_R * 3 * nmc normals: as
                                           // little LDS as the call needs, so that the stream
                                           // walkers of the next batch fit beside this kernel
+    __shared__ double s_halo[HALO_TBL];
     stage_exp_table(s_tbl);
+    stage_halo_table(pp, s_halo);
+    const double *const ht = pp.halo_tbl != 0. ? s_halo : nullptr;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rec8 = lane / MCA_G, grp = lane % MCA_G;
@@ -848,7 +899,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                             double d_, a_, r_, lin, epar;
                             bool inb;
                             mc_sample_lin(pp, g, zr[t], zr[pp.nmc + t], zr[2 * pp.nmc + t], s0, a0, r0, L,
-                                          Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar);
+                                          Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar, ht);
                             ninb += inb ? 1 : 0;
                             if (g.has_par || g.dust_on) {
                                 const double dM = epar - M;
