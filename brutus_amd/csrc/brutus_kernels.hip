@@ -1508,7 +1508,7 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     pp.c0_halo = pp.ln_f_halo - pp.lnK;
     // halo_pow (post_kernels.hpp): (1 + r)^-h = sum_n b_n r^n, b_n = b_(n-1) (-h - n + 1) / n.
     // The table form needs the series' first dropped term below 2^-54 at |r| = 1/256 and
-    // X = reff^2 / reff_sun^2 >= 2^-HALO_E0 for every distance.
+    // reff^2 >= Rs_halo^2 >= 2^-HALO_E0 for every distance.
     const double h = 0.5 * pp.eta_halo;
     double b = 1.;
     for (int n = 1; n <= 8; ++n) {
@@ -1516,7 +1516,8 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
         if (n <= 7) pp.halo_b[n - 1] = b;
     }
     const bool ok = std::isfinite(h) && fabs(b) * ldexp(1., -64) < ldexp(1., -54) &&
-                    pp.Rs_halo2 * pp.inv_reff_solar2 >= ldexp(1., -HALO_E0) && std::isfinite(pp.c0_halo) &&
+                    pp.Rs_halo2 >= ldexp(1., -HALO_E0) && std::isfinite(pp.c0_halo) &&
+                    std::isfinite(pow(pp.inv_reff_solar2, -h)) &&
                     !getenv("BRUTUS_NO_HALO_TBL");
     pp.halo_tbl = ok ? 1. : 0.;
 }
@@ -1601,7 +1602,8 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
         {
             const int nitem = PCH * nstar;
             HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
-            hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
+            hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_post_mc<true> : k_post_mc<false>,
+                               dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
                                capacity, 0, nitem, w.mc_counter, (const double *)nullptr,
                                (const int64_t *)nullptr, w.mc_stage, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp,
@@ -1766,7 +1768,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                 static const int use_arr = env_int("BRUTUS_POST_MC_ARR", 1);
                 static const int arr_persistent = env_int("BRUTUS_POST_MC_ARR_PERSISTENT", 0);
                 if (use_arr && pp.nmc <= MCA_NMC)
-                    hipLaunchKernelGGL(k_post_mc_arr,
+                    hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_post_mc_arr<true> : k_post_mc_arr<false>,
                                        dim3(arr_persistent ? (nitem < MC_SLOTS ? nitem : MC_SLOTS) : nitem), blk,
                                        sizeof(double) * (TILE / 64) * MCA_R * 3 * pp.nmc,
                                        st, pp, capacity, PCH * s0, PCH * s1,
@@ -1775,7 +1777,8 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                                        d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
                                        d_loga, w.rp, w.part_max, w.part_chi2, el.zm);
                 else
-                    hipLaunchKernelGGL(k_post_mc, dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
+                    hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_post_mc<true> : k_post_mc<false>,
+                                       dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
                                        pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, w.mc_stage,
                                        d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,

@@ -165,7 +165,30 @@ struct StarGeom {      // per object: sightline unit vector and parallax
     int dust_on, nd;
     const double *los;
     double d_off, d_scale, d_smooth, d_scat2;
+    // constants of the Monte Carlo integrand for this object (k_post_geom, McC): read by
+    // scalar loads inside the sample loop (mc_sample_c)
+    double mc[32];
 };
+
+// Layout of StarGeom::mc.  With the sightline's direction u and the frame offset o,
+// R^2(d) = |d u_xy + o_xy|^2 = A2 d^2 + A1 d + A0 and Z(d) = uz d + o2; the disks'
+// exponents with |Z_sun| folded into the constant, exp(1 - x) = e exp(-x) folded into dq.
+enum McC {
+    MC_A2, MC_A1, MC_A0, MC_UZ, MC_O2, MC_RS_THIN2, MC_RS_THICK2, MC_C0T, MC_IRT, MC_IZT, MC_C0K,
+    MC_IRK, MC_IZK, MC_QINF, MC_DQE, MC_RQ2, MC_IRQ, MC_RS_HALO2, MC_B1, MC_B2, MC_B3, MC_B4, MC_B5,
+    MC_B6, MC_B7, MC_AV0, MC_AV1, MC_RV0, MC_RV1, MC_PAR, MC_PIVAR, MC_NC
+};
+static_assert(MC_NC <= 32, "StarGeom::mc");
+// pointer into the constant address space: uniform loads through it are scalar loads
+typedef const double __attribute__((address_space(4))) *CPtr;
+// the same pointer, opaque to the optimiser: loads through the result cannot be hoisted
+// above this point, so the constants are fetched (s_load) per use instead of being held in --
+// and, beyond ~100, spilled from -- scalar registers for the whole loop
+__device__ __forceinline__ CPtr mc_refresh(CPtr p) {
+    uint64_t a = (uint64_t)p;
+    asm volatile("" : "+s"(a));
+    return (CPtr)a;
+}
 
 struct DustCtx {       // host side of brutus_post_set_dust
     const double *d_los;     // (nstar, 3, nd)
@@ -235,16 +258,16 @@ __device__ __forceinline__ void label_terms(const PostParams &pp, double feh, do
 }
 
 // The halo's power law f (reff / reff_sun)^-eta without a logarithm and an exponential.
-// With X = reff^2 / reff_sun^2 = 2^e c_k (1 + r), c_k = 1 + (k + 1/2) / 128 the centre of the
-// mantissa's k-th 1/128 step and h = eta / 2:
-//   e^c0_halo X^-h = [e^c0_halo 2^(-h e)] [c_k^-h] (1 + r)^-h,   |r| <= 1/256,
+// With Y = reff^2 = 2^e c_k (1 + r), c_k = 1 + (k + 1/2) / 128 the centre of the mantissa's
+// k-th 1/128 step, h = eta / 2 and X = Y / reff_sun^2:
+//   e^c0_halo X^-h = [e^c0_halo reff_sun^(2h) 2^(-h e)] [c_k^-h] (1 + r)^-h,   |r| <= 1/256,
 // two table entries and a degree-7 binomial series (next term < 2^-54 for the h that
 // fill_post_params admits): 10 float64 operations and a handful of integer ones instead of
-// the ~50 of fast_exp_fin(c0 - h fast_log_pos(X)); <= 4 ulp.  HALO_E0 bounds X from below
-// (fill_post_params checks Rs_halo^2 / reff_sun^2 >= 2^-HALO_E0; an in-bounds sample has
+// the ~50 of fast_exp_fin(c0 - h fast_log_pos(X)); <= 4 ulp.  HALO_E0 bounds Y from below
+// (fill_post_params checks Rs_halo^2 >= 2^-HALO_E0; an in-bounds sample has
 // dist <= 1e10 kpc, far inside the 128 exponents tabulated).
-// Table layout (LDS, stage_halo_table): [0, 128) e^c0_halo 2^(-h (i - HALO_E0)), [128, 256) c_k^-h,
-// [256, 384) 1 / c_k.
+// Table layout (LDS, stage_halo_table): [0, 128) e^c0_halo reff_sun^(2h) 2^(-h (i - HALO_E0)),
+// [128, 256) c_k^-h, [256, 384) 1 / c_k.
 constexpr int HALO_E0 = 8, HALO_TBL = 384;
 __device__ __forceinline__ void stage_halo_table(const PostParams &pp, double *ht) {
     if (pp.halo_tbl == 0.) return;
@@ -253,22 +276,23 @@ __device__ __forceinline__ void stage_halo_table(const PostParams &pp, double *h
         const double ic = 1. / (1. + ((double)k + 0.5) * (1. / 128.));
         ht[256 + k] = ic;
         ht[128 + k] = pow(ic, h);              // (1 / ic)^-h with the ROUNDED 1 / c_k: consistent with r
-        ht[k] = exp(pp.c0_halo) * pow(2., -h * (double)(k - HALO_E0));
+        ht[k] = exp(pp.c0_halo) * pow(pp.inv_reff_solar2, -h) * pow(2., -h * (double)(k - HALO_E0));
     }
 }
-__device__ __forceinline__ double halo_pow(const PostParams &pp, double X, const double *__restrict__ ht) {
-    const unsigned hi = (unsigned)__double2hiint(X);
+template <class B>
+__device__ __forceinline__ double halo_pow(const B &hb, double Y, const double *__restrict__ ht) {
+    const unsigned hi = (unsigned)__double2hiint(Y);
     const unsigned ie = ((hi >> 20) - (unsigned)(1023 - HALO_E0)) & 127u;
     const unsigned k = (hi >> 13) & 127u;
-    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(X));
+    const double m = __hiloint2double((int)((hi & 0x000fffffu) | 0x3ff00000u), __double2loint(Y));
     const double r = fma(m, ht[256 + k], -1.);
-    double pl = pp.halo_b[6];
-    pl = fma(pl, r, pp.halo_b[5]);
-    pl = fma(pl, r, pp.halo_b[4]);
-    pl = fma(pl, r, pp.halo_b[3]);
-    pl = fma(pl, r, pp.halo_b[2]);
-    pl = fma(pl, r, pp.halo_b[1]);
-    pl = fma(pl, r, pp.halo_b[0]);
+    double pl = hb[6];
+    pl = fma(pl, r, hb[5]);
+    pl = fma(pl, r, hb[4]);
+    pl = fma(pl, r, hb[3]);
+    pl = fma(pl, r, hb[2]);
+    pl = fma(pl, r, hb[1]);
+    pl = fma(pl, r, hb[0]);
     pl = fma(pl, r, 1.);
     return (ht[ie] * ht[128 + k]) * pl;
 }
@@ -301,9 +325,9 @@ __device__ __forceinline__ double gal_prior_lin(const PostParams &pp, const Star
                      (pp.q_halo_inf - pp.q_halo_ctr) *
                          fast_exp_fin(1. - fast_sqrt(R2 + Z * Z + pp.rq2) * pp.inv_r_q, tbl);
     const double zq = Z * fast_rcp(q);
-    const double X = (R2 + zq * zq + pp.Rs_halo2) * pp.inv_reff_solar2;
-    const double T2 = ht ? halo_pow(pp, X, ht)
-                         : fast_exp_fin(pp.c0_halo - 0.5 * pp.eta_halo * fast_log_pos(X), tbl);
+    const double Y = R2 + zq * zq + pp.Rs_halo2;
+    const double T2 = ht ? halo_pow(pp.halo_b, Y, ht)
+                         : fast_exp_fin(pp.c0_halo - 0.5 * pp.eta_halo * fast_log_pos(Y * pp.inv_reff_solar2), tbl);
     double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
     if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
     if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
@@ -602,6 +626,55 @@ __device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGe
           r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
 }
 
+// mc_sample_lin with the object's constants read through `cb` (StarGeom::mc, McC) and the
+// halo table: the form the two Monte Carlo kernels run when the table is valid.  Same
+// quantities; R^2 from the quadratic in d (rounding differs from x^2 + y^2 by ~1e-15
+// relative to R^2 + Rs^2), clamped at 0 against cancellation on a sightline through the
+// Galactic centre's axis.
+__device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const StarGeom &g, bool has_par,
+                                            bool dust_on, bool one_rs, double z0, double z1, double z2,
+                                            double s0, double a0, double r0, const double (&L)[6],
+                                            const double (&EF)[3], const double (&EA)[3],
+                                            const double *__restrict__ tbl, const double *__restrict__ ht,
+                                            bool &inb, double &lin, double &epar) {
+    const double s_mc = s0 + L[0] * z0;
+    const double a_mc = a0 + (L[1] * z0 + L[2] * z1);
+    const double r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
+    double par, d;
+    fast_sqrt_rsqrt(s_mc, par, d);
+    const double R2 = fmax(fma(fma(cb[MC_A2], d, cb[MC_A1]), d, cb[MC_A0]), 0.);
+    const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
+    const double aZ = fabs(Z);
+    const double Rt = fast_sqrt(R2 + cb[MC_RS_THIN2]);
+    const double Rk = one_rs ? Rt : fast_sqrt(R2 + cb[MC_RS_THICK2]);
+    const double T0 = fast_exp_fin(cb[MC_C0T] - fma(Rt, cb[MC_IRT], aZ * cb[MC_IZT]), tbl);
+    const double T1 = fast_exp_fin(cb[MC_C0K] - fma(Rk, cb[MC_IRK], aZ * cb[MC_IZK]), tbl);
+    const double q = cb[MC_QINF] -
+                     cb[MC_DQE] * fast_exp_fin(-(fast_sqrt(fma(Z, Z, R2) + cb[MC_RQ2]) * cb[MC_IRQ]), tbl);
+    const double zq = Z * fast_rcp(q);
+    struct HB {
+        CPtr c;
+        __device__ __forceinline__ double operator[](int k) const { return c[MC_B1 + k]; }
+    };
+    const double T2 = halo_pow(HB{cb}, fma(zq, zq, R2) + cb[MC_RS_HALO2], ht);
+    double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
+    if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
+    if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
+    const double S = T0 + T1 + T2;
+    const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
+    if (npow == 2) num *= fast_rcp(S);
+    else if (npow == 0) num *= S;
+    lin = num;
+    epar = 0.;
+    if (has_par) {
+        const double dp = par - cb[MC_PAR];                     // pdf.py:166-173
+        epar = -0.5 * (dp * dp * cb[MC_PIVAR]);
+    }
+    if (dust_on) epar += dust_lnp(g, d, a_mc);                  // fitting.py:1084-1085
+    inb = s_mc >= 1e-20 && a_mc >= cb[MC_AV0] && a_mc <= cb[MC_AV1] && r_mc >= cb[MC_RV0] &&
+          r_mc <= cb[MC_RV1];
+}
+
 // the same as one log value (-BIG outside the bounds, fitting.py:1086-1090),
 // drawing the normals on the fly
 __device__ __forceinline__ double mc_sample(const PostParams &pp, NormalReader (&rd)[3],
@@ -639,6 +712,7 @@ __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2;
 // double2); afterwards the lane integrates, reading three normals per sample.
 constexpr int MC_PEND = 8;
 
+template <bool HT>
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
           const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
@@ -657,8 +731,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     __shared__ double s_halo[HALO_TBL];
     stage_exp_table(s_tbl);
     stage_zig_table(s_zx);
-    stage_halo_table(pp, s_halo);
-    const double *const ht = pp.halo_tbl != 0. ? s_halo : nullptr;
+    if constexpr (HT) stage_halo_table(pp, s_halo);
+    const double *const ht = HT ? s_halo : nullptr;
     double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
     for (;;) {
         __syncthreads();
@@ -666,10 +740,12 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
         __syncthreads();
         const unsigned int item = s_item;
         if (item >= (unsigned int)nitem) break;
-        const int s = (int)(item / PCH), c = (int)(item % PCH);
+        const int s = __builtin_amdgcn_readfirstlane((int)(item / PCH)), c = (int)(item % PCH);
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
+        const CPtr cb0 = (CPtr)(uintptr_t)geom[s].mc;
+        const bool one_rs = pp.Rs_thick2 == pp.Rs_thin2;
         // array source (numpy stream reproduced by k_mt_stream): the object's normals are
         // numbered from 0 in its own slice of zarr
         const double2 *const zsrc = zarr ? reinterpret_cast<const double2 *>(zarr + zoff[s]) : nullptr;
@@ -738,10 +814,15 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                         bool inb;
                         // normal jj of the run: component jj & 1 of row jj >> 1
                         const int j0 = jb + t, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
-                        mc_sample_lin(pp, g, zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
-                                      zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
-                                      zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)], s0, a0, r0, L, Fc, Ac,
-                                      s_tbl, d_, a_, r_, inb, lin, epar, ht);
+                        const double z0 = zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
+                                     z1 = zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
+                                     z2 = zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)];
+                        if constexpr (HT)
+                            mc_sample_c(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, z0, z1, z2, s0,
+                                        a0, r0, L, Fc, Ac, s_tbl, ht, inb, lin, epar);
+                        else
+                            mc_sample_lin(pp, g, z0, z1, z2, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb, lin,
+                                          epar);
                         ninb += inb ? 1 : 0;
                         if (g.has_par || g.dust_on) {
                             const double dM = epar - M;
@@ -788,6 +869,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
 constexpr int MCA_R = 8, MCA_G = 8, MCA_NMC = 64;
 constexpr int MCA_U = 8;          // loads of the tile copy a lane keeps in flight
 
+template <bool HT>
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
               const double *__restrict__ zarr, const int64_t *__restrict__ zoff,
@@ -806,8 +888,8 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                                           // walkers of the next batch fit beside this kernel
     __shared__ double s_halo[HALO_TBL];
     stage_exp_table(s_tbl);
-    stage_halo_table(pp, s_halo);
-    const double *const ht = pp.halo_tbl != 0. ? s_halo : nullptr;
+    if constexpr (HT) stage_halo_table(pp, s_halo);
+    const double *const ht = HT ? s_halo : nullptr;
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int rec8 = lane / MCA_G, grp = lane % MCA_G;
@@ -822,10 +904,12 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
         __syncthreads();
         const unsigned int item = counter ? s_item : (unsigned int)item_base + blockIdx.x;
         if (item >= (unsigned int)nitem) break;
-        const int s = (int)(item / PCH), c = (int)(item % PCH);
+        const int s = __builtin_amdgcn_readfirstlane((int)(item / PCH)), c = (int)(item % PCH);
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
+        const CPtr cb0 = (CPtr)(uintptr_t)geom[s].mc;
+        const bool one_rs = pp.Rs_thick2 == pp.Rs_thin2;
         // the object's normals, numbered from 0: a flat array, or (zm.zloc) the pairs where
         // pass 1 of the stream walk left them, through the object's segment list
         const bool mapped = zm.zloc != nullptr;
@@ -898,8 +982,13 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
                         for (int t = grp; t < pp.nmc; t += MCA_G) {
                             double d_, a_, r_, lin, epar;
                             bool inb;
-                            mc_sample_lin(pp, g, zr[t], zr[pp.nmc + t], zr[2 * pp.nmc + t], s0, a0, r0, L,
-                                          Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar, ht);
+                            if constexpr (HT)
+                                mc_sample_c(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, zr[t],
+                                            zr[pp.nmc + t], zr[2 * pp.nmc + t], s0, a0, r0, L, Fc, Ac, s_tbl,
+                                            ht, inb, lin, epar);
+                            else
+                                mc_sample_lin(pp, g, zr[t], zr[pp.nmc + t], zr[2 * pp.nmc + t], s0, a0, r0, L,
+                                              Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar);
                             ninb += inb ? 1 : 0;
                             if (g.has_par || g.dust_on) {
                                 const double dM = epar - M;
@@ -1237,6 +1326,33 @@ __global__ void k_post_geom(PostParams pp, int nstar, const double *__restrict__
     g.d_scale = dc.scale;
     g.d_smooth = dc.smooth;
     g.d_scat2 = dc.scatter * dc.scatter;
+    const double o0 = pp.frame_off[0], o1 = pp.frame_off[1];
+    for (int k = 0; k < 32; ++k) g.mc[k] = 0.;
+    g.mc[MC_A2] = g.ux * g.ux + g.uy * g.uy;
+    g.mc[MC_A1] = 2. * (g.ux * o0 + g.uy * o1);
+    g.mc[MC_A0] = o0 * o0 + o1 * o1;
+    g.mc[MC_UZ] = g.uz;
+    g.mc[MC_O2] = pp.frame_off[2];
+    g.mc[MC_RS_THIN2] = pp.Rs_thin2;
+    g.mc[MC_RS_THICK2] = pp.Rs_thick2;
+    g.mc[MC_C0T] = pp.c0_thin + pp.abs_Z_solar * pp.inv_Z_thin;
+    g.mc[MC_IRT] = pp.inv_R_thin;
+    g.mc[MC_IZT] = pp.inv_Z_thin;
+    g.mc[MC_C0K] = pp.c0_thick + pp.abs_Z_solar * pp.inv_Z_thick;
+    g.mc[MC_IRK] = pp.inv_R_thick;
+    g.mc[MC_IZK] = pp.inv_Z_thick;
+    g.mc[MC_QINF] = pp.q_halo_inf;
+    g.mc[MC_DQE] = (pp.q_halo_inf - pp.q_halo_ctr) * 2.71828182845904523536;
+    g.mc[MC_RQ2] = pp.rq2;
+    g.mc[MC_IRQ] = pp.inv_r_q;
+    g.mc[MC_RS_HALO2] = pp.Rs_halo2;
+    for (int k = 0; k < 7; ++k) g.mc[MC_B1 + k] = pp.halo_b[k];
+    g.mc[MC_AV0] = pp.avlim[0];
+    g.mc[MC_AV1] = pp.avlim[1];
+    g.mc[MC_RV0] = pp.rvlim[0];
+    g.mc[MC_RV1] = pp.rvlim[1];
+    g.mc[MC_PAR] = g.par;
+    g.mc[MC_PIVAR] = g.par_ivar;
     geom[s] = g;
 }
 
