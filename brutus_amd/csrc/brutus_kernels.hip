@@ -1987,6 +1987,29 @@ int brutus_debug_galprior(const brutus_post_params *params, int n, const double 
     return 0;
 }
 
+int brutus_debug_galprior_mc(const brutus_post_params *params, int n, const double *d_dist,
+                             const double *d_coord, const double *d_feh, const double *d_loga,
+                             double *d_out, void *stream) {
+    if (!params || !d_dist || !d_coord || !d_feh || !d_loga || !d_out || n <= 0)
+        return fail(BRUTUS_EINVAL, "bad arguments");
+    PostParams pp;
+    fill_post_params(pp, params);
+    hipStream_t st = (hipStream_t)stream;
+    StarGeom *geom = nullptr;
+    HIP_TRY(hipMalloc(&geom, sizeof(StarGeom)));
+    DustCtx dc{};
+    hipLaunchKernelGGL(k_post_geom, dim3(1), dim3(64), 0, st, pp, 1, d_coord, (const double *)nullptr,
+                       (const double *)nullptr, dc, geom);
+    hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_debug_galprior_mc<true> : k_debug_galprior_mc<false>,
+                       dim3((n + 255) / 256), dim3(256), 0, st, pp, n, d_dist, geom, d_feh, d_loga, d_out);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(geom);
+    HIP_TRY(e);
+    HIP_TRY(e2);
+    return 0;
+}
+
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *stream) {
     if (!d_in || !d_out || n <= 0) return fail(BRUTUS_EINVAL, "bad calibration arguments");
     hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(TILE), 0, (hipStream_t)stream, d_in, d_out, n);

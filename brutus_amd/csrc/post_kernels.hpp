@@ -1379,4 +1379,35 @@ __global__ void k_debug_galprior(PostParams pp, int n, const double *__restrict_
     out[i] = gal_lnprior_dev(pp, g, dist[i], Fc, Ac, kExp2Tbl);
 }
 
+// the same ln prior as the sample loop of k_post_mc / k_post_mc_arr evaluates it: the object's
+// constant block (geom[0], from k_post_geom) through scalar loads and the halo table when the
+// parameters admit it, the plain form otherwise -- a sample with z = 0 at s0 = 1 / d^2
+template <bool HT>
+__global__ void k_debug_galprior_mc(PostParams pp, int n, const double *__restrict__ dist,
+                                    const StarGeom *__restrict__ geom, const double *__restrict__ feh,
+                                    const double *__restrict__ loga, double *__restrict__ out) {
+    __shared__ double s_tbl[64];
+    __shared__ double s_halo[HALO_TBL];
+    stage_exp_table(s_tbl);
+    if constexpr (HT) stage_halo_table(pp, s_halo);
+    __syncthreads();
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const StarGeom g = geom[0];
+    double Fc[3], Ac[3];
+    label_terms(pp, feh[i], loga[i], Fc, Ac, s_tbl);
+    const double L[6] = {0., 0., 0., 0., 0., 0.};
+    const double s0 = 1. / (dist[i] * dist[i]), a0 = 0.5 * (pp.avlim[0] + pp.avlim[1]),
+                 r0 = 0.5 * (pp.rvlim[0] + pp.rvlim[1]);
+    double lin, epar, d_, a_, r_;
+    bool inb;
+    if constexpr (HT)
+        mc_sample_c(mc_refresh((CPtr)(uintptr_t)geom[0].mc), pp, g, false, false,
+                    pp.Rs_thick2 == pp.Rs_thin2, 0., 0., 0., s0, a0, r0, L, Fc, Ac, s_tbl, s_halo, inb, lin,
+                    epar);
+    else
+        mc_sample_lin(pp, g, 0., 0., 0., s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar);
+    out[i] = inb ? pp.lnK + fast_log_r(lin) : nan("");
+}
+
 }  // namespace

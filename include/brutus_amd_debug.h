@@ -31,6 +31,15 @@ int brutus_debug_galprior(const brutus_post_params *params, int n,
                           const double *d_feh, const double *d_loga, double *d_out,
                           void *stream);
 
+/* The same ln prior in the form the Monte Carlo sample loop evaluates it (per-object
+ * constant block read by scalar loads, table-driven halo power law when the parameters
+ * admit it, the plain form otherwise; BRUTUS_NO_HALO_TBL=1 forces the plain form).
+ * Synchronises the stream. */
+int brutus_debug_galprior_mc(const brutus_post_params *params, int n,
+                             const double *d_dist, const double *d_coord,
+                             const double *d_feh, const double *d_loga, double *d_out,
+                             void *stream);
+
 /* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
  * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
  * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated

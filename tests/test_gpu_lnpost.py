@@ -2,6 +2,8 @@
 reference semantics.  The random stream is brutus_amd/rng.PhiloxRandomState, a
 valid `rstate` object for the reference/oracle, so the device result is compared
 with the ORACLE run on the same `rstate` -- indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -52,6 +54,14 @@ def _post_params(**kw):
     return pp
 
 
+def _lnp_err(ref, got):
+    """|difference| of two ln-prior vectors relative to max(|ref|, 1) (a ln prior crosses
+    zero: its last-bit errors are absolute), same -inf pattern required."""
+    fin = np.isfinite(ref)
+    assert np.array_equal(fin, np.isfinite(got)) and np.array_equal(ref[~fin], got[~fin])
+    return float(np.max(np.abs(ref[fin] - got[fin]) / np.maximum(np.abs(ref[fin]), 1.)))
+
+
 def test_device_galprior_matches_host():
     import torch
     from brutus_amd import _lib
@@ -75,6 +85,28 @@ def test_device_galprior_matches_host():
             torch.cuda.synchronize()
             ref = gal_lnprior(d, coord, labels=lab, frame=frame)
             assert relerr(ref, out.cpu().numpy()) < 1e-12, (frame, coord)
+            # ... and in the form the Monte Carlo sample loop evaluates it (per-object
+            # constant block, R^2(d) as a quadratic, table-driven halo power law), plus the
+            # plain form it falls back to when the parameters do not admit the table
+            for env in (None, "1"):
+                if env:
+                    os.environ["BRUTUS_NO_HALO_TBL"] = env
+                try:
+                    out.fill_(0.)
+                    _lib.check(L.brutus_debug_galprior_mc(_post_params(frame=frame), n, td.data_ptr(),
+                                                          tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
+                                                          out.data_ptr(), None))
+                finally:
+                    os.environ.pop("BRUTUS_NO_HALO_TBL", None)
+                assert _lnp_err(ref, out.cpu().numpy()) < 1e-12, (frame, coord, env)
+    # a steep halo (eta = 40): the series' dropped term is too large, the library must
+    # take the plain form by itself
+    pp = _post_params(eta_halo=40.)
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    _lib.check(L.brutus_debug_galprior_mc(pp, n, td.data_ptr(), tc.data_ptr(), tf.data_ptr(),
+                                          tl.data_ptr(), out.data_ptr(), None))
+    ref = gal_lnprior(d, coord, labels=lab, eta_halo=40.)
+    assert _lnp_err(ref, out.cpu().numpy()) < 1e-12
 
 
 def _setup(nmodel=6000, nstar=9, seed=31):
