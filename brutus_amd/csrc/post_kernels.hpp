@@ -809,14 +809,21 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     int ninb = 0;
                     const double *const zc = (const double *)col;
                     const int jb = (int)(j_lo & 1);
+                    // (the normals of sample t + 1 are requested while sample t is integrated)
+                    auto zat = [&](int jj) { return zc[(int64_t)(jj >> 1) * (2 * TILE) + (jj & 1)]; };
+                    double zn0 = zat(jb), zn1 = zat(jb + pp.nmc), zn2 = zat(jb + 2 * pp.nmc);
                     for (int t = 0; t < pp.nmc; ++t) {
                         double d_, a_, r_, lin, epar;
                         bool inb;
                         // normal jj of the run: component jj & 1 of row jj >> 1
-                        const int j0 = jb + t, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
-                        const double z0 = zc[(int64_t)(j0 >> 1) * (2 * TILE) + (j0 & 1)],
-                                     z1 = zc[(int64_t)(j1 >> 1) * (2 * TILE) + (j1 & 1)],
-                                     z2 = zc[(int64_t)(j2 >> 1) * (2 * TILE) + (j2 & 1)];
+                        const double z0 = zn0, z1 = zn1, z2 = zn2;
+                        {
+                            const int tn = t + 1 < pp.nmc ? t + 1 : t;
+                            const int j0 = jb + tn, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
+                            zn0 = zat(j0);
+                            zn1 = zat(j1);
+                            zn2 = zat(j2);
+                        }
                         if constexpr (HT)
                             mc_sample_c(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, z0, z1, z2, s0,
                                         a0, r0, L, Fc, Ac, s_tbl, ht, inb, lin, epar);
