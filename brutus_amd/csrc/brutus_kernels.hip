@@ -1517,8 +1517,7 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     }
     const bool ok = std::isfinite(h) && fabs(b) * ldexp(1., -64) < ldexp(1., -54) &&
                     pp.Rs_halo2 >= ldexp(1., -HALO_E0) && std::isfinite(pp.c0_halo) &&
-                    std::isfinite(pow(pp.inv_reff_solar2, -h)) &&
-                    !getenv("BRUTUS_NO_HALO_TBL");
+                    std::isfinite(pow(pp.inv_reff_solar2, -h));
     pp.halo_tbl = ok ? 1. : 0.;
 }
 

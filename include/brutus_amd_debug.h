@@ -33,7 +33,7 @@ int brutus_debug_galprior(const brutus_post_params *params, int n,
 
 /* The same ln prior in the form the Monte Carlo sample loop evaluates it (per-object
  * constant block read by scalar loads, table-driven halo power law when the parameters
- * admit it, the plain form otherwise; BRUTUS_NO_HALO_TBL=1 forces the plain form).
+ * admit it, the plain form otherwise).
  * Synchronises the stream. */
 int brutus_debug_galprior_mc(const brutus_post_params *params, int n,
                              const double *d_dist, const double *d_coord,

@@ -2,8 +2,6 @@
 reference semantics.  The random stream is brutus_amd/rng.PhiloxRandomState, a
 valid `rstate` object for the reference/oracle, so the device result is compared
 with the ORACLE run on the same `rstate` -- indices bit-exact."""
-import os
-
 import numpy as np
 import pytest
 
@@ -88,25 +86,15 @@ def test_device_galprior_matches_host():
             # ... and in the form the Monte Carlo sample loop evaluates it (per-object
             # constant block, R^2(d) as a quadratic, table-driven halo power law), plus the
             # plain form it falls back to when the parameters do not admit the table
-            for env in (None, "1"):
-                if env:
-                    os.environ["BRUTUS_NO_HALO_TBL"] = env
-                try:
-                    out.fill_(0.)
-                    _lib.check(L.brutus_debug_galprior_mc(_post_params(frame=frame), n, td.data_ptr(),
-                                                          tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
-                                                          out.data_ptr(), None))
-                finally:
-                    os.environ.pop("BRUTUS_NO_HALO_TBL", None)
-                assert _lnp_err(ref, out.cpu().numpy()) < 1e-12, (frame, coord, env)
-    # a steep halo (eta = 40): the series' dropped term is too large, the library must
-    # take the plain form by itself
-    pp = _post_params(eta_halo=40.)
-    out = torch.empty(n, dtype=torch.float64, device="cuda")
-    _lib.check(L.brutus_debug_galprior_mc(pp, n, td.data_ptr(), tc.data_ptr(), tf.data_ptr(),
-                                          tl.data_ptr(), out.data_ptr(), None))
-    ref = gal_lnprior(d, coord, labels=lab, eta_halo=40.)
-    assert _lnp_err(ref, out.cpu().numpy()) < 1e-12
+            # (eta = 40: the series' dropped term is too large for the table form, the
+            # library must take the plain form by itself -- and a tiny Rs_halo likewise)
+            for kw in (dict(), dict(eta_halo=40.), dict(Rs_halo=0.03)):
+                out.fill_(0.)
+                _lib.check(L.brutus_debug_galprior_mc(_post_params(frame=frame, **kw), n, td.data_ptr(),
+                                                      tc.data_ptr(), tf.data_ptr(), tl.data_ptr(),
+                                                      out.data_ptr(), None))
+                refk = gal_lnprior(d, coord, labels=lab, frame=frame, **kw)
+                assert _lnp_err(refk, out.cpu().numpy()) < 1e-12, (frame, coord, kw)
 
 
 def _setup(nmodel=6000, nstar=9, seed=31):
@@ -157,6 +145,40 @@ def test_device_lnpost_shared_stream_vs_oracle():
         _compare(dev[i], ref, i)
     # the device advanced the caller's rstate exactly like the host would have
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
+def _steep_halo_hook():
+    """The built-in prior with a halo too steep for the table form of its power law (the
+    library must run the plain form: `k_post_mc<false>` / `k_post_mc_arr<false>`)."""
+    from brutus_amd.galprior import device_params, gal_lnprior
+
+    def steep(dists, coord, labels=None, **kw):
+        return gal_lnprior(dists, coord, labels=labels, eta_halo=40., **kw)
+    steep.broadcasts_labels = True
+    steep.device_params = lambda **kw: device_params(**dict(dict(eta_halo=40.), **kw))
+    return steep
+
+
+@pytest.mark.parametrize("stream", ["philox", "numpy"])
+def test_device_lnpost_plain_halo_form_vs_oracle(stream):
+    """As test_device_lnpost_shared_stream_vs_oracle with prior parameters that do not admit
+    the halo table, through both Monte Carlo kernels (counter-based and numpy streams)."""
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    hook = _steep_halo_hook()
+    BF, models, labels, st, lnprior = _setup()
+    BF.batch_size = 4
+    mk = (lambda: PhiloxRandomState(77)) if stream == "philox" else (lambda: np.random.RandomState(77))
+    rs = mk()
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=hook, data_coords=st["coords"], Ndraws=60, rstate=rs))
+    ro = mk()
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, hook, Nmc_prior=20, Ndraws=60)
+        _compare(dev[i], ref, (stream, i))
 
 
 def test_full_size_fit_vs_oracle():
