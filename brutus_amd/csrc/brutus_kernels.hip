@@ -1517,7 +1517,11 @@ void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     }
     const bool ok = std::isfinite(h) && fabs(b) * ldexp(1., -64) < ldexp(1., -54) &&
                     pp.Rs_halo2 >= ldexp(1., -HALO_E0) && std::isfinite(pp.c0_halo) &&
-                    std::isfinite(pow(pp.inv_reff_solar2, -h));
+                    std::isfinite(pow(pp.inv_reff_solar2, -h)) &&
+                    // (reff^2 stays finite and in the tabulated range: 0 < q(r) between q_ctr and q_inf)
+                    pp.q_halo_ctr > 0. && pp.q_halo_inf > 0. && pp.r_q_halo > 0. &&
+                    // (mc_sample_c takes its square roots without the x == 0 select)
+                    pp.Rs_thin2 >= ldexp(1., -HALO_E0) && pp.Rs_thick2 >= ldexp(1., -HALO_E0);
     pp.halo_tbl = ok ? 1. : 0.;
 }
 

@@ -153,6 +153,26 @@ __device__ __forceinline__ void fast_sqrt_rsqrt(double x, double &sq, double &rs
     sq = x == 0. ? 0. : g;
     rsq = y2;
 }
+// the same for x > 0 in the normal range (no select for x == 0: 0 gives NaN)
+__device__ __forceinline__ void fast_sqrt_rsqrt_pos(double x, double &sq, double &rsq) {
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    const double r = fma(-h, g, 0.5);
+    g = fma(g, r, g);
+    h = fma(h, r, h);
+    g = fma(fma(-g, g, x), h, g);
+    g = fma(fma(-g, g, x), h, g);
+    double y2 = h + h;
+    y2 = fma(y2, fma(-y2, g, 1.), y2);
+    y2 = fma(y2, fma(-y2, g, 1.), y2);
+    sq = g;
+    rsq = y2;
+}
+__device__ __forceinline__ double fast_sqrt_pos(double x) {
+    double g, h;
+    fast_sqrt_rsqrt_pos(x, g, h);
+    return g;
+}
 __device__ __forceinline__ double fast_sqrt(double x) {
     double g, h;
     fast_sqrt_rsqrt(x, g, h);

@@ -641,16 +641,16 @@ __device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const
     const double a_mc = a0 + (L[1] * z0 + L[2] * z1);
     const double r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
     double par, d;
-    fast_sqrt_rsqrt(s_mc, par, d);
+    fast_sqrt_rsqrt_pos(s_mc, par, d);       // (s_mc <= 0: NaN, and the sample is out of bounds)
     const double R2 = fmax(fma(fma(cb[MC_A2], d, cb[MC_A1]), d, cb[MC_A0]), 0.);
     const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
     const double aZ = fabs(Z);
-    const double Rt = fast_sqrt(R2 + cb[MC_RS_THIN2]);
-    const double Rk = one_rs ? Rt : fast_sqrt(R2 + cb[MC_RS_THICK2]);
+    const double Rt = fast_sqrt_pos(R2 + cb[MC_RS_THIN2]);      // (Rs^2, rq^2 > 0: fill_post_params)
+    const double Rk = one_rs ? Rt : fast_sqrt_pos(R2 + cb[MC_RS_THICK2]);
     const double T0 = fast_exp_fin(cb[MC_C0T] - fma(Rt, cb[MC_IRT], aZ * cb[MC_IZT]), tbl);
     const double T1 = fast_exp_fin(cb[MC_C0K] - fma(Rk, cb[MC_IRK], aZ * cb[MC_IZK]), tbl);
     const double q = cb[MC_QINF] -
-                     cb[MC_DQE] * fast_exp_fin(-(fast_sqrt(fma(Z, Z, R2) + cb[MC_RQ2]) * cb[MC_IRQ]), tbl);
+                     cb[MC_DQE] * fast_exp_fin(-(fast_sqrt_pos(fma(Z, Z, R2) + cb[MC_RQ2]) * cb[MC_IRQ]), tbl);
     const double zq = Z * fast_rcp(q);
     struct HB {
         CPtr c;
