@@ -1405,7 +1405,6 @@ PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
     w.star_out = (double *)take(8 * 4 * (size_t)nstar);
     w.rp.src = (int32_t *)take(4 * c);
     w.rp.lnp = (double *)take(8 * c);
-    w.rp.cov = (double *)take(8 * 6 * c);
     w.rp.chol = (double *)take(8 * 6 * c);
     w.cdf = (double *)take(8 * c);
     w.sort_keys = (double *)take(8 * c);
@@ -1449,7 +1448,7 @@ int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep,
     const unsigned kb = (unsigned)((keep + 255) / 256);
     // permute every per-record array through the (now free) lnp1-sized scratch
     double *tmp = w.lnp1;
-    if (14 * keep <= cap) {          // all planes at once: two launches instead of 28
+    if (8 * keep <= cap) {           // all planes at once: two launches instead of 16
         hipLaunchKernelGGL(k_clip_gather, dim3(kb), dim3(256), 0, st, w.rp, cap, a, w.sort_perm, keep, tmp);
         hipLaunchKernelGGL(k_clip_store, dim3(kb), dim3(256), 0, st, w.rp, cap, a, keep, tmp);
         HIP_TRY(hipGetLastError());
@@ -1461,10 +1460,8 @@ int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep,
         return 0;
     };
     if (int rc = permute64(w.rp.lnp)) return rc;
-    for (int q = 0; q < 6; ++q) {
-        if (int rc = permute64(w.rp.cov + (size_t)q * cap)) return rc;
+    for (int q = 0; q < 6; ++q)
         if (int rc = permute64(w.rp.chol + (size_t)q * cap)) return rc;
-    }
     hipLaunchKernelGGL(k_gather<int32_t>, dim3(kb), dim3(256), 0, st, (int32_t *)tmp, w.rp.src + a,
                        w.sort_perm, keep);
     HIP_TRY(hipMemcpyAsync(w.rp.src + a, tmp, 4 * (size_t)keep, hipMemcpyDeviceToDevice, st));

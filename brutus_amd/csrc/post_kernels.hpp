@@ -481,8 +481,10 @@ __global__ void k_post_offsets(PostParams pp, int nstar, const int64_t *__restri
 struct RecPost {      // arrays over second-cut records (capacity = first-cut capacity)
     int32_t *src;     // position in the first-cut record arrays
     double *lnp;      // lnp0, later the final lnp
-    double *cov;      // [6][cap]
-    double *chol;     // [6][cap]  L00 L10 L11 L20 L21 L22
+    double *chol;     // [6][cap]  L00 L10 L11 L20 L21 L22 of the record's covariance
+    // (the covariance itself is not stored: only the Ndraws resampled records of an object
+    // report it, and k_post_draw derives it again with rec_cov -- 48 bytes per kept record
+    // less to write, permute and hold)
 };
 
 __device__ __forceinline__ bool inv3_sym(const double (&A)[6], double (&C)[6]) {
@@ -507,6 +509,28 @@ __device__ __forceinline__ bool is_pd3(const double (&C)[6]) {
     const double m3 = C[0] * (C[3] * C[5] - C[4] * C[4]) - C[1] * (C[1] * C[5] - C[4] * C[2]) +
                       C[2] * (C[1] * C[4] - C[3] * C[2]);
     return C[0] > 0. && m2 > 0. && m3 > 0.;
+}
+
+// covariance of the record at value slot `vs`: inverse of its precision matrix with the
+// reference's repair loop for matrices that are not positive definite (fitting.py:1039-1065)
+__device__ __forceinline__ void rec_cov(const double *__restrict__ sel_vals, int64_t cap, int64_t vs,
+                                        double (&C)[6]) {
+    double A[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + vs];
+    inv3_sym(A, C);
+    const double scale = sel_vals[2 * cap + vs];
+    const double width = 0.02;
+    double count = 1.;
+    for (int it = 0; it < 200 && !is_pd3(C); ++it) {       // fitting.py:1045-1065
+        const double sf = scale * width;
+        const bool i1 = C[0] <= 0., i2 = C[3] <= 0., i3 = C[5] <= 0.;
+        if (i1 || (!i2 && !i3)) A[0] += count / (sf * sf);
+        if (i2 || (!i1 && !i3)) A[3] += count / (width * width);
+        if (i3 || (!i1 && !i2)) A[5] += count / (width * width);
+        inv3_sym(A, C);
+        count *= 2.;
+    }
 }
 
 __global__ void __launch_bounds__(TILE)
@@ -535,24 +559,8 @@ k_post_scatter2(int64_t cap, const int32_t *__restrict__ sel_idx, const int32_t 
             rp.src[o] = (int32_t)(r - sel_off[s]);
             const int64_t vs = rec_slot[r];
             rp.lnp[o] = sel_vals[vs] + lnprior[sel_idx[r]];
-            double A[6], C[6];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) A[k] = sel_vals[(int64_t)(5 + k) * cap + vs];
-            inv3_sym(A, C);
-            const double scale = sel_vals[2 * cap + vs];
-            const double width = 0.02;
-            double count = 1.;
-            for (int it = 0; it < 200 && !is_pd3(C); ++it) {       // fitting.py:1045-1065
-                const double sf = scale * width;
-                const bool i1 = C[0] <= 0., i2 = C[3] <= 0., i3 = C[5] <= 0.;
-                if (i1 || (!i2 && !i3)) A[0] += count / (sf * sf);
-                if (i2 || (!i1 && !i3)) A[3] += count / (width * width);
-                if (i3 || (!i1 && !i2)) A[5] += count / (width * width);
-                inv3_sym(A, C);
-                count *= 2.;
-            }
-#pragma unroll
-            for (int k = 0; k < 6; ++k) rp.cov[(int64_t)k * cap + o] = C[k];
+            double C[6];
+            rec_cov(sel_vals, cap, vs, C);
             // Cholesky of cov + 1e-30 I (utils.py:892-894)
             const double l00 = sqrt(C[0] + 1e-30);
             const double l10 = C[1] / l00, l20 = C[2] / l00;
@@ -1214,8 +1222,7 @@ k_post_draw(PostParams pp, int sbase, const double *__restrict__ zarr, const int
     ov[1] = a0;
     ov[2] = r0;
     double C[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) C[k] = rp.cov[(int64_t)k * cap + o];
+    rec_cov(sel_vals, cap, vs, C);
     ov[3] = C[0]; ov[4] = C[1]; ov[5] = C[2];
     ov[6] = C[1]; ov[7] = C[3]; ov[8] = C[4];
     ov[9] = C[2]; ov[10] = C[4]; ov[11] = C[5];
@@ -1274,9 +1281,9 @@ __global__ void k_gather(T *__restrict__ dst, const T *__restrict__ src,
     if (i < n) dst[i] = src[perm[i]];
 }
 
-// Nsel_max clip: the kept records of one object, best first.  k_clip_gather pulls lnp, the six
-// covariance and the six Cholesky planes and the source index through `perm` into a dense
-// scratch (13 planes of `keep` doubles + `keep` ints), k_clip_store writes them back in place.
+// Nsel_max clip: the kept records of one object, best first.  k_clip_gather pulls lnp, the
+// six Cholesky planes and the source index through `perm` into a dense scratch (7 planes of
+// `keep` doubles + `keep` ints), k_clip_store writes them back in place.
 __global__ void k_clip_gather(RecPost rp, int64_t cap, int64_t a, const int32_t *__restrict__ perm,
                               int64_t keep, double *__restrict__ tmp) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1284,11 +1291,8 @@ __global__ void k_clip_gather(RecPost rp, int64_t cap, int64_t a, const int32_t 
     const int64_t j = a + perm[i];
     tmp[i] = rp.lnp[j];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        tmp[(1 + q) * keep + i] = rp.cov[(int64_t)q * cap + j];
-        tmp[(7 + q) * keep + i] = rp.chol[(int64_t)q * cap + j];
-    }
-    reinterpret_cast<int32_t *>(tmp + 13 * keep)[i] = rp.src[j];
+    for (int q = 0; q < 6; ++q) tmp[(1 + q) * keep + i] = rp.chol[(int64_t)q * cap + j];
+    reinterpret_cast<int32_t *>(tmp + 7 * keep)[i] = rp.src[j];
 }
 __global__ void k_clip_store(RecPost rp, int64_t cap, int64_t a, int64_t keep,
                              const double *__restrict__ tmp) {
@@ -1297,11 +1301,8 @@ __global__ void k_clip_store(RecPost rp, int64_t cap, int64_t a, int64_t keep,
     const int64_t j = a + i;
     rp.lnp[j] = tmp[i];
 #pragma unroll
-    for (int q = 0; q < 6; ++q) {
-        rp.cov[(int64_t)q * cap + j] = tmp[(1 + q) * keep + i];
-        rp.chol[(int64_t)q * cap + j] = tmp[(7 + q) * keep + i];
-    }
-    rp.src[j] = reinterpret_cast<const int32_t *>(tmp + 13 * keep)[i];
+    for (int q = 0; q < 6; ++q) rp.chol[(int64_t)q * cap + j] = tmp[(1 + q) * keep + i];
+    rp.src[j] = reinterpret_cast<const int32_t *>(tmp + 7 * keep)[i];
 }
 
 // direction of the sightline (l, b) [rad] in the Galactocentric frame of `pp`

@@ -1309,8 +1309,15 @@ class BruteForce(object):
             with torch.cuda.device(dev), torch.cuda.stream(fin_stream):
                 return eng.post_numpy_end(slot)
 
+        def flagged_records(a, S, rec, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
+                            nbase, ubase0, pre=None):
+            """Host copies of the records of the (rare) objects `rows` hands to the host stage,
+            taken while the engine's record buffers still hold this batch."""
+            return {s: eng.record_of(rec, off, s, ndim[s], k1[s], k2[s])
+                    for s in range(S) if flags[s]}
+
         def rows(a, S, rec, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
-                 nbase, ubase0):
+                 nbase, ubase0, pre=None):
             """The tuples `_fit` yields for the objects of one batch."""
             for s in range(S):
                 i = a + s
@@ -1321,7 +1328,8 @@ class BruteForce(object):
                     rs = (PhiloxRandomState(seed0 + i) if seed0 is not None else
                           PhiloxRandomState(rstate.seed, n_normal=int(nbase[s]),
                                             n_uniform=int(ubase0) + s * K))
-                    rec1 = eng.record_of(rec, off, s, ndim[s], k1[s], k2[s])
+                    rec1 = (pre[s] if pre is not None else
+                            eng.record_of(rec, off, s, ndim[s], k1[s], k2[s]))
                     yield self._finish_star(rec1, parallax[i], parallax_err[i],
                                             data_coords[i], Nmc_prior, lnprior,
                                             wt_thresh, cdf_thresh, lngalprior, None,
@@ -1350,8 +1358,19 @@ class BruteForce(object):
                 b = min(Ndata, a + step)
                 S = b - a
                 with torch.cuda.device(dev):
+                    ready = None
                     if ahead:
                         (rec, off, ndim, k1, k2) = fut.result()
+                        if pending is not None:
+                            # Phase 2 of batch kb - 2 reads the record buffers of the engine
+                            # the scan of batch kb + 1 is about to overwrite (three engines),
+                            # and its post slot is the one this batch takes: wait for it
+                            # BEFORE that scan is submitted; its rows are handed out later,
+                            # while the device is busy again.
+                            prev, pargs = pending
+                            pending = None
+                            ready = pargs + prev.result() + (0,)
+                            ready = ready + (flagged_records(*ready),)
                         fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
                     else:
                         (rec, off, ndim, k1, k2) = scan(kb)
@@ -1394,11 +1413,7 @@ class BruteForce(object):
                         # THIS batch's walk is through (its kernels need whole compute units
                         # and would starve behind the Monte Carlo integral), then runs beside
                         # the walk itself.  `pending`: phase 2 submitted; `unsub`: phase 1 done.
-                        ready = None
-                        if pending is not None:      # (its slot is the one this batch takes:
-                            prev, pargs = pending    # wait for it now, hand out its rows later,
-                            pending = None           # while the device is busy again)
-                            ready = pargs + prev.result() + (0,)
+                        # (`ready`: the rows of batch kb - 2, waited for at the top of the loop)
                         sub = []
 
                         def submit_prev():
@@ -1451,8 +1466,11 @@ class BruteForce(object):
                 for row in rows(*(pargs + finisher.submit(finish, slot_).result() + (0,))):
                     yield row
         finally:
-            if pool is not None:      # also when the caller abandons the generator
-                pool.shutdown(wait=False)
+            # also when the caller abandons the generator: the scan that runs ahead still
+            # writes its engine's workspace and record buffers (it ends with a stream
+            # synchronize), and the next `_fit` on this object starts on the same engines
+            if pool is not None:
+                pool.shutdown(wait=True)
             if finisher is not None:
                 finisher.shutdown(wait=True)     # a running phase 2 still reads the buffers
 

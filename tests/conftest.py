@@ -27,3 +27,23 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(autouse=True)
+def _release_device_memory(request):
+    """After every GPU test: drop what the test left in torch's caching allocator.  The
+    engines size their buffers from the device's FREE memory (and `BruteForce._fit` decides
+    from it whether the three-engine numpy-stream pipeline fits), so a test must not inherit
+    the cached blocks of the full-size tests that ran before it."""
+    yield
+    if "gpu" not in request.keywords:
+        return
+    import gc
+    gc.collect()
+    try:
+        import torch
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+    except Exception:
+        pass
