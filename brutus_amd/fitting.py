@@ -1306,6 +1306,9 @@ class BruteForce(object):
                     return out
 
         def finish(slot):
+            delay = getattr(self, "_test_phase2_delay", 0.)     # (test hook: a late phase 2)
+            if delay:
+                time.sleep(delay)
             with torch.cuda.device(dev), torch.cuda.stream(fin_stream):
                 return eng.post_numpy_end(slot)
 

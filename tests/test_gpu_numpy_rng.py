@@ -386,3 +386,31 @@ def test_pipelined_numpy_fit_can_be_abandoned_and_repeated():
     again = list(bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(1), **kw))
     assert all(np.array_equal(a[0], b[0]) and np.array_equal(a[6], b[6])
                for a, b in zip(again, full))
+
+
+def test_pipeline_with_a_late_phase_two_equals_the_sequential_form():
+    """Phase 2 of batch k reads the scan records of batch k while batch k + 1 is walked and
+    batch k + 2 is scanned; the engine that scans batch k + 3 is the one that holds batch k.
+    With phase 2 artificially late (test hook) every hand-over in that chain is exercised:
+    the pipelined run must equal the run without the pipeline, row for row."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    models, labels, lmask = synth.make_mist_like_grid(60000, 8, seed=5)
+    st = synth.make_stars(models, 48, seed=6)
+    bf = fitting.BruteForce(models, labels, lmask)
+    bf.batch_size = 6
+    lnprior = bf._setup(st["flux"], st["err"], st["mask"], None, data_coords=st["coords"],
+                        lngalprior=gal_lnprior)[5]
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
+              lnprior=lnprior, lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=50)
+    bf.post_pipeline = False
+    ref = list(bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(9), **kw))
+    bf.post_pipeline = True
+    for delay in (0., 0.03):
+        bf._test_phase2_delay = delay
+        got = list(bf._fit(st["flux"], st["err"], st["mask"], rstate=np.random.RandomState(9), **kw))
+        assert len(got) == len(ref) == 48
+        for i, (a, b) in enumerate(zip(got, ref)):
+            assert np.array_equal(a[0], b[0]), (delay, i)
+            for x, y in zip(a[1:], b[1:]):
+                assert np.array_equal(np.asarray(x), np.asarray(y)), (delay, i)
