@@ -1252,19 +1252,23 @@ class BruteForce(object):
         # numpy streams: the generator state is final after the stream walk, so the Monte
         # Carlo integral / evidence / draws of batch k (a second helper thread and stream)
         # run beside the cuts + stream walk of batch k + 1 (this thread): the first is bound
-        # by float64 issue, the second by LDS and HBM.  Needs a third scan engine, because
-        # the records of batch k are still being read when batch k + 2 is scanned.
+        # by float64 issue, the second by LDS and HBM.  Needs FOUR scan engines: the records
+        # of batch k are read until phase 2 of batch k has been waited for, at the top of
+        # iteration k + 2 -- after the scan of batch k + 3 has been submitted there (it has to
+        # go first: submitted behind the wait it lands on the next batch's jump-ahead kernels
+        # and delays the phase 2 behind them, -11 % with per-object streams).  With three
+        # engines that scan overwrote the records under the tail of a long phase 2.
         pipelined = ahead and np_mode is not None and getattr(self, "post_pipeline", True)
         if pipelined:
-            # the pipeline holds a third scan workspace and a second post workspace + normal
+            # the pipeline holds two more scan workspaces and a second post workspace + normal
             # buffer: only where that clearly fits (a quarter of the device free per slot)
-            have = (len(getattr(self, "_engine_extra", None) or ()) >= 2
+            have = (len(getattr(self, "_engine_extra", None) or ()) >= 3
                     and len(getattr(eng, "_post_slots", None) or ()) >= 2)
             free = torch.cuda.mem_get_info(dev)[0]
             per_engine = eng.L.brutus_workspace_bytes(eng.grid.nmodel, eng.grid.nfilt,
                                                       eng.batch) + eng.batch * 600000 * 92
-            pipelined = have or free > 4 * per_engine + (16 << 30)
-        nE = 3 if pipelined else 2
+            pipelined = have or free > 5 * per_engine + (16 << 30)
+        nE = 4 if pipelined else 2
         finisher = None
         if ahead:
             import concurrent.futures
@@ -1364,16 +1368,8 @@ class BruteForce(object):
                     ready = None
                     if ahead:
                         (rec, off, ndim, k1, k2) = fut.result()
-                        if pending is not None:
-                            # Phase 2 of batch kb - 2 reads the record buffers of the engine
-                            # the scan of batch kb + 1 is about to overwrite (three engines),
-                            # and its post slot is the one this batch takes: wait for it
-                            # BEFORE that scan is submitted; its rows are handed out later,
-                            # while the device is busy again.
-                            prev, pargs = pending
-                            pending = None
-                            ready = pargs + prev.result() + (0,)
-                            ready = ready + (flagged_records(*ready),)
+                        # (engine (kb + 1) % nE: with four engines its last batch was kb - 3,
+                        # whose phase 2 was waited for an iteration ago)
                         fut = pool.submit(scan, kb + 1) if kb + 1 < len(starts) else None
                     else:
                         (rec, off, ndim, k1, k2) = scan(kb)
@@ -1416,7 +1412,17 @@ class BruteForce(object):
                         # THIS batch's walk is through (its kernels need whole compute units
                         # and would starve behind the Monte Carlo integral), then runs beside
                         # the walk itself.  `pending`: phase 2 submitted; `unsub`: phase 1 done.
-                        # (`ready`: the rows of batch kb - 2, waited for at the top of the loop)
+                        if pending is not None:
+                            # Phase 2 of batch kb - 2 holds the post slot this batch takes:
+                            # wait for it here -- behind this batch's host preparations (128
+                            # generator states with per-object streams), which so overlap its
+                            # tail -- and hand out its rows later, while the device is busy
+                            # again (the records of the objects that go to the host stage are
+                            # copied out now).
+                            prev, pargs = pending
+                            pending = None
+                            ready = pargs + prev.result() + (0,)
+                            ready = ready + (flagged_records(*ready),)
                         sub = []
 
                         def submit_prev():
