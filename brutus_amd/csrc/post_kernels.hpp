@@ -69,6 +69,11 @@ __device__ __forceinline__ bool zig_try(uint32_t a, uint32_t b, const double *__
     x = u * X[i];
     return x < X[i + 1];
 }
+// +-x for x >= 0 with the sign zig_try reads (bit 10 of `b`): two integer operations on the
+// high word instead of a compare and two selects
+__device__ __forceinline__ double zig_signed(double x, uint32_t b) {
+    return __hiloint2double(__double2hiint(x) | (int)((b << 21) & 0x80000000u), __double2loint(x));
+}
 __device__ __forceinline__ Philox4 philox_at(uint64_t seed, uint64_t idx, uint32_t c2, uint32_t stream) {
     return philox4x32_7((uint32_t)idx, (uint32_t)(idx >> 32), c2, stream, (uint32_t)seed,
                         (uint32_t)(seed >> 32));
@@ -120,6 +125,19 @@ __device__ __forceinline__ double rng_normal(uint64_t seed, uint64_t j) {
 // copy kZigX to LDS (ZIG_N + 1 doubles); follow with __syncthreads()
 __device__ __forceinline__ void stage_zig_table(double *lds_x) {
     for (int k = threadIdx.x; k <= ZIG_N; k += blockDim.x) lds_x[k] = kZigX[k];
+}
+// The generator loop of k_post_mc reads the table as pairs P[i] = (X[i] 2^-53, X[i+1]): one
+// 16-byte LDS read per normal, and the 53-bit integer U is multiplied by the scaled edge
+// directly -- U (X[i] 2^-53) and (U 2^-53) X[i] are the same double (a power of two scales
+// exactly), so the rectangle decision and the value stay bit-equal to zig_try's.
+__device__ __forceinline__ void stage_zig_pairs(double2 *lds_p) {
+    for (int k = threadIdx.x; k < ZIG_N; k += blockDim.x)
+        lds_p[k] = make_double2(ldexp(kZigX[k], -53), kZigX[k + 1]);
+}
+__device__ __forceinline__ bool zig_try_p(uint32_t a, uint32_t b, const double2 *__restrict__ P, double &x) {
+    const double2 e = P[b & (uint32_t)(ZIG_N - 1)];
+    x = ((double)a * 2097152.0 + (double)(b >> 11)) * e.x;
+    return x < e.y;
 }
 
 struct PostParams {     // mirrors brutus_post_params
@@ -734,11 +752,11 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
     __shared__ unsigned int s_item;
-    __shared__ double s_zx[ZIG_N + 1];
+    __shared__ double2 s_zp[ZIG_N];
     __shared__ unsigned short s_pend[MC_PEND][TILE];
     __shared__ double s_halo[HALO_TBL];
     stage_exp_table(s_tbl);
-    stage_zig_table(s_zx);
+    stage_zig_pairs(s_zp);
     if constexpr (HT) stage_halo_table(pp, s_halo);
     const double *const ht = HT ? s_halo : nullptr;
     double2 *const col = zs + (int64_t)blockIdx.x * mc_npair_max(pp.nmc) * TILE + threadIdx.x;
@@ -781,19 +799,17 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     // both normals of row `row` by the full algorithm (slow path where needed)
                     auto redo = [&](int row) {
                         double z0, z1;
-                        rng_normal_call(seed, p_lo + (uint64_t)row, s_zx, z0, z1);
+                        rng_normal_call(seed, p_lo + (uint64_t)row, kZigX, z0, z1);
                         col[(int64_t)row * TILE] = make_double2(z0, z1);
                     };
                     int npend = 0;
                     for (int row = 0; row < nrow; ++row) {
                         const Philox4 w4 = philox_at(seed, p_lo + (uint64_t)row, 0u, STREAM_NORMAL);
                         double x0, x1;
-                        int i0, i1;
-                        bool n0, n1;
-                        const bool f0 = zig_try(w4.w[0], w4.w[1], s_zx, x0, i0, n0),
-                                   f1 = zig_try(w4.w[2], w4.w[3], s_zx, x1, i1, n1);
+                        const bool f0 = zig_try_p(w4.w[0], w4.w[1], s_zp, x0),
+                                   f1 = zig_try_p(w4.w[2], w4.w[3], s_zp, x1);
                         if (f0 && f1) {
-                            col[(int64_t)row * TILE] = make_double2(n0 ? -x0 : x0, n1 ? -x1 : x1);
+                            col[(int64_t)row * TILE] = make_double2(zig_signed(x0, w4.w[1]), zig_signed(x1, w4.w[3]));
                         } else if (npend < MC_PEND) {
                             s_pend[npend++][threadIdx.x] = (unsigned short)row;
                         } else {
