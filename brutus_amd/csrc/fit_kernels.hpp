@@ -270,9 +270,8 @@ __device__ __forceinline__ void load_F0(const float *__restrict__ grid, int64_t 
 #pragma unroll
     for (int j = 0; j < NB; ++j) F0[j] = t[(int64_t)j * nmodel_pad + i];
 }
-// The gather kernels are close to memory-bound and VGPR-limited, so they
-// recompute F0 with the table-free polynomial (<= 1 ulp from the tabulated
-// value) instead of reading 8*NB more bytes per model.
+// F0 with the table-free polynomial (<= 1 ulp from the tabulated value): for kernels where
+// registers, not issue slots, are the limit (none of the hot kernels any more).
 template <int NB>
 __device__ __forceinline__ void compute_F0_fast(const Coef<NB> &c, double (&F0)[NB]) {
 #pragma unroll
@@ -729,8 +728,11 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
             double F0[NB];
-            if constexpr (RVF) compute_F0_tbl<NB>(c, s_tbl, F0);
-            else compute_F0_fast<NB>(c, F0);
+            // (table-driven in both instantiations: the general kernel ran the table-free
+            // degree-13 form until round 3 -- 19 instead of 15 operations per exponential --
+            // for the sake of registers it turned out not to need: 215 -> 223 VGPRs, still
+            // two waves per SIMD, k_fflux 1.12 -> 1.00 ms per 128 stars on configs[2])
+            compute_F0_tbl<NB>(c, s_tbl, F0);
             double av, rv, step, lnl_old;
             double R[RVF ? NB : 1];
             if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
@@ -765,7 +767,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             }
             Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
-            else mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+            else mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             if constexpr (FIRST) {
                 go = cull_stat(sp, m) > thr_cull[s];
                 if (go) surv32[o] = surv_tag(q - cand_off[s]);     // a failed candidate keeps its lnprob~
@@ -785,7 +787,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                     if (drv < p.rvmin - rv) drv = p.rvmin - rv;
                     if (drv > p.rvmax - rv) drv = p.rvmax - rv;
                     rv += drv;
-                    mle_fast<NB, false>(c, F0, sp, p, av, rv, nullptr, m);
+                    mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
                 }
                 lnl_new = -0.5 * m.chi2;
                 dl = fabs(lnl_new - lnl_old);
