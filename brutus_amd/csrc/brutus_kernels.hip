@@ -1369,6 +1369,7 @@ struct PostWs {
     size_t sort_tmp_bytes;
     // k_post_mc: work counter and staged normals
     unsigned int *mc_counter;
+    int32_t *mc_order;      // objects by falling number of kept records (k_post_order)
     double2 *mc_stage;
     // numpy-stream mode (mt_kernels.hpp)
     uint32_t *mt_states;      // (nstar, MT_STATE_WORDS)
@@ -1413,6 +1414,7 @@ PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
     w.sort_tmp_bytes = 16 * c + (8u << 20);
     w.sort_tmp = take(w.sort_tmp_bytes);
     w.mc_counter = (unsigned int *)take(256);
+    w.mc_order = (int32_t *)take(4 * (size_t)BRUTUS_MAX_BATCH);
     w.mc_stage = (double2 *)take(sizeof(double2) * (size_t)MC_SLOTS * mc_npair_max(nmc) * TILE);
     w.mt_states = (uint32_t *)take(sizeof(uint32_t) * (size_t)nstar * MT_STATE_WORDS);
     w.mt_nnorm = (int64_t *)take(8 * (size_t)nstar);
@@ -1602,12 +1604,13 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
         {
             const int nitem = PCH * nstar;
             HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
+            hipLaunchKernelGGL(k_post_order, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, 0, nstar, w.nsel, w.mc_order);
             hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_post_mc<true> : k_post_mc<false>,
                                dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st, pp,
                                capacity, 0, nitem, w.mc_counter, (const double *)nullptr,
                                (const int64_t *)nullptr, w.mc_stage, d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off,
                                w.off2, w.nsel, w.nbase, w.flags, w.geom, d_feh, d_loga, w.rp,
-                               w.part_max, w.part_chi2);
+                               w.part_max, w.part_chi2, (const int32_t *)w.mc_order);
         }
         tm.end();
         tm.begin("k_post_cdf");
@@ -1765,6 +1768,7 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
             {
                 const int nitem = PCH * ng;
                 HIP_TRY(hipMemsetAsync(w.mc_counter, 0, 4, st));
+                hipLaunchKernelGGL(k_post_order, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, s0, s1, w.nsel, w.mc_order);
                 static const int use_arr = env_int("BRUTUS_POST_MC_ARR", 1);
                 static const int arr_persistent = env_int("BRUTUS_POST_MC_ARR_PERSISTENT", 0);
                 if (use_arr && pp.nmc <= MCA_NMC)
@@ -1775,14 +1779,15 @@ int post_batch_impl(int nstar, int64_t capacity, const int32_t *d_sel_idx, const
                                        arr_persistent ? w.mc_counter : (unsigned int *)nullptr,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, d_sel_idx, d_rec_slot,
                                        d_sel_vals, d_sel_off, w.off2, w.nsel, w.flags, w.geom, d_feh,
-                                       d_loga, w.rp, w.part_max, w.part_chi2, el.zm);
+                                       d_loga, w.rp, w.part_max, w.part_chi2, el.zm, (const int32_t *)w.mc_order);
                 else
                     hipLaunchKernelGGL(pp.halo_tbl != 0. ? k_post_mc<true> : k_post_mc<false>,
                                        dim3(nitem < MC_SLOTS ? nitem : MC_SLOTS), blk, 0, st,
                                        pp, capacity, PCH * s0, PCH * s1, w.mc_counter,
                                        (const double *)zbase, (const int64_t *)w.mt_zoff, w.mc_stage,
                                        d_sel_idx, d_rec_slot, d_sel_vals, d_sel_off, w.off2, w.nsel, w.nbase, w.flags,
-                                       w.geom, d_feh, d_loga, w.rp, w.part_max, w.part_chi2);
+                                       w.geom, d_feh, d_loga, w.rp, w.part_max, w.part_chi2,
+                                       (const int32_t *)w.mc_order);
             }
             tm.end();
             const dim3 gg(PCH, ng);

@@ -738,6 +738,23 @@ __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2;
 // double2); afterwards the lane integrates, reading three normals per sample.
 constexpr int MC_PEND = 8;
 
+// Objects s0 .. s1 - 1 by falling number of kept records: the Monte Carlo kernels take the work
+// items (object, chunk) in this order, largest first, so that the items left for the end of the
+// launch are the short ones (items are 1 / PCH of an object: 0.5 - 3.5 ms each at the bench's
+// posteriors against 18 ms for the launch -- taken in index order the last ones idled half the
+// device for the length of an average item).
+__global__ void k_post_order(int s0, int s1, const int64_t *__restrict__ nsel, int32_t *__restrict__ ord) {
+    const int s = s0 + (int)threadIdx.x;
+    if (s >= s1) return;
+    const int64_t n = nsel[s];
+    int rank = 0;
+    for (int j = s0; j < s1; ++j) {
+        const int64_t m = nsel[j];
+        rank += (m > n || (m == n && j < s)) ? 1 : 0;
+    }
+    ord[rank] = s;
+}
+
 template <bool HT>
 __global__ void __launch_bounds__(TILE, 3)
 k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__restrict__ counter,
@@ -748,7 +765,7 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
           const uint64_t *__restrict__ nbase, const int32_t *__restrict__ flags,
           const StarGeom *__restrict__ geom, const double *__restrict__ feh,
           const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
-          double *__restrict__ part_chi2) {
+          double *__restrict__ part_chi2, const int32_t *__restrict__ ord) {
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
     __shared__ unsigned int s_item;
@@ -766,7 +783,9 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
         __syncthreads();
         const unsigned int item = s_item;
         if (item >= (unsigned int)nitem) break;
-        const int s = __builtin_amdgcn_readfirstlane((int)(item / PCH)), c = (int)(item % PCH);
+        // (k-th item of the launch -> chunk k % PCH of the object with the (k / PCH)-th most records)
+        const int s = __builtin_amdgcn_readfirstlane(ord[(item - (unsigned int)item_base) / PCH]),
+                  c = (int)(item % PCH);
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
@@ -909,7 +928,7 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
               const int64_t *__restrict__ nsel, const int32_t *__restrict__ flags,
               const StarGeom *__restrict__ geom, const double *__restrict__ feh,
               const double *__restrict__ loga, RecPost rp, double *__restrict__ part_max,
-              double *__restrict__ part_chi2, ZMap zm) {
+              double *__restrict__ part_chi2, ZMap zm, const int32_t *__restrict__ ord) {
     static_assert(MCA_R * MCA_G == 64, "one wave = records x sample groups");
     __shared__ double slot[4];
     __shared__ double s_tbl[64];
@@ -935,7 +954,8 @@ k_post_mc_arr(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int
         __syncthreads();
         const unsigned int item = counter ? s_item : (unsigned int)item_base + blockIdx.x;
         if (item >= (unsigned int)nitem) break;
-        const int s = __builtin_amdgcn_readfirstlane((int)(item / PCH)), c = (int)(item % PCH);
+        const int s = __builtin_amdgcn_readfirstlane(ord[(item - (unsigned int)item_base) / PCH]),
+                  c = (int)(item % PCH);
         int64_t a, b;
         rec_range_n(off2[s], nsel[s], c, a, b);
         const StarGeom g = geom[s];
