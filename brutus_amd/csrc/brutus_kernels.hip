@@ -1296,7 +1296,7 @@ struct OffsetsWs {
     void *tmp;
     size_t tmp_bytes, bytes;
 };
-int carve_offsets(char *base, int n, int nmc, OffsetsWs &w) {
+static int carve_offsets(char *base, int n, int nmc, OffsetsWs &w) {
     const size_t nv = (size_t)n * nmc;
     size_t off = 0;
     w.vals = (double *)(base + off);
@@ -1381,7 +1381,7 @@ struct PostWs {
 
 constexpr int MC_SLOTS = 1024;     // persistent workgroups (= staging slots) of k_post_mc
 
-PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
+static PostWs carve_post(char *base, int nstar, int64_t cap, int nmc, int ndraws = 0) {
     PostWs w{};
     size_t off = 0;
     auto take = [&](size_t n) {
@@ -1437,7 +1437,7 @@ struct MtArgs {            // numpy-stream mode of post_batch_impl
 };
 
 // Keep the nsel_max best records of object s, best first (fitting.py:1029-1036).
-int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep, hipStream_t st) {
+static int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep, hipStream_t st) {
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_iota32, dim3(nb), dim3(256), 0, st, w.sort_in, n);
     size_t need = 0;
@@ -1471,7 +1471,7 @@ int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_t keep,
     return 0;
 }
 
-void fill_post_params(PostParams &pp, const brutus_post_params *params) {
+static void fill_post_params(PostParams &pp, const brutus_post_params *params) {
     memcpy(&pp, params, sizeof(brutus_post_params));
     pp.ln_f_thick = log(pp.f_thick);
     pp.ln_f_halo = log(pp.f_halo);

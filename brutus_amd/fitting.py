@@ -51,6 +51,10 @@ def _torch():
     return torch
 
 
+def _is_tensor(x):
+    return type(x).__module__.startswith("torch")
+
+
 def _stream_ptr(torch):
     return torch.cuda.current_stream().cuda_stream
 
@@ -81,6 +85,26 @@ def _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol, ltol_subthresh,
     return p
 
 
+def _bands_in_use(data_mask, nfilt):
+    """Indices of the bands at least one object of the call has unmasked, or None when the
+    grid is to be used as it is.  The reference drops masked bands per object before any
+    arithmetic (fitting.py:709-716: `mcoeffs = mag_coeffs[:, mask, :]`), so a band no object
+    of the call uses never enters a result: compacting the grid to the used bands changes
+    nothing but the amount of work -- and lets a grid file with all 49 filters
+    (`load_models(filters=None)`, utils.py:575-576) be fitted with the data's few bands.
+    Compaction happens when it saves a padded band count or is needed to fit the kernels'
+    32-band limit."""
+    used = np.asarray(data_mask, dtype=bool).reshape(-1, nfilt).any(axis=0)
+    nused = int(used.sum())
+    if nused == nfilt or nused == 0:
+        return None
+    L = _lib.lib()
+    pad_all, pad_used = L.brutus_padded_filters(nfilt), L.brutus_padded_filters(nused)
+    if pad_all >= 0 and pad_used >= pad_all:
+        return None
+    return np.flatnonzero(used)
+
+
 class DeviceGrid(object):
     """The model grid resident in HBM in the kernels' band-major SoA layout.
 
@@ -106,8 +130,10 @@ class DeviceGrid(object):
             raise ValueError("models must have shape (Nmodel, Nfilt, 3)")
         self.nmodel, self.nfilt = int(aos.shape[0]), int(aos.shape[1])
         if L.brutus_padded_filters(self.nfilt) < 0:
-            raise ValueError("at most %d filters per fit are supported; "
-                             "sub-select the bands you fit" % _lib.MAX_FILT)
+            raise ValueError("at most %d filters can be fitted at once (the grid has %d); "
+                             "`BruteForce` / `loglike` compact the grid to the bands the "
+                             "data actually use -- more than %d are unmasked here"
+                             % (_lib.MAX_FILT, self.nfilt, _lib.MAX_FILT))
         nbytes = L.brutus_grid_soa_bytes(self.nmodel, self.nfilt)
         self.soa = torch.empty(nbytes // 4, dtype=torch.float32,
                                device=self.device)
@@ -530,13 +556,22 @@ def loglike_batch(data, data_err, data_mask, mag_coeffs,
     `(Nstar, Nfilt)`, `parallax`/`parallax_err` `(Nstar,)` or None.  Returns a
     dict of full-grid arrays `(Nstar, Nmodel)` plus `ndim`, `k1`, `k2`.
     `av_init` / `rv_init` `(Nmodel,)`: starting values shared by the stars."""
+    data = np.atleast_2d(np.asarray(data, dtype=np.float64))
+    data_err = np.atleast_2d(np.asarray(data_err, dtype=np.float64))
+    data_mask = np.atleast_2d(np.asarray(data_mask))
+    if not isinstance(mag_coeffs, DeviceGrid) and not _is_tensor(mag_coeffs):
+        # bands no star of the call uses never enter a result (fitting.py:709-716)
+        with np.errstate(all="ignore"):
+            live = (data_mask.astype(bool) & np.isfinite(data) & np.isfinite(data_err)
+                    & (data_err > 0.))
+        bands = _bands_in_use(live, data.shape[1])
+        if bands is not None:
+            mag_coeffs = np.asarray(mag_coeffs)[:, bands, :]
+            data, data_err, data_mask = data[:, bands], data_err[:, bands], data_mask[:, bands]
     grid = mag_coeffs if isinstance(mag_coeffs, DeviceGrid) else DeviceGrid(mag_coeffs)
     params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
                           ltol_subthresh, init_thresh, dim_prior)
     eng = _Engine(grid, max_batch=max_batch, mem_budget=4e9)
-    data = np.atleast_2d(np.asarray(data, dtype=np.float64))
-    data_err = np.atleast_2d(np.asarray(data_err, dtype=np.float64))
-    data_mask = np.atleast_2d(np.asarray(data_mask))
     outs = []
     for a in range(0, data.shape[0], eng.batch):
         b = min(data.shape[0], a + eng.batch)
@@ -822,8 +857,10 @@ class BruteForce(object):
         self.labels_mask = labels_mask
         self.NLABELS = len(models_labels[0])
         self._grid = None
+        self._grid_adopted = False
         self._engine_obj = None
         self._engine_for = None
+        self._band_engines = []     # [(band tuple, batch_size, engine)]: compacted grids, newest last
         #: stars per device batch (None = sized from the memory budget)
         self.batch_size = None
         #: run `lnpost` + resampling on the device when the priors are the
@@ -841,7 +878,23 @@ class BruteForce(object):
         self.device_numpy_rng = True
 
     # -- device state -------------------------------------------------------
-    def _engine(self):
+    def _engine(self, bands=None):
+        """The engine over the whole grid, or (`bands`: sorted band indices) over the grid
+        compacted to those bands -- built on first use and kept (two band sets at most)."""
+        if bands is not None:
+            key = tuple(int(b) for b in bands)
+            for i, (k, bs, en) in enumerate(self._band_engines):
+                if k == key and bs == self.batch_size:
+                    self._band_engines.append(self._band_engines.pop(i))
+                    return en
+            grid = next((en.grid for k, _, en in self._band_engines if k == key), None)
+            if grid is None:
+                grid = DeviceGrid(np.ascontiguousarray(
+                    np.asarray(self.models)[:, list(key), :], dtype=np.float32))
+            en = _Engine(grid, max_batch=self.batch_size)
+            self._band_engines.append((key, self.batch_size, en))
+            del self._band_engines[:-2]
+            return en
         if self._engine_obj is None or self._engine_for != self.batch_size:
             if self._grid is None:
                 self._grid = DeviceGrid(self.models)
@@ -849,9 +902,17 @@ class BruteForce(object):
             self._engine_for = self.batch_size
         return self._engine_obj
 
+    def _bands_for(self, data_mask):
+        """Band subset of this call (`_bands_in_use`), None = the grid as it is.  A grid that
+        was adopted in kernel layout (`use_device_grid`) is used as it is."""
+        if self._grid_adopted:
+            return None
+        return _bands_in_use(data_mask, self.NDIM)
+
     def use_device_grid(self, grid):
         """Adopt a `DeviceGrid` that is already resident (e.g. broadcast)."""
         self._grid = grid
+        self._grid_adopted = True
         self._engine_obj = None
 
     # -- set-up (reference fitting.py:1144-1424) ------------------------------
@@ -1103,7 +1164,12 @@ class BruteForce(object):
         parallax = np.asarray(parallax, dtype=np.float64)
         parallax_err = np.asarray(parallax_err, dtype=np.float64)
 
-        eng = self._engine()
+        # bands no object of this call uses are dropped from the grid (identical results:
+        # the reference drops an object's masked bands before any arithmetic, :709-716)
+        bands = self._bands_for(data_mask)
+        eng = self._engine(bands)
+        if bands is not None:
+            data, data_err, data_mask = data[:, bands], data_err[:, bands], data_mask[:, bands]
         params = _make_params(avlim, av_gauss, rvlim, rv_gauss, ltol,
                               ltol_subthresh, logl_initthresh, logl_dim_prior,
                               wt_thresh=wt_thresh)
@@ -1129,9 +1195,19 @@ class BruteForce(object):
         from . import pdf as _pdf
         dust_tables = None
         if apply_av_prior and lndustprior is _pdf.dust_lnprior:
-            # built per batch (bounded memory, no catalogue-long Python loop up front);
-            # provider errors surface to the caller
-            dust_tables = lambda a, b: _pdf.los_tables(dustfile, data_coords[a:b])
+            # built per batch (bounded memory, no catalogue-long Python loop up front).  The
+            # provider is probed on the first batch BEFORE anything is yielded: whatever it
+            # returns that `los_tables` cannot tabulate but the host `dust_lnprior` accepts
+            # keeps the host stage for the whole call (as before the device dust stage
+            # existed); later provider errors surface to the caller.
+            b0 = min(Ndata, eng.batch)
+            try:
+                first = _pdf.los_tables(dustfile, data_coords[:b0])
+            except Exception:
+                first = None
+            if first is not None:
+                dust_tables = lambda a, b: (first if (a, b) == (0, b0) else
+                                            _pdf.los_tables(dustfile, data_coords[a:b]))
         dust_ok = (not apply_av_prior and lndustprior is None) or dust_tables is not None
         if (self.device_lnpost and lnprior_ext is None and dust_ok
                 and wt_thresh is not None and wt_thresh > 0

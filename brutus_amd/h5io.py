@@ -501,6 +501,7 @@ class ResultsFile(object):
         import queue
         import threading
         self._err = None
+        self.dropped = []               # [lo, hi) row ranges lost to a writer failure
         self._cur = None
         self._free = queue.Queue()
         self._full = queue.Queue(maxsize=self.NBLOCKS + 4)    # back-pressure on write_block
@@ -520,37 +521,71 @@ class ResultsFile(object):
             try:
                 if self._err is None:
                     self._write_job(job)
-            except BaseException as e:          # surfaces at the next write_row / close
+                else:                           # after a failure nothing more is written:
+                    self._note_dropped(job)     # the row ranges are reported with the error
+            except BaseException as e:          # surfaces at the next write_row / flush / close
                 self._err = e
+                self._note_dropped(job)
             finally:
                 if isinstance(job, ResultsFile._Block):
                     job.n = 0
                     self._free.put(job)
                 self._full.task_done()
 
-    def _write_job(self, job):
+    def _note_dropped(self, job):
         if isinstance(job, ResultsFile._Block):
-            n = job.n
-            rows = job.rows[:n]
-            if n and np.all(rows[1:] == rows[:-1] + 1):      # the usual case: one ascending run
-                for k in self.layout:
-                    self.file.write_rows(k, int(rows[0]), job.arr[k][:n])
-            elif n:
-                order = np.argsort(rows, kind="stable")
-                srt = rows[order]
-                cuts = np.flatnonzero(srt[1:] != srt[:-1] + 1) + 1
-                for a, b in zip(np.r_[0, cuts], np.r_[cuts, n]):
-                    for k in self.layout:
-                        self.file.write_rows(k, int(srt[a]), job.arr[k][order[a:b]])
-        else:                                   # (first row, {dataset: rows}) from write_block
+            rows = np.sort(job.rows[:job.n])
+            if rows.size:
+                cuts = np.flatnonzero(rows[1:] != rows[:-1] + 1) + 1
+                for a, b in zip(np.r_[0, cuts], np.r_[cuts, rows.size]):
+                    self.dropped.append((int(rows[a]), int(rows[b - 1]) + 1))
+        else:
             start, blocks = job
-            for k in self.layout:
-                self.file.write_rows(k, start, blocks[k])
-        self.file.flush()
+            self.dropped.append((int(start), int(start) + len(next(iter(blocks.values())))))
+
+    #: `resume()` decides from this dataset alone whether a row was fitted (the reference's
+    #: -99 sentinel, fitting.py:1635), so it is written LAST, after every other dataset of
+    #: the same rows has been flushed: a run killed between two datasets leaves rows whose
+    #: sentinel is still in place, never rows that look finished and are not.
+    SENTINEL = "model_idx"
+
+    def _write_job(self, job):
+        names = [k for k in self.layout if k != self.SENTINEL]
+        for part in (names, [self.SENTINEL]):
+            if isinstance(job, ResultsFile._Block):
+                n = job.n
+                rows = job.rows[:n]
+                if n and np.all(rows[1:] == rows[:-1] + 1):      # the usual case: one ascending run
+                    for k in part:
+                        self.file.write_rows(k, int(rows[0]), job.arr[k][:n])
+                elif n:
+                    order = np.argsort(rows, kind="stable")
+                    srt = rows[order]
+                    cuts = np.flatnonzero(srt[1:] != srt[:-1] + 1) + 1
+                    for a, b in zip(np.r_[0, cuts], np.r_[cuts, n]):
+                        for k in part:
+                            self.file.write_rows(k, int(srt[a]), job.arr[k][order[a:b]])
+            else:                                   # (first row, {dataset: rows}) from write_block
+                start, blocks = job
+                for k in part:
+                    self.file.write_rows(k, start, blocks[k])
+            self.file.flush()
 
     def _check_err(self):
-        if getattr(self, "_err", None) is not None:
-            e, self._err = self._err, None
+        """A failure of the writer is sticky: every later `write_row` / `write_block` /
+        `flush` / `close` raises it again (with the row ranges that never reached the
+        file), until the file is closed -- a caller that caught the first one cannot end
+        up with a file that has holes and a clean exit."""
+        e = getattr(self, "_err", None)
+        if e is not None:
+            if self.dropped and not getattr(e, "_brutus_noted", False):
+                try:
+                    e.args = (e.args + ("results rows not written: %s"
+                                        % ", ".join("[%d, %d)" % r for r in self.dropped[:8])
+                                        + (" ..." if len(self.dropped) > 8 else ""),))
+                    e._brutus_noted = True
+                except Exception:
+                    pass
             raise e
 
     def _next_block(self):
@@ -564,7 +599,14 @@ class ResultsFile(object):
             self._full.put(job)
         else:
             try:
-                self._write_job(job)
+                if self._err is None:
+                    self._write_job(job)
+                else:
+                    self._note_dropped(job)
+            except BaseException as e:
+                self._err = e
+                self._note_dropped(job)
+                raise
             finally:
                 if isinstance(job, ResultsFile._Block):
                     job.n = 0

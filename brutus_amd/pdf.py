@@ -11,8 +11,16 @@ import os
 
 import numpy as np
 
+from .galprior import (gal_lnprior, logn_disk, logn_halo, logp_age_from_feh,   # noqa: F401
+                       logp_feh)
+
+# the reference's `brutus.pdf.__all__` (pdf.py:30-35) minus `bin_pdfs_distred` (plot binning,
+# out of scope), plus the table type of the Bayestar-free dust interface
 __all__ = ["imf_lnprior", "ps1_MrLF_lnprior", "parallax_lnprior",
-           "scale_parallax_lnprior", "parallax_to_scale", "dust_lnprior",
+           "scale_parallax_lnprior", "parallax_to_scale",
+           "logn_disk", "logn_halo",
+           "logp_feh", "logp_age_from_feh",
+           "gal_lnprior", "dust_lnprior",
            "LOSTable"]
 
 
@@ -172,8 +180,14 @@ def los_tables(dustfile, coords):
     rows, ok = [], []
     for c in np.asarray(coords, dtype=np.float64):
         d, m, e = (np.atleast_1d(np.asarray(x, dtype=np.float64)) for x in q(c))
-        if not (d.shape == m.shape == e.shape) or d.ndim != 1 or d.size < 2:
-            raise ValueError("a line-of-sight profile needs >= 2 nodes of (dist, mean, err)")
+        if not (d.shape == m.shape == e.shape) or d.ndim != 1 or d.size < 1:
+            raise ValueError("a line-of-sight profile is three equally long 1-d arrays "
+                             "(dist, mean, err)")
+        if d.size == 1:
+            # `numpy.interp` (the host form) takes a one-node profile as a constant; a second
+            # node with the same values further out says the same to the device stage
+            d = np.array([d[0], d[0] + 1.])
+            m, e = np.repeat(m, 2), np.repeat(e, 2)
         good = bool(np.all(np.isfinite(m) & np.isfinite(e)))
         ok.append(1 if good else 0)
         rows.append(np.stack([d, np.where(np.isfinite(m), m, 0.), np.where(np.isfinite(e), e, 0.)]))

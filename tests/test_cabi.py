@@ -33,6 +33,28 @@ def test_library_exports_every_declared_symbol():
     assert not [n for n in names if "debug" in n or "calibrate" in n]
 
 
+def test_library_exports_nothing_outside_its_prefix():
+    """Every defined text symbol of the shared library is a `brutus_*` entry point (C++
+    helpers are `static`; device-stub / runtime registration symbols are not `T`-global C
+    names and carry the compiler's own prefixes)."""
+    import subprocess
+    from brutus_amd import _lib
+    out = subprocess.check_output(["nm", "-D", "--defined-only", _lib.LIB_PATH], text=True)
+    leaked = [ln.split()[-1] for ln in out.splitlines()
+              if len(ln.split()) == 3 and ln.split()[1] == "T"
+              and not ln.split()[-1].startswith(("brutus_", "_Z", "__hip", "_init", "_fini"))]
+    assert not leaked, leaked
+    # and no unprefixed free C++ function of ours either (mangled names in the global namespace
+    # that are not kernels' host stubs): the kernels live in templates / have device stubs only
+    mangled = [ln.split()[-1] for ln in out.splitlines()
+               if len(ln.split()) == 3 and ln.split()[1] == "T" and ln.split()[-1].startswith("_Z")]
+    names = subprocess.run(["c++filt"], input="\n".join(mangled), text=True,
+                           capture_output=True).stdout.splitlines()
+    helpers = [n for n in names if not n.startswith(("__device_stub__", "void __device_stub__"))
+               and "k_" not in n.split("(")[0]]
+    assert not helpers, helpers[:10]
+
+
 def test_abi_version_and_queries():
     from brutus_amd import _lib
     L = _lib.lib()

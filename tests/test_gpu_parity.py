@@ -551,6 +551,10 @@ def test_argument_errors():
         fitting.loglike(f, e, m, models, init_thresh=None)
     with pytest.raises(ValueError, match="filters"):
         fitting.DeviceGrid(np.zeros((10, 33, 3), np.float32))
+    # more than 32 bands UNMASKED in one call is the only band count that is refused
+    with pytest.raises(ValueError, match="filters"):
+        fitting.loglike(np.ones(40), np.ones(40), np.ones(40, bool),
+                        np.zeros((10, 40, 3), np.float32))
     with pytest.raises(ValueError, match="bands"):
         fitting.loglike(f[:5], e[:5], m[:5], models)
 
@@ -769,3 +773,69 @@ def test_device_newton_and_select_free_forms_accuracy():
     ty = torch.ones_like(tx)
     _lib.check(L.brutus_debug_math(3, tx.data_ptr(), ty.data_ptr(), 4, None))
     assert np.array_equal(ty.cpu().numpy(), np.zeros(4))
+
+
+def test_grid_file_with_all_49_filters_fits_like_the_sub_grid(tmp_path):
+    """The first cell of the reference's notebooks: `load_models(path)` with its defaults
+    returns every filter of the file (utils.py:575-576, filters.py:13-29); the data then carry
+    eight of them (Orion: PS grizy + 2MASS JHKs) and every other band is masked for every
+    object.  The reference drops masked bands per object (fitting.py:709-716), so the fit on
+    the 49-filter grid must be the fit on the 8-band sub-grid -- bit for bit here, because the
+    49-band grid is compacted to the used bands before it goes to the device."""
+    from brutus_amd import fitting, h5io, synth, utils
+    from brutus_amd.filters import FILTERS
+    assert len(FILTERS) == 49
+    n = 4000
+    used = ["PS_g", "PS_r", "PS_i", "PS_z", "PS_y", "2MASS_J", "2MASS_H", "2MASS_Ks"]
+    big, labels, lmask = synth.make_grid(n, 49, seed=31)
+    ctype = np.dtype([(f, "f4", (3,)) for f in FILTERS])
+    coeffs = np.zeros(n, dtype=ctype)
+    for j, f in enumerate(FILTERS):
+        coeffs[f] = big[:, j]
+    lab = np.zeros(n, dtype=[("mini", "f8"), ("eep", "f8"), ("feh", "f8"), ("smf", "f8")])
+    par = np.zeros(n, dtype=[("loga", "f8"), ("agewt", "f8")])
+    for k in ("mini", "eep", "feh"):
+        lab[k] = labels[k]
+    for k in ("loga", "agewt"):
+        par[k] = labels[k]
+    path = os.path.join(str(tmp_path), "grid49.h5")
+    h5io.write_datasets(path, {"mag_coeffs": coeffs, "labels": lab, "parameters": par})
+    models, mlab, mmask = utils.load_models(path, verbose=False)          # defaults
+    assert models.shape == (n, 49, 3)
+    cols = [FILTERS.index(f) for f in used]
+    sub = np.ascontiguousarray(models[:, cols, :])
+    st = synth.make_stars(sub, 12, seed=32)
+    # Orion-style: a missing band here and there (never fewer than four left)
+    rng = np.random.RandomState(3)
+    for i in range(12):
+        st["mask"][i, rng.choice(8, size=rng.randint(0, 3), replace=False)] = False
+    wide = lambda a, fill: np.stack([a[:, cols.index(j)] if j in cols else
+                                     np.full(a.shape[0], fill) for j in range(49)], axis=1)
+    flux49, err49 = wide(st["flux"], 1.), wide(st["err"], np.inf)   # (mag -999, err inf) style
+    mask49 = wide(st["mask"], False).astype(bool)
+
+    def run(m, f, e, k):
+        BF = fitting.BruteForce(m, mlab, mmask)
+        BF.batch_size = 5
+        return list(BF._fit(f, e, k, parallax=st["parallax"], parallax_err=st["parallax_err"],
+                            Nmc_prior=20, lngalprior=galprior, data_coords=st["coords"],
+                            rstate=np.random.RandomState(7), Ndraws=60))
+    a = run(models, flux49, err49, mask49)
+    b = run(sub, st["flux"], st["err"], st["mask"])
+    assert len(a) == len(b) == 12
+    for ra, rb in zip(a, b):
+        for xa, xb in zip(ra, rb):
+            assert np.array_equal(np.asarray(xa), np.asarray(xb))
+    # the module-level `loglike` takes the 49-band grid too (full-grid outputs are per model)
+    la = fitting.loglike(flux49[0], err49[0], mask49[0], models, return_vals=True)
+    lb = fitting.loglike(st["flux"][0], st["err"][0], st["mask"][0], sub, return_vals=True)
+    for xa, xb in zip(la, lb):
+        assert np.array_equal(np.asarray(xa), np.asarray(xb))
+    # and fit() writes the file through the same path
+    BF = fitting.BruteForce(models, mlab, mmask)
+    BF.fit(flux49, err49, mask49, np.arange(12), os.path.join(str(tmp_path), "out49"),
+           parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
+           lngalprior=galprior, data_coords=st["coords"], rstate=np.random.RandomState(7),
+           Ndraws=60, verbose=False)
+    got = h5io.read_dataset(os.path.join(str(tmp_path), "out49.h5"), "model_idx")
+    assert np.array_equal(got, np.stack([r[0] for r in b]).astype(got.dtype))

@@ -292,8 +292,58 @@ def test_results_writer_reports_errors_of_the_background_thread(tmp_path):
     rf.write_row(1, rows[1])            # hands a block to the writer, which fails
     with pytest.raises(OSError):
         rf.flush()
-    rf.file.close()
-    rf.file = None
+    # sticky: a caller that swallowed the first report still cannot finish cleanly, and the
+    # rows that never reached the file are named
+    with pytest.raises(OSError, match="disk full") as ei:
+        rf.write_row(2, rows[2])
+    assert "not written" in str(ei.value.args) and (0, 2) in rf.dropped
+    rf._cur = None
+    with pytest.raises(OSError):
+        rf.close()
+    assert rf.file is None
+
+
+@pytest.mark.parametrize("mode", ["rows", "block"])
+def test_results_writer_killed_between_datasets_keeps_the_sentinel(tmp_path, mode):
+    """`resume()` trusts `model_idx != -99` alone (reference fitting.py:1635), so within a
+    block the sentinel dataset must reach the disk LAST: a writer that dies after any of
+    the other datasets leaves the block's rows marked unfitted."""
+    from brutus_amd import h5io
+    names = list(h5io.ResultsFile.row_dtype(3, True)[0].names)
+    rows = _rows(6, 3)
+    for die_after in range(len(names)):
+        p = str(tmp_path / ("kill_%s_%d.h5" % (mode, die_after)))
+        rf = h5io.ResultsFile(p, 6, 3, None, True, flush_every=2, async_io=False)
+        rf.write_row(0, rows[0])
+        rf.write_row(1, rows[1])            # block 0 complete and written
+        real = rf.file.write_rows
+        seen = []
+
+        def dying(name, start, arr, real=real, seen=seen):
+            if len(seen) == die_after:
+                raise KeyboardInterrupt("killed")
+            seen.append(name)
+            return real(name, start, arr)
+        rf.file.write_rows = dying
+        with pytest.raises(KeyboardInterrupt):
+            if mode == "rows":
+                rf.write_row(2, rows[2])
+                rf.write_row(3, rows[3])
+            else:
+                dt, positions = h5io.ResultsFile.row_dtype(3, True)
+                blk = np.zeros(2, dtype=dt)
+                for name, pos in positions:
+                    for j in range(2):
+                        blk[name][j] = rows[2 + j][pos]
+                rf.write_block(2, {name: blk[name] for name in dt.names})
+        assert seen == [n for n in names if n != "model_idx"][:die_after] + \
+            (["model_idx"] if die_after == len(names) else [])
+        rf.file.write_rows = real
+        rf.file.close()
+        rf.file = None
+        todo = h5io.ResultsFile.resume(p, 6, 3, True)
+        assert list(todo.todo) == [2, 3, 4, 5], (die_after, list(todo.todo))
+        todo.close()
 
 
 def test_los_tables_pad_shorter_profiles():
@@ -308,5 +358,10 @@ def test_los_tables_pad_shorter_profiles():
     assert np.array_equal(los[1, 0], [0.2, 2., 2.])
     d = np.linspace(0.05, 5., 50)
     assert np.array_equal(np.interp(d, los[0, 0], los[0, 1]), np.interp(d, *prof[0][:2]))
+    # one node (or scalars): a constant profile for numpy.interp, and so for the table
+    for one in ((np.array([1.]), np.array([0.7]), np.array([0.2])), (1., 0.7, 0.2)):
+        los, ok = pdf.los_tables(lambda c: one, np.zeros((1, 2)))
+        assert ok.tolist() == [1] and los.shape == (1, 3, 2)
+        assert np.array_equal(np.interp(d, los[0, 0], los[0, 1]), np.interp(d, [1.], [0.7]))
     with pytest.raises(ValueError):
-        pdf.los_tables(lambda c: (np.array([1.]), np.array([1.]), np.array([1.])), np.zeros((1, 2)))
+        pdf.los_tables(lambda c: (np.array([1., 2.]), np.array([1.]), np.array([1.])), np.zeros((1, 2)))

@@ -82,3 +82,28 @@ def test_lnpost_host_stage_matches_oracle():
         assert np.array_equal(a[0], b[0])
         for x, y in zip(a[1:], b[1:]):
             assert relerr(x, y) < 1e-9
+
+
+def test_bands_in_use_and_pdf_names():
+    """Host logic of the band compaction (no GPU): which bands a call needs, and the
+    reference's `brutus.pdf` names (pdf.py:30-35) importable from `brutus_amd.pdf`."""
+    from brutus_amd import fitting
+    m = np.zeros((3, 49), bool)
+    m[:, [3, 9, 10, 11, 40]] = True
+    m[1, 9] = False
+    assert np.array_equal(fitting._bands_in_use(m, 49), [3, 9, 10, 11, 40])
+    assert fitting._bands_in_use(np.ones((2, 12), bool), 12) is None
+    k = np.ones((2, 12), bool)
+    k[:, 11] = False                      # 11 of 12: the padded band count stays 12
+    assert fitting._bands_in_use(k, 12) is None
+    k[:, 6:] = False                      # 6 of 12 -> the 8-band kernels
+    assert np.array_equal(fitting._bands_in_use(k, 12), np.arange(6))
+    w = np.ones((1, 40), bool)            # 40 used of 40: nothing to drop (DeviceGrid raises)
+    assert fitting._bands_in_use(w, 40) is None
+    from brutus_amd.pdf import (gal_lnprior, logn_disk, logn_halo, logp_feh,   # noqa: F401
+                                logp_age_from_feh, dust_lnprior, imf_lnprior)
+    import brutus_amd.pdf as pdf
+    ref_all = ["imf_lnprior", "ps1_MrLF_lnprior", "parallax_lnprior",
+               "scale_parallax_lnprior", "parallax_to_scale", "logn_disk", "logn_halo",
+               "logp_feh", "logp_age_from_feh", "gal_lnprior", "dust_lnprior"]
+    assert [n for n in ref_all if n not in pdf.__all__] == []
