@@ -653,6 +653,60 @@ __device__ __forceinline__ void gather_coef(const float *__restrict__ grid, int6
     }
 }
 
+// The same row kept RAW in registers (3*NB/4 float4): requested one work item ahead and turned
+// into a Coef when its item comes up, so the gather's latency lies under the previous item's
+// arithmetic (k_derive).
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // (a native vector: an asm operand)
+template <int NB>
+struct RowRegs {
+    f32x4 q[3 * NB / 4];
+};
+template <int NB>
+__device__ __forceinline__ void gather_row(const float *__restrict__ grid, int64_t nmodel_pad,
+                                           int64_t i, RowRegs<NB> &r) {
+    const f32x4 *row =
+        reinterpret_cast<const f32x4 *>(grid + (int64_t)3 * NB * nmodel_pad + i * (3 * NB));
+#pragma unroll
+    for (int q = 0; q < 3 * NB / 4; ++q) r.q[q] = row[q];
+}
+template <int NB>
+__device__ __forceinline__ void row_to_coef(const RowRegs<NB> &r, Coef<NB> &c) {
+    float t[3 * NB];
+#pragma unroll
+    for (int q = 0; q < 3 * NB / 4; ++q) {
+        t[4 * q] = r.q[q].x;
+        t[4 * q + 1] = r.q[q].y;
+        t[4 * q + 2] = r.q[q].z;
+        t[4 * q + 3] = r.q[q].w;
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        c.m[j] = t[3 * j];
+        c.r0[j] = t[3 * j + 1];
+        c.dr[j] = t[3 * j + 2];
+    }
+}
+// "These loads have to have landed HERE": an empty asm that takes the registers as operands
+// and orders memory operations.  gfx9 counts loads and stores in ONE counter (vmcnt) and the
+// compiler, once both kinds are pending, can only wait for everything -- so a wait for a
+// prefetched load placed BEHIND a batch of stores also waits for the stores' write
+// acknowledgements (a full memory round trip per work item).  Placed in FRONT of the
+// stores it finds only loads that were issued a whole work item ago.
+template <int NB>
+__device__ __forceinline__ void landed(RowRegs<NB> &r) {
+#pragma unroll
+    for (int q = 0; q < 3 * NB / 4; ++q) {
+        f32x4 t = r.q[q];
+        asm volatile("" : "+v"(t) : : "memory");
+        r.q[q] = t;
+    }
+}
+__device__ __forceinline__ void landed(int32_t &x) {
+    int32_t t = x;
+    asm volatile("" : "+v"(t) : : "memory");
+    x = t;
+}
+
 // The caller's record value planes (BRUTUS_NVALS x cap float64; include/brutus_amd.h):
 //   0 lnlike, 1 chi2, 2 scale, 3 av, 4 rv, 5..10 icov[00, 01, 02, 11, 12, 22].
 // Slots [0, ncand) belong to the candidates of the cull in candidate-list order -- the flux
@@ -693,8 +747,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     // this lane's model in a work item, requested one item ahead (a dead lane reads the
     // item's last entry: no select on the loaded value, so nothing waits for it here)
     auto lane_model = [&](int item) -> int32_t {
-        if (item < 0) return 0;
-        const ItemGeom ig = items[item];
+        const ItemGeom ig = items[item < 0 ? 0 : item];      // (past the end: item 0 again, unused)
         const int64_t q = ig.q0 + threadIdx.x;
         const int64_t last = ig.q0 + ig.n - 1;
         return cand_idx[q < last ? q : last];
@@ -715,7 +768,10 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int s = ig.s;
         const int32_t i_me = i_nxt;
         i_nxt = lane_model(wk.item);
-        if (k2state[s] < 0) continue;
+        if (k2state[s] < 0) {
+            landed(i_nxt);      // (every path into the loop head has taken it: no wait there)
+            continue;
+        }
         const StarPrep &sp = stars[s];
         const int64_t q = ig.q0 + threadIdx.x;       // list position = record slot
         const bool live = (int)threadIdx.x < ig.n && q < rec.cap;
@@ -724,6 +780,9 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int64_t i = i_me;
         const int64_t o = (int64_t)s * nmodel + i;
         if (!FIRST && live) go = surv_is(surv32[o]);
+        Mle m;
+        double o_lnl = 0., o_lnprob = 0., o_av = 0., o_rv = 0., o_step = 0.;
+        bool store = false;
         if (go) {
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
@@ -765,7 +824,6 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 step = step_st[q];
                 lnl_old = -0.5 * r_chi2[q];
             }
-            Mle m;
             if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
             else mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             if constexpr (FIRST) {
@@ -795,27 +853,37 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 lnl_old = lnl_new;
             }
             if (go) {
-                const double lnl = final_lnl<RVF>(sp, p, m.chi2, true);
-                const double lnprob = first_cut_lnprob(sp, lnl, m.scale, m.i00);
-                r_lnl[q] = lnl;
-                r_chi2[q] = m.chi2;
-                r_scale[q] = m.scale;
-                r_av[q] = av;
-                if constexpr (!RVF) r_rv[q] = rv;
-                rec.plane(5)[q] = m.i00;
-                rec.plane(6)[q] = m.i01;
-                rec.plane(7)[q] = m.i02;
-                rec.plane(8)[q] = m.i11;
-                rec.plane(9)[q] = m.i12;
-                rec.plane(10)[q] = m.i22;
-                step_st[q] = step;
-                lnprob_st[q] = lnprob;
-                M = lnprob;
+                o_lnl = final_lnl<RVF>(sp, p, m.chi2, true);
+                o_lnprob = first_cut_lnprob(sp, o_lnl, m.scale, m.i00);
+                o_av = av;
+                o_rv = rv;
+                o_step = step;
+                M = o_lnprob;
                 if (lnl_new == lnl_new) {
                     L = lnl_new;
                     if (dl > p.ltol) T = lnl_new;
                 }
             }
+            store = go;
+        }
+        // The next item's list entry was requested a whole item ago: it is taken HERE, on every
+        // path and in front of this item's stores, not at the top of the next iteration behind
+        // them (see `landed`: that wait would include the stores' write acknowledgements).
+        landed(i_nxt);
+        if (store) {
+            r_lnl[q] = o_lnl;
+            r_chi2[q] = m.chi2;
+            r_scale[q] = m.scale;
+            r_av[q] = o_av;
+            if constexpr (!RVF) r_rv[q] = o_rv;
+            rec.plane(5)[q] = m.i00;
+            rec.plane(6)[q] = m.i01;
+            rec.plane(7)[q] = m.i02;
+            rec.plane(8)[q] = m.i11;
+            rec.plane(9)[q] = m.i12;
+            rec.plane(10)[q] = m.i22;
+            step_st[q] = o_step;
+            lnprob_st[q] = o_lnprob;
         }
         // one partial per wave: no workgroup barrier in the loop, the four waves drift
         // apart and overlap each other's gather latency
@@ -986,53 +1054,80 @@ k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
     const int64_t slot0 = cand_off[nstar];
     ItemWalk wk;
     wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
-    int32_t i_nxt = lane_model(wk.item);
-    while (!wk.done()) {
-        const int item = wk.item;
-        wk.next();
+    if (wk.done()) return;
+    // Software pipeline over the work items (two waves per SIMD cannot hide a gather AND a
+    // write acknowledgement per item): while item k is computed, the coefficient rows of item
+    // k + 1 (36 registers at 12 bands) and the list entry of item k + 2 are in flight; both are
+    // taken in front of item k's stores (`landed`), so no wait in the loop finds a load younger
+    // than a whole item or a store younger than the previous item's.
+    int item = wk.item;
+    wk.next();
+    int item1 = wk.item;
+    int32_t i0 = lane_model(item), i1 = lane_model(item1);
+    RowRegs<NB> nx;
+    gather_row<NB>(grid, nmodel_pad, i0, nx);
+    landed(i1);
+    landed<NB>(nx);
+    while (item >= 0) {
+        Coef<NB> c;
+        row_to_coef<NB>(nx, c);
+        gather_row<NB>(grid, nmodel_pad, i1, nx);        // (item1 < 0: row 0, never used)
+        if (item1 >= 0) wk.next();
+        const int item2 = item1 >= 0 ? wk.item : -1;
+        int32_t i2 = lane_model(item2);
         const ItemGeom ig = items[item];
         const int s = ig.s;
-        const int64_t i = i_nxt;
-        i_nxt = lane_model(wk.item);
         const int64_t slot = slot0 + ig.q0 + threadIdx.x;
-        if ((int)threadIdx.x >= ig.n || slot >= rec.cap) continue;
-        const StarPrep &sp = stars[s];
-        Coef<NB> c;
-        gather_coef<NB>(grid, nmodel_pad, i, c);
-        double F0[NB];
-        compute_F0_tbl<NB>(c, s_tbl, F0);
-        double av = p.av_mean, rv = p.rv_mean;
-        const int K = k1[s];
+        const bool live = (int)threadIdx.x < ig.n && slot < rec.cap;
+        const bool wave_live = (int)(threadIdx.x & ~63u) < ig.n;      // wave-uniform
+        double o_lnl = 0., o_av = 0., o_rv = 0.;
         Mle m;
-        if constexpr (RVF) {
-            double R[NB];
-            coef_R<NB>(c, rv, R);
-            GramR G;
-            gram_init_rf<NB>(c, R, sp, G);
-            double a_, c_;
-            if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_k1probe)
-            mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
-        } else {
-            Gram G;
-            gram_init<NB>(c, sp, G);
-            for (int kk = 0; kk < K; ++kk) {
-                double a_, b_, c_;
-                gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+        if (wave_live) {
+            const StarPrep &sp = stars[s];
+            double F0[NB];
+            compute_F0_tbl<NB>(c, s_tbl, F0);
+            double av = p.av_mean, rv = p.rv_mean;
+            const int K = k1[s];
+            if constexpr (RVF) {
+                double R[NB];
+                coef_R<NB>(c, rv, R);
+                GramR G;
+                gram_init_rf<NB>(c, R, sp, G);
+                double a_, c_;
+                if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_k1probe)
+                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+            } else {
+                Gram G;
+                gram_init<NB>(c, sp, G);
+                for (int kk = 0; kk < K; ++kk) {
+                    double a_, b_, c_;
+                    gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
+                }
+                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
             }
-            mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+            o_lnl = final_lnl<RVF>(sp, p, m.chi2, false);
+            o_av = av;
+            o_rv = rv;
         }
-        double *out = rec.vals + slot;
-        out[0] = final_lnl<RVF>(sp, p, m.chi2, false);
-        out[(int64_t)1 * rec.cap] = m.chi2;
-        out[(int64_t)2 * rec.cap] = m.scale;
-        out[(int64_t)3 * rec.cap] = av;
-        if constexpr (!RVF) out[(int64_t)4 * rec.cap] = rv;      // pinned Rv is not stored
-        out[(int64_t)5 * rec.cap] = m.i00;
-        out[(int64_t)6 * rec.cap] = m.i01;
-        out[(int64_t)7 * rec.cap] = m.i02;
-        out[(int64_t)8 * rec.cap] = m.i11;
-        out[(int64_t)9 * rec.cap] = m.i12;
-        out[(int64_t)10 * rec.cap] = m.i22;
+        landed<NB>(nx);
+        landed(i2);
+        if (wave_live && live) {
+            double *out = rec.vals + slot;
+            out[0] = o_lnl;
+            out[(int64_t)1 * rec.cap] = m.chi2;
+            out[(int64_t)2 * rec.cap] = m.scale;
+            out[(int64_t)3 * rec.cap] = o_av;
+            if constexpr (!RVF) out[(int64_t)4 * rec.cap] = o_rv;      // pinned Rv is not stored
+            out[(int64_t)5 * rec.cap] = m.i00;
+            out[(int64_t)6 * rec.cap] = m.i01;
+            out[(int64_t)7 * rec.cap] = m.i02;
+            out[(int64_t)8 * rec.cap] = m.i11;
+            out[(int64_t)9 * rec.cap] = m.i12;
+            out[(int64_t)10 * rec.cap] = m.i22;
+        }
+        item = item1;
+        item1 = item2;
+        i1 = i2;
     }
 }
 

@@ -831,11 +831,17 @@ def test_grid_file_with_all_49_filters_fits_like_the_sub_grid(tmp_path):
     lb = fitting.loglike(st["flux"][0], st["err"][0], st["mask"][0], sub, return_vals=True)
     for xa, xb in zip(la, lb):
         assert np.array_equal(np.asarray(xa), np.asarray(xb))
-    # and fit() writes the file through the same path
-    BF = fitting.BruteForce(models, mlab, mmask)
-    BF.fit(flux49, err49, mask49, np.arange(12), os.path.join(str(tmp_path), "out49"),
-           parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
-           lngalprior=galprior, data_coords=st["coords"], rstate=np.random.RandomState(7),
-           Ndraws=60, verbose=False)
-    got = h5io.read_dataset(os.path.join(str(tmp_path), "out49.h5"), "model_idx")
-    assert np.array_equal(got, np.stack([r[0] for r in b]).astype(got.dtype))
+    # and fit() (which adds the age-weight / grid-spacing priors) writes the same file
+    outs = []
+    for tag, m, f, e, k in (("out49", models, flux49, err49, mask49),
+                            ("out8", sub, st["flux"], st["err"], st["mask"])):
+        BF = fitting.BruteForce(m, mlab, mmask)
+        BF.fit(f, e, k, np.arange(12), os.path.join(str(tmp_path), tag),
+               parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
+               lngalprior=galprior, data_coords=st["coords"], rstate=np.random.RandomState(7),
+               Ndraws=60, verbose=False)
+        outs.append({n: h5io.read_dataset(os.path.join(str(tmp_path), tag + ".h5"), n)
+                     for n in ("model_idx", "ml_av", "obj_log_evid", "samps_dist", "obj_Nbands")})
+    assert (outs[0]["model_idx"] != -99).all()
+    for n in outs[0]:
+        assert np.array_equal(outs[0][n], outs[1][n]), n
