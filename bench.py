@@ -53,9 +53,19 @@ def parse():
                          "(BASELINE configs[3]: --scaling strong --steps 250 --batch 4000)")
     ap.add_argument("--single-config", action="store_true",
                     help="skip the second configuration reported under other_config")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 4, 5),
                     help="2 / 3: the grid-likelihood path (BASELINE configs[1] / [2]); "
+                         "4: configs[3], the sharded 1M-star catalogue = configs[2] with "
+                         "--scaling strong --steps 250 --batch 4000 (the same line); "
                          "5: cluster.isochrone_loglike (configs[4], supplementary line)")
+    ap.add_argument("--repeats", type=int, default=5,
+                    help="timed repeats of the K steps (SURVEY 8(d): >= 5 repeats of the whole "
+                         "star set): every repeat times EXACTLY `--steps` steps between two "
+                         "barrier + synchronize fences; `value` is the median, min / max and "
+                         "every repeat's time ride along")
+    ap.add_argument("--no-parity", action="store_true",
+                    help="skip the parity block (a few timed stars re-checked against the C "
+                         "restatement, 16 end-to-end objects against the oracle)")
     ap.add_argument("--cluster-stars", type=int, default=5000)
     ap.add_argument("--nmodel", type=int, default=750000)
     ap.add_argument("--nfilt", type=int, default=12)
@@ -105,7 +115,7 @@ def cpu_baseline(config, nmodel, nfilt, budget_s):
     return res
 
 
-def end_to_end(models, grid, stars, n, kw, with_par):
+def end_to_end(models, grid, stars, n, kw, with_par, check=True):
     """Second number asked for by SURVEY 8d: the whole `BruteForce.fit()` -- device scan +
     `lnpost` (second cut, Monte Carlo prior integral with Nmc_prior=50, resampling with
     Ndraws=250) + HDF5 output -- on stars of the same workload, default Galactic prior.
@@ -130,9 +140,14 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     # Av-only end to end = Rv pinned by its prior: rvlim=(3.32, 3.32) would reject every
     # Monte Carlo draw in lnpost
 
+    kept = {}
+
     def run(st, nfit, batch, **fkw):
+        """stars/s of `reps` whole fit() calls: the MEDIAN (a best-of-N flatters)."""
         bf.batch_size = batch
-        best = None
+        keep = fkw.pop("keep", None)
+        mk_rstate = fkw.pop("rstate")
+        times = []
         for rep in range(fkw.pop("reps", 1)):
             with tempfile.TemporaryDirectory() as tmp:
                 t0 = time.perf_counter()
@@ -141,15 +156,18 @@ def end_to_end(models, grid, stars, n, kw, with_par):
                        parallax=st["parallax"][:nfit] if with_par else None,
                        parallax_err=st["parallax_err"][:nfit] if with_par else None,
                        data_coords=st["coords"][:nfit], lngalprior=gal_lnprior,
-                       rv_gauss=rvg, verbose=False, **fkw)
-                dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
-        return nfit / best
+                       rv_gauss=rvg, verbose=False, rstate=mk_rstate(), **fkw)
+                times.append(time.perf_counter() - t0)
+                if keep is not None and keep not in kept:
+                    from brutus_amd import h5io
+                    kept[keep] = {k: h5io.read_dataset(os.path.join(tmp, "e2e.h5"), k)[:16]
+                                  for k in ("model_idx", "obj_log_evid", "obj_log_post")}
+        return nfit / float(np.median(times))
 
     n_shared = max(n, 1)
     big = synth.make_stars(models, 4096, seed=4242, with_parallax=with_par)
-    res = {"value": run(big, n_shared, 128, rstate=np.random.RandomState(862), reps=2),
-           "unit": "stars/s", "stars": n_shared,
+    res = {"value": run(big, n_shared, 128, rstate=lambda: np.random.RandomState(862), reps=3),
+           "unit": "stars/s", "stars": n_shared, "statistic": "median of 3 whole fit() calls",
            "note": "BruteForce.fit, one sequential numpy RandomState like the reference "
                    "(Nmc_prior=50, Ndraws=250, HDF5); lnpost on the device, numpy's stream "
                    "reproduced word for word"}
@@ -159,8 +177,8 @@ def end_to_end(models, grid, stars, n, kw, with_par):
     bf.batch_size = 128
     lnprior = bf._setup(big["flux"][:n2], big["err"][:n2], big["mask"][:n2], None,
                         data_coords=big["coords"][:n2], lngalprior=gal_lnprior)[5]
-    best = None
-    for rep in range(2):
+    times = []
+    for rep in range(3):
         with tempfile.TemporaryDirectory() as tmp:
             t0 = time.perf_counter()
             out = h5io.ResultsFile(os.path.join(tmp, "e2e.h5"), n2, 250, np.arange(n2), True)
@@ -172,30 +190,48 @@ def end_to_end(models, grid, stars, n, kw, with_par):
             for i, row in enumerate(gen):
                 out.write_row(i, row)
             out.close()
-            dt = time.perf_counter() - t0
-        best = dt if best is None else min(best, dt)
-    res["numpy_per_object"] = {"value": n2 / best, "unit": "stars/s", "stars": n2,
+            times.append(time.perf_counter() - t0)
+    res["numpy_per_object"] = {"value": n2 / float(np.median(times)), "unit": "stars/s", "stars": n2,
                                "note": "RandomState(seed0 + i) per object, device lnpost"}
-    res["device_lnpost"] = {"value": run(big, 4096, 128, rstate=PhiloxRandomState(862), reps=2),
+    res["device_lnpost"] = {"value": run(big, 4096, 128, rstate=lambda: PhiloxRandomState(862),
+                                         reps=3, keep="philox"),
                             "unit": "stars/s", "stars": 4096,
                             "note": "rstate=PhiloxRandomState: counter-based stream"}
     bf.device_numpy_rng = False
     nh = 6
-    res["host_lnpost"] = {"value": run(big, nh, nh, rstate=np.random.RandomState(862)),
+    res["host_lnpost"] = {"value": run(big, nh, nh, rstate=lambda: np.random.RandomState(862)),
                           "unit": "stars/s", "stars": nh,
                           "note": "same fit with the host stage (numpy draws the normals), "
                                   "what round 1 reported as fit_end_to_end.value"}
     bf.device_numpy_rng = True
+    if check and "philox" in kept:
+        res["parity"] = parity_end_to_end(models, labels, lmask, big, kept["philox"], rvg, with_par)
     return res
 
 
+def csrc_sha16():
+    """Fingerprint of the kernel sources (brutus_amd/csrc + include): the PMC table under
+    profiles/ carries the fingerprint it was measured on, so a kernel edited after the PMC
+    pass shows up as `roofline.traffic_stale` (the GPU box has no .git to diff against)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    for fn in sorted(glob.glob(os.path.join(ROOT, "brutus_amd", "csrc", "*"))
+                     + glob.glob(os.path.join(ROOT, "include", "*.h"))):
+        if os.path.isfile(fn):
+            h.update(os.path.basename(fn).encode())
+            h.update(open(fn, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def traffic_commit():
-    """Commit the PMC table under profiles/ was measured on (None if not recorded)."""
+    """(commit, source fingerprint) the PMC table under profiles/ was measured on."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f).get("commit")
+            t = json.load(f)
+            return t.get("commit"), t.get("csrc_sha16")
     except (IOError, ValueError):
-        return None
+        return None, None
 
 
 def measured_traffic(kernel, batch, config):
@@ -353,6 +389,76 @@ def bench_cluster(args, emit=True):
     return line
 
 
+def parity_scan(recs, stars, picks, models, kw, with_par):
+    """CHECKER (never timed, never part of the product path): `picks` stars of the timed set,
+    their device records against oracle/loglike_ref.c + the first cut of `lnpost`
+    (fitting.py:976-991) -- SURVEY 8(d) "parity gates reported with the metric"."""
+    try:
+        from oracle import c_oracle
+        from brutus_amd.pdf import scale_parallax_lnprior
+        if not c_oracle.available():
+            return {"error": "oracle/libbrutus_ref.so not built"}
+        rec, off, ndim, k1, k2 = recs
+        sel_equal = k_equal = True
+        max_rel = max_av = 0.
+        for s in picks:
+            par = float(stars["parallax"][s]) if with_par else np.nan
+            perr = float(stars["parallax_err"][s]) if with_par else np.nan
+            tr = {}
+            lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(
+                stars["flux"][s], stars["err"][s], stars["mask"][s], models, parallax=par,
+                parallax_err=perr, trace=tr, **kw)
+            with np.errstate(all="ignore"):
+                lnprob = lnl + scale_parallax_lnprior(sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), par, perr)
+            lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+            sel = np.where(lnprob > np.log(1e-3) + lnprob.max())[0]
+            idx, vals = rec.host(int(off[s]), int(off[s + 1]))
+            k_equal = k_equal and int(k1[s]) == tr["K1"] and int(k2[s]) == tr["K2"]
+            same = np.array_equal(idx, sel)
+            sel_equal = sel_equal and same
+            if same:
+                with np.errstate(all="ignore"):
+                    for got, ref in ((vals[0], lnl[sel]), (vals[1], chi2[sel]), (vals[2], sc[sel])):
+                        max_rel = max(max_rel, float(np.max(np.abs(got - ref) / np.maximum(np.abs(ref), 1e-300))))
+                    max_av = max(max_av, float(np.max(np.abs(vals[3] - av[sel]))))
+        return {"stars": len(picks), "sel_equal": bool(sel_equal), "k1_k2_equal": bool(k_equal),
+                "max_rel": max_rel, "max_abs_av": max_av,
+                "against": "oracle/loglike_ref.c + first cut, same inputs; max_rel over lnlike, chi2, scale"}
+    except Exception as e:                  # the parity block never costs the measurement
+        return {"error": repr(e)}
+
+
+def parity_end_to_end(models, labels, lmask, st, got, rvg, with_par, n=16):
+    """CHECKER: the first `n` rows fit() wrote in the counter-based leg against C `loglike` +
+    the oracle's numpy `lnpost` / resampling driven by the same PhiloxRandomState(862)."""
+    try:
+        from oracle import brutus_oracle as O
+        from oracle import c_oracle
+        from brutus_amd.galprior import gal_lnprior
+        from brutus_amd.rng import PhiloxRandomState
+        lnprior = O.static_lnprior(labels, lmask)
+        ro = PhiloxRandomState(862)
+        idx_equal, max_rel = True, 0.
+        for i in range(n):
+            par = float(st["parallax"][i]) if with_par else np.nan
+            perr = float(st["parallax_err"][i]) if with_par else np.nan
+            # fit()'s band cuts (reference fitting.py:1405-1410: mag_max=50, merr_max=0.25)
+            with np.errstate(all="ignore"):
+                mag, merr = O.magnitude(st["flux"][i][None, :], st["err"][i][None, :])
+            mask = st["mask"][i] & ~((mag[0] > 50.) | (merr[0] > 0.25))
+            results = c_oracle.loglike(st["flux"][i], st["err"][i], mask, models,
+                                       parallax=par, parallax_err=perr, rv_gauss=rvg)
+            ref = O.finish_star(results, lnprior, labels, st["coords"][i], par, perr, ro,
+                                gal_lnprior, Nmc_prior=50, Ndraws=250)
+            idx_equal = idx_equal and np.array_equal(np.asarray(ref[0]), got["model_idx"][i])
+            ev = float(got["obj_log_evid"][i])
+            max_rel = max(max_rel, abs(ev - ref[7]) / max(abs(ref[7]), 1e-300))
+        return {"objects": n, "model_idx_equal": bool(idx_equal), "max_rel_log_evid": max_rel,
+                "note": "file values are float32 (the reference's layout): 6e-8 is rounding"}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
 WORKLOADS = {
     2: "configs[1]: 750k-model x 12-band grid, Av-only solve (rvlim=(3.32,3.32)), no parallax",
     3: "configs[2]: 750k-model x 12-band grid, Av+Rv free, parallax prior",
@@ -466,23 +572,50 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
     run(max(args.warmup * nsub, NS if args.warmup else 0))
     if any(en.regrown for en in engines):       # buffers grew: once more, now at full size
         run(NS)
-    fence()
     grown = [en.regrown for en in engines]
-    t0 = time.perf_counter()
-    out = run(len(subs))              # exactly `steps` steps (this rank's share of them)
-    fence()
-    dt = time.perf_counter() - t0
+    # SURVEY 8(d) timing protocol: >= 5 timed repeats of the whole star set; every repeat is
+    # EXACTLY `steps` steps (this rank's share of them) between two barrier + synchronize
+    # fences, its time the max over ranks; the line reports the MEDIAN repeat, min / max beside
+    R = max(1, args.repeats)
+    own, job = [], []
+    for rep in range(R):
+        fence()
+        t0 = time.perf_counter()
+        out = run(len(subs))
+        fence()
+        dt = time.perf_counter() - t0
+        own.append(dt)
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        job.append(dt)
     if [en.regrown for en in engines] != grown:
         raise SystemExit("record buffers grew inside the timed region: timing invalid")
     nsel_total = int(out[0].counts[0])
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    med = int(np.argsort(job)[len(job) // 2])          # the median repeat
+    dt = job[med]
+    per_rank = [own[med]]
+    if world > 1:                                      # every rank's OWN time of that repeat
+        t = torch.zeros(world, dtype=torch.float64, device=dev)
+        t[rank] = own[med]
+        dist.all_reduce(t)
+        per_rank = [float(x) for x in t.cpu()]
     total_stars = nstars_job if strong else world * nstars_job
     res = {"value": total_stars / dt, "ms_per_step": dt / args.steps * 1e3,
+           "repeats": R, "repeat_s": job, "value_min": total_stars / max(job),
+           "value_max": total_stars / min(job), "per_rank_s": per_rank,
+           "timed_region_s": float(sum(job)),
            "stars_timed_per_rank": mine, "selected_models_last_sub_batch": nsel_total,
            "selected_fraction": nsel_total / float(int(subs[(len(subs) - 1)][0].shape[0]) * nmodel)}
+    if rank == 0 and not args.no_parity:
+        # parity gate beside the metric: four stars of the timed set, re-fitted now
+        rec, ndim_t, k1, k2 = one(0)
+        torch.cuda.synchronize()
+        n0 = int(subs[0][0].shape[0])
+        picks = sorted(set([0, n0 // 3, (2 * n0) // 3, n0 - 1]))
+        res["parity"] = parity_scan((rec, rec.off.cpu().numpy(), ndim_t, k1, k2), stars, picks,
+                                    models, kw, with_par)
 
     # ---- per-kernel durations (HIP events on the launch stream), after the timed
     # region and strictly sequential: with two streams the kernels of two sub-batches
@@ -550,7 +683,8 @@ def roofline_of(res, args, config, world, with_traffic=True):
             rl["traffic_over_algorithmic"] = traffic / (SB * g)
             rl["traffic_source"] = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE "
                                     "passes of tools/pmc_workload.py, not measured in this run")
-            rl["traffic_from_commit"] = traffic_commit()
+            rl["traffic_from_commit"], sha = traffic_commit()
+            rl["traffic_stale"] = sha != csrc_sha16()      # kernels edited since the PMC pass
     return rl
 
 
@@ -558,6 +692,14 @@ def main():
     args = parse()
     if args.config == 5:
         return bench_cluster(args)
+    cfg4 = args.config == 4
+    if cfg4:
+        # BASELINE configs[3]: ONE catalogue of 1M stars (configs[2]'s generator) split over the
+        # ranks by parallel.shard_range; one timed pass of it is 30 s at 8 ranks, so one repeat
+        args.config, args.scaling, args.steps, args.batch = 3, "strong", 250, 4000
+        args.single_config = args.no_survey_grid = args.no_cluster = True
+        args.e2e_stars, args.cpu_seconds = 0, 0.
+        args.repeats = min(args.repeats, 2)
     import torch
     import torch.distributed as dist
     from brutus_amd import _lib, fitting, synth
@@ -656,7 +798,17 @@ def main():
         "ms_per_step": res["ms_per_step"], "higher_is_better": True,
         "scaling": args.scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic", "config": cfg_block(main_cfg, res), "ranks_seen": ranks_seen,
+        "statistic": "median of %d timed repeats of the %d steps" % (res["repeats"], args.steps),
+        "repeats": res["repeats"], "value_min": res["value_min"], "value_max": res["value_max"],
+        "repeat_s": res["repeat_s"], "per_rank_s": res["per_rank_s"],
+        "timed_region_s": res["timed_region_s"],
     }
+    if cfg4:
+        line["config"]["workload"] = ("configs[3]: 1M stars (configs[2]'s generator) sharded over "
+                                      "%d rank(s), grid broadcast once; " % world
+                                      + line["config"]["workload"])
+    if "parity" in res:
+        line["parity"] = res["parity"]
     rl = roofline_of(res, args, main_cfg, world)
     if stream_gbs is not None:
         rl["measured_stream_gbs"] = stream_gbs
@@ -664,16 +816,21 @@ def main():
     if res_other is not None:
         line["other_config"] = {
             "value": res_other["value"], "unit": "stars/s", "ms_per_step": res_other["ms_per_step"],
+            "repeats": res_other["repeats"], "value_min": res_other["value_min"], "value_max": res_other["value_max"],
+            "parity": res_other.get("parity"),
             "config": cfg_block(other_cfg, res_other),
             "roofline": roofline_of(res_other, args, other_cfg, world)}
     if res_8d is not None:
         line["survey8d_grid"] = {
             "value": res_8d["value"], "unit": "stars/s", "ms_per_step": res_8d["ms_per_step"],
+            "repeats": res_8d["repeats"], "value_min": res_8d["value_min"], "value_max": res_8d["value_max"],
+            "parity": res_8d.get("parity"),
             "config": cfg_block(main_cfg, res_8d, "survey8d"),
             "roofline": roofline_of(res_8d, args, main_cfg, world, with_traffic=False)}
     if world == 1 and args.e2e_stars > 0:
         kw = dict(rvlim=(3.32, 3.32)) if main_cfg == 2 else dict()
-        line["fit_end_to_end"] = end_to_end(models, grid, None, args.e2e_stars, kw, main_cfg == 3)
+        line["fit_end_to_end"] = end_to_end(models, grid, None, args.e2e_stars, kw, main_cfg == 3,
+                                            check=not args.no_parity)
     if world == 1 and args.cpu_seconds > 0:
         line["cpu_baseline"] = cpu_baseline(main_cfg, nmodel, nfilt, args.cpu_seconds)
     if world == 1 and not args.no_cluster:

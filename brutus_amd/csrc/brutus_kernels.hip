@@ -39,6 +39,7 @@
 
 #include <stdlib.h>
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -85,6 +86,8 @@ struct Workspace {
     int64_t *offsets;   // (S, NCHUNK)
     // brutus_fit_batch
     int32_t *ids;       // (S,) star list of a launch
+    int32_t *ids2;      // (S,) second list (device-driven call: probe list beside the redo list)
+    int32_t *ctr;       // (8,) device-driven call: [0] stars to probe, [1] stars to redo, [3] "host path needed"
     int32_t *kfix;      // (S,)
     double *thr_cull, *maxsurv, *thr_sel;
     int32_t *surv_idx;  // (S * nmodel,) worst case: candidate lists, then band queues, then derived lists
@@ -149,6 +152,8 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool fit) {
         w.pl.step = (double *)take_big(sizeof(double) * pairs);
     } else {
         w.ids = (int32_t *)take(sizeof(int32_t) * nstar);
+        w.ids2 = (int32_t *)take(sizeof(int32_t) * nstar);
+        w.ctr = (int32_t *)take(sizeof(int32_t) * 8);
         w.kfix = (int32_t *)take(sizeof(int32_t) * nstar);
         w.thr_cull = (double *)take(sizeof(double) * nstar);
         w.maxsurv = (double *)take(sizeof(double) * nstar);
@@ -355,6 +360,8 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
 }
 
 // ---- hot path host orchestration (brutus_fit_batch) ----------------------------------
+constexpr int BRUTUS_RETRY_HOSTDRIVEN = -1000;     // internal: never leaves dispatch_fit
+std::atomic<long long> g_fit_calls{0}, g_fit_retries{0};     // device-driven calls / repeated host-driven
 constexpr int FS_TILES_PER_BLOCK = 8;
 constexpr int PERSIST_BLOCKS = 4096;
 
@@ -369,37 +376,60 @@ double env_double(const char *name, double dflt) {
 
 // nact == 0: the opening launch (all stars); else a continuation over the `nact` stars listed
 // in w.ids (device) that are still iterating.
+// nact < 0: a continuation whose list (w.ids) and length (*nact_dev) were written by
+// k_fflux_decide on the device -- a launch of fixed size.
+constexpr int CONT_BLOCKS = 2048;
 template <int NB, bool RVF>
 void launch_fflux(hipStream_t st, int nact, const float *grid, int64_t nmodel, int64_t nmodel_pad,
-                  int nstar, const DevParams &p, const Workspace &w, const RecPlanes &rec) {
+                  int nstar, const DevParams &p, const Workspace &w, const RecPlanes &rec,
+                  const int32_t *nact_dev = nullptr) {
     if (nact == 0)
         hipLaunchKernelGGL((k_fflux<NB, RVF, true>), dim3(PERSIST_BLOCKS), dim3(TILE), 0, st, grid,
                            nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx, w.surv_off,
                            w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part, w.lnpr32,
-                           w.thr_cull, (const int32_t *)nullptr, 0);
-    else
+                           w.thr_cull, (const int32_t *)nullptr, 0, (const int32_t *)nullptr);
+    else if (nact > 0)
         hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(NCHUNK * nact * CONT_P), dim3(TILE), 0, st,
                            grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx,
                            w.surv_off, w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part,
-                           w.lnpr32, w.thr_cull, w.ids, nact);
+                           w.lnpr32, w.thr_cull, w.ids, nact, (const int32_t *)nullptr);
+    else
+        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(CONT_BLOCKS), dim3(TILE), 0, st,
+                           grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx,
+                           w.surv_off, w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part,
+                           w.lnpr32, w.thr_cull, w.ids, 0, nact_dev);
 }
 
 // Exact K1 of the stars in `ids` by probing KS = 8 sweeps in float64 (k1 = 0: more needed).
+// `ids` = nullptr: the probe list (w.ids2, length w.ctr[0]) was put together on the device by
+// k_pre_decide; k_k1_decide then appends to the redo list (w.ids, length w.ctr[1]) itself.
 template <int NB, bool RVF>
-int launch_k1probe(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> &ids,
-                   const DevParams &p, Workspace &w, hipStream_t st, Timer &tm) {
+int launch_k1probe(const float *grid, int64_t nmodel, int nstar, const std::vector<int32_t> *ids,
+                   const DevParams &p, int max_iter, Workspace &w, hipStream_t st, Timer &tm) {
     constexpr int KS = 8;
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     const int nblkx = (ntile + FS_TILES_PER_BLOCK - 1) / FS_TILES_PER_BLOCK;
-    const int nrun = (int)ids.size();
-    HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
-    tm.begin("k_k1probe");
-    hipLaunchKernelGGL((k_k1probe<NB, KS, RVF>), dim3(nblkx, nrun), dim3(TILE), 0, st, grid, nmodel,
-                       nmodel_pad, nstar, nrun, w.ids, w.stars, p, FS_TILES_PER_BLOCK, ntile, w.part);
-    tm.end();
-    hipLaunchKernelGGL(k_k1_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, w.ids, KS, w.part,
-                       p.ln_init, w.k1);
+    if (ids) {
+        const int nrun = (int)ids->size();
+        HIP_TRY(hipMemcpyAsync(w.ids, ids->data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
+        tm.begin("k_k1probe");
+        hipLaunchKernelGGL((k_k1probe<NB, KS, RVF>), dim3(nblkx, nrun), dim3(TILE), 0, st, grid, nmodel,
+                           nmodel_pad, nstar, nrun, w.ids, w.stars, p, FS_TILES_PER_BLOCK, ntile, w.part,
+                           (const int32_t *)nullptr);
+        tm.end();
+        hipLaunchKernelGGL(k_k1_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, w.ids, KS, w.part,
+                           p.ln_init, w.k1, (const int32_t *)nullptr, (int32_t *)nullptr,
+                           (int32_t *)nullptr, (int32_t *)nullptr, RVF ? 1 : 0, max_iter);
+    } else {
+        tm.begin("k_k1probe");
+        hipLaunchKernelGGL((k_k1probe<NB, KS, RVF>), dim3(nblkx, nstar < 8 ? nstar : 8), dim3(TILE), 0, st,
+                           grid, nmodel, nmodel_pad, nstar, 0, w.ids2, w.stars, p, FS_TILES_PER_BLOCK,
+                           ntile, w.part, w.ctr + 0);
+        tm.end();
+        hipLaunchKernelGGL(k_k1_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids2, KS, w.part,
+                           p.ln_init, w.k1, w.ctr + 0, w.kfix, w.ctr, w.ids, RVF ? 1 : 0, max_iter);
+    }
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -430,17 +460,24 @@ int probe_k1_deep(const float *grid, int64_t nmodel, int star, const DevParams &
     }
 }
 
+// mode 0: host-driven (`ids`, `kfix` from the host; k_pre_decide leaves k1 / status for the host)
+// mode 1: device-driven opening pass over all stars (`ids`, `kfix` uploaded; k_pre_decide puts
+//         the probe list w.ids2 / w.ctr[0] and the redo list w.ids / w.ctr[1] together)
+// mode 2: device-driven re-run over the redo list as it stands on the device (accept = 1)
 template <int NB, bool RVF>
 int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
                  const std::vector<int32_t> &ids, const std::vector<int32_t> &kfix,
-                 const DevParams &p, Workspace &w, int accept, hipStream_t st, Timer &tm) {
+                 const DevParams &p, Workspace &w, int accept, hipStream_t st, Timer &tm,
+                 int mode = 0) {
     constexpr int G = 4;
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
     const int nblkx = (ntile + F2_T - 1) / F2_T;
-    const int nrun = (int)ids.size();
-    HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
+    const int nrun = mode == 2 ? nstar : (int)ids.size();
+    const int32_t *list = mode == 1 ? w.ids_all : w.ids;
+    if (mode == 0) HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
+    if (mode != 2) HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
+    const int32_t *nrun_dev = mode == 2 ? w.ctr + 1 : nullptr;
     P32 q;
     q.avmin = (float)p.avmin;
     q.avmax = (float)p.avmax;
@@ -457,12 +494,12 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     tm.begin("k_pre32");
     hipLaunchKernelGGL((k_pre32<NB, RVF, G>), dim3(8 * ((nblkx + 7) / 8) * ((nrun + G - 1) / G)),
                        dim3(TILE), 0, st, grid,
-                       nmodel, nmodel_pad, nstar, nrun, w.ids, w.s32, q, w.kfix, ntile, w.lnlp32,
-                       w.lnpr32, w.part32);
+                       nmodel, nmodel_pad, nstar, nrun, list, w.s32, q, w.kfix, ntile, w.lnlp32,
+                       w.lnpr32, w.part32, nrun_dev);
     tm.end();
-    hipLaunchKernelGGL(k_pre_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, w.ids, w.part32,
+    hipLaunchKernelGGL(k_pre_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, list, w.part32,
                        w.s32, (float)p.ln_init, RVF ? 1 : 0, w.kfix, accept, w.st32, w.k1, w.status,
-                       w.nomA);
+                       w.nomA, mode == 1 ? w.ctr : (int32_t *)nullptr, w.ids2, w.ids, nrun_dev);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -473,7 +510,7 @@ template <int NB, bool RVF>
 int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevParams &p,
             int max_iter, Workspace &w, int64_t capacity, int32_t *d_rec_idx, int32_t *d_rec_slot,
             double *d_rec_vals, int64_t *d_rec_off, int32_t *h_k1, int32_t *h_k2, int64_t *h_counts,
-            hipStream_t st, Timer &tm) {
+            hipStream_t st, Timer &tm, bool device_driven) {
     constexpr int G = 4;
     const int64_t nmodel_pad = pad_models(nmodel);
     const int ntile = (int)(nmodel_pad / TILE);
@@ -491,6 +528,23 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     // ---- float32 pass over the whole grid; K1 where float32 can decide it ----------
     hipLaunchKernelGGL(k_prep32, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.stars,
                        (float)env_double("BRUTUS_EPS_SCALE", 1.0), p.dim_prior, w.s32);
+    // Two drivers for the same kernels.  DEVICE-DRIVEN (default): which stars need the exact K1
+    // probe, which need their float32 planes redone and which iterate on in the flux phase is
+    // decided and listed ON THE DEVICE (k_pre_decide, k_k1_decide, k_fflux_decide), the
+    // follow-up launches are issued unconditionally with a size that fits any list (their
+    // surplus workgroups leave at once), and the host sees the call once, at its end.  What
+    // that cannot express -- a star that needs more than the eight probed sweeps, a flux phase
+    // longer than FLUX_ROUNDS continuations -- raises a flag, and the batch is done again by
+    // the HOST-DRIVEN driver below (round 3's: a host decision after the float32 pass and after
+    // every flux launch; each one idles the stream for a round trip).
+    constexpr int FLUX_ROUNDS = 4;
+    if (device_driven) {
+        HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(int32_t) * 8, st));
+        if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm, 1)) return rc;
+        if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, nullptr, p, max_iter, w, st, tm)) return rc;
+        if (!RVF)       // (pinned Rv: the planes never depend on the sweep count)
+            if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 1, st, tm, 2)) return rc;
+    } else {
     if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm)) return rc;
     HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(status.data(), w.status, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
@@ -501,7 +555,7 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
         if (status[s] == 2) probe.push_back(s);
     }
     if (!probe.empty()) {   // float32 could not decide: exact probe (float64, up to 8 sweeps, then deeper)
-        if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, probe, p, w, st, tm)) return rc;
+        if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, &probe, p, max_iter, w, st, tm)) return rc;
         HIP_TRY(hipMemcpyAsync(k1.data(), w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         for (int s : probe) {
@@ -517,6 +571,7 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     for (int s : redo) kfix[s] = k1[s];
     if (!redo.empty())      // float32 statistics at the state after K1 sweeps
         if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, redo, kfix, p, w, 1, st, tm)) return rc;
+    }
 
     // ---- exact cull threshold ---------------------------------------------------------
     tm.begin("k_top");
@@ -548,13 +603,28 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     int32_t h_unconv = 0;
     int iter = 2;
     std::vector<int32_t> k2s(nstar), act;
+    if (device_driven) {
+        // opening launch + FLUX_ROUNDS continuations; round r's decision counts and lists the
+        // stars that iterate on in w.n_unconv[r & 1] / w.ids, the next launch reads them there
+        for (int r = 0; r <= FLUX_ROUNDS; ++r) {
+            tm.begin(r == 0 ? "k_fflux" : "k_fflux_cont");
+            launch_fflux<NB, RVF>(st, r == 0 ? 0 : -1, grid, nmodel, nmodel_pad, nstar, p, w, rec,
+                                  w.n_unconv + ((r - 1) & 1));
+            tm.end();
+            HIP_TRY(hipMemsetAsync(w.n_unconv + (r & 1), 0, sizeof(int32_t), st));
+            hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
+                               p.ln_sub, w.k2, w.maxsurv, w.n_unconv + (r & 1), w.ids);
+        }
+        HIP_TRY(hipMemcpyAsync(w.n_unconv + 2, w.n_unconv + (FLUX_ROUNDS & 1), sizeof(int32_t),
+                               hipMemcpyDeviceToDevice, st));      // stars still iterating at the end
+    } else
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
         tm.begin(first ? "k_fflux" : "k_fflux_cont");
         launch_fflux<NB, RVF>(st, (int)act.size(), grid, nmodel, nmodel_pad, nstar, p, w, rec);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
-                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv);
+                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv, (int32_t *)nullptr);
         HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(k2s.data(), w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -615,12 +685,24 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
                        w.stars, p, w.k1, w.surv_idx, w.wbase_der, w.items_der, w.surv_off, rec);
     tm.end();
     int64_t h_nder = 0;
+    int32_t h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h_left = 0;
     HIP_TRY(hipMemcpyAsync(&h_counts[0], d_rec_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     HIP_TRY(hipMemcpyAsync(&h_nder, w.der_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
     if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
     if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
+    if (device_driven) {
+        HIP_TRY(hipMemcpyAsync(h_ctr, w.ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(&h_left, w.n_unconv + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    }
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    if (device_driven && h_ncand > capacity) {      // (every write was bounded by the capacity)
+        h_counts[1] = h_ncand;
+        h_counts[2] = h_ncand + (h_nder > 0 ? h_nder : h_ncand);
+        return fail(BRUTUS_ENOMEM, "record buffer too small: %lld candidate slots, capacity %lld",
+                    (long long)h_ncand, (long long)capacity);
+    }
+    if (device_driven && (h_ctr[3] != 0 || h_left != 0)) return BRUTUS_RETRY_HOSTDRIVEN;
     h_counts[1] = h_ncand;
     h_counts[2] = h_ncand + h_nder;
     if (h_counts[2] > capacity)
@@ -1043,14 +1125,29 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
                  int32_t *d_rec_idx, int32_t *d_rec_slot, double *d_rec_vals, int64_t *d_rec_off,
                  int32_t *h_k1, int32_t *h_k2, int64_t *h_counts, hipStream_t st, Timer &tm) {
     const bool rvf = rv_pinned(p);
+    // BRUTUS_FIT_HOSTDRIVEN=1: round 3's driver for every batch (A/B timing, and the tests
+    // that compare the two drivers record for record)
+    const bool hostdriven = env_int("BRUTUS_FIT_HOSTDRIVEN", 0) != 0;
 #define BRUTUS_CASE(N)                                                                             \
-    case N:                                                                                        \
+    case N: {                                                                                      \
+        int rc = hostdriven ? BRUTUS_RETRY_HOSTDRIVEN : 0;                                         \
+        g_fit_calls.fetch_add(1);                                                                  \
+        if (!hostdriven)                                                                           \
+            rc = rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,      \
+                                        d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,  \
+                                        h_counts, st, tm, true)                                    \
+                     : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,     \
+                                         d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2, \
+                                         h_counts, st, tm, true);                                  \
+        if (rc != BRUTUS_RETRY_HOSTDRIVEN) return rc;                                              \
+        if (!hostdriven) g_fit_retries.fetch_add(1);                                               \
         return rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,        \
                                       d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,    \
-                                      h_counts, st, tm)                                            \
+                                      h_counts, st, tm, false)                                     \
                    : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,       \
                                        d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,   \
-                                       h_counts, st, tm);
+                                       h_counts, st, tm, false);                                   \
+    }
     switch (nb) {
         BRUTUS_CASE(12)
 #ifndef BRUTUS_DEV_NB12_ONLY
@@ -1969,6 +2066,12 @@ namespace zig_host {
 #include "zig_table.inc"
 #undef ZIG_TABLE_QUAL
 }   // namespace zig_host
+
+int brutus_debug_fit_stats(int64_t *calls, int64_t *repeated) {
+    if (calls) *calls = g_fit_calls.load();
+    if (repeated) *repeated = g_fit_retries.load();
+    return 0;
+}
 
 int brutus_debug_zig_table(double *h_x, double *h_y, int n) {
     if (!h_x || !h_y || n != zig_host::ZIG_N + 1) return fail(BRUTUS_EINVAL, "bad arguments");

@@ -157,8 +157,13 @@ __global__ void __launch_bounds__(TILE)
 k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
         const int32_t *__restrict__ star_ids, const Star32 *__restrict__ stars, P32 p,
         const int32_t *__restrict__ kfix, int ntile, float *__restrict__ lnlp32,
-        float *__restrict__ lnpr32, float *__restrict__ part) {
+        float *__restrict__ lnpr32, float *__restrict__ part,
+        const int32_t *__restrict__ nrun_dev) {
     __shared__ float slot[4][G * NV32];
+    // (re-run over a star list that was put together on the device: its length lives there
+    // too; the launch is sized for the whole batch and the surplus workgroups leave here)
+    if (nrun_dev) nrun = *nrun_dev;
+    if (nrun <= 0) return;
     const float C10 = -1.32877123795494494f;     // -0.4 log2(10)
     const float NINF = -INFINITY;
     // 1-D launch of 8 * ceil(nchunk / 8) * ngroup workgroups.  Workgroup L runs on XCD L % 8
@@ -415,12 +420,19 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
 // Per-star reduction of the float32 partials and the K1 decision they allow.
 //   status[s] = 0: K1 = k1[s] decided (== kfix used)      1: K1 = 1 decided, planes were
 //   computed after 2 sweeps -> redo k_pre32 with kfix = 1  2: undecided -> exact probe
+// With `ctr` given the follow-up lists are put together here, on the device (no host round
+// trip): status 1 -> kfix[s] = K1 and s appended to redo_ids (count ctr[1]); status 2 -> s
+// appended to probe_ids (count ctr[0]).  `nrun_dev`: the launch covers the whole batch, only
+// the first *nrun_dev entries of star_ids exist.
 __global__ void k_pre_decide(int nblkx, int nstar, const int32_t *__restrict__ star_ids,
                              const float *__restrict__ part, const Star32 *__restrict__ stars,
-                             float ln_init, int rvf, const int32_t *__restrict__ kfix,
+                             float ln_init, int rvf, int32_t *kfix,
                              int accept, float *__restrict__ st32, int32_t *__restrict__ k1,
-                             int32_t *__restrict__ status, double *__restrict__ nomA) {
+                             int32_t *__restrict__ status, double *__restrict__ nomA,
+                             int32_t *ctr, int32_t *__restrict__ probe_ids,
+                             int32_t *__restrict__ redo_ids, const int32_t *nrun_dev) {
     __shared__ float sm[NV32][4];
+    if (nrun_dev && (int)blockIdx.x >= *nrun_dev) return;
     const int s = star_ids[blockIdx.x];
     float v[NV32];
     for (int q = 0; q < NV32; ++q) v[q] = -INFINITY;
@@ -467,6 +479,14 @@ __global__ void k_pre_decide(int nblkx, int nstar, const int32_t *__restrict__ s
     if (!accept) {      // accept: K1 already known exactly (exact probe / redo), stats only
         k1[s] = K1;
         status[s] = st;
+        if (ctr) {
+            if (st == 1) {
+                kfix[s] = K1;
+                redo_ids[atomicAdd(ctr + 1, 1)] = s;
+            } else if (st == 2) {
+                probe_ids[atomicAdd(ctr + 0, 1)] = s;
+            }
+        }
     }
     // nominees for the exact maximum of lnl_p: within 2 eps of the float32 maximum
     nomA[s] = (double)v[6] - 2. * (double)sp.eps;

@@ -332,10 +332,15 @@ template <int NB, int KS, bool RVF>
 __global__ void __launch_bounds__(TILE)
 k_k1probe(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
           const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
-          int tiles_per_block, int ntile, double *__restrict__ part) {
+          int tiles_per_block, int ntile, double *__restrict__ part,
+          const int32_t *__restrict__ nrun_dev) {
     constexpr int NV = 2 * KS;
     __shared__ double slot[4];
-    const int s = star_ids[blockIdx.y];
+    // (nrun_dev: the list and its length were put together on the device; row y of the launch
+    // takes the entries y, y + gridDim.y, ...)
+    if (nrun_dev) nrun = *nrun_dev;
+    for (int y = blockIdx.y; y < nrun; y += gridDim.y) {
+    const int s = star_ids[y];
     const StarPrep &sp = stars[s];
     double mx[NV];
 #pragma unroll
@@ -385,13 +390,19 @@ k_k1probe(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, in
 #pragma unroll
     for (int v = 0; v < NV; ++v)
         block_max_store(mx[v], slot, part + ((int64_t)blockIdx.x * nstar + s) * NV + v);
+    }
 }
 
 // K1 of the probed stars from the partials of k_k1probe (0 = not converged in KS sweeps).
+// With `ctr` given (device-driven call): kfix[s] = K1; a general-Rv star whose K1 is not the 2
+// the float32 planes were computed with joins redo_ids (count ctr[1]); K1 = 0 (more than KS
+// sweeps) or K1 > max_iter raises ctr[3]: the host repeats the batch along its own path.
 __global__ void k_k1_decide(int nblkx, int nstar, const int32_t *__restrict__ star_ids, int KS,
                             const double *__restrict__ part, double ln_init,
-                            int32_t *__restrict__ k1) {
+                            int32_t *__restrict__ k1, const int32_t *nrun_dev, int32_t *kfix,
+                            int32_t *ctr, int32_t *__restrict__ redo_ids, int rvf, int max_iter) {
     __shared__ double sm[KCAP * 2][4];
+    if (nrun_dev && (int)blockIdx.x >= *nrun_dev) return;
     const int s = star_ids[blockIdx.x];
     const int NV = 2 * KS;
     double v[KCAP * 2];
@@ -420,6 +431,14 @@ __global__ void k_k1_decide(int nblkx, int nstar, const int32_t *__restrict__ st
         }
     }
     k1[s] = K1;
+    if (ctr) {
+        if (K1 == 0 || K1 > max_iter) {
+            atomicOr(ctr + 3, 1);
+        } else {
+            kfix[s] = K1;
+            if (!rvf && K1 != 2) redo_ids[atomicAdd(ctr + 1, 1)] = s;
+        }
+    }
 }
 
 // Exclusive scans of per-(star, chunk) counts, one workgroup per job (blockIdx.x):
@@ -615,9 +634,10 @@ struct ItemWalk {
 constexpr int CONT_P = 16;
 struct SegWalk {
     int item, end;
-    __device__ __forceinline__ void init(const int32_t *wbase, int nstar, const int32_t *act, int nact) {
-        const int c = blockIdx.x % NCHUNK, a = (blockIdx.x / NCHUNK) % nact;
-        const int piece = blockIdx.x / (NCHUNK * nact);
+    __device__ __forceinline__ void init(const int32_t *wbase, int nstar, const int32_t *act, int nact,
+                                         int unit) {
+        const int c = unit % NCHUNK, a = (unit / NCHUNK) % nact;
+        const int piece = unit / (NCHUNK * nact);
         const int e = c * nstar + act[a];
         end = wbase[e + 1];
         item = wbase[e] + piece;
@@ -737,7 +757,13 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         const int64_t *__restrict__ cand_off, const int32_t *__restrict__ wbase,
         const ItemGeom *__restrict__ items, RecPlanes rec, double *__restrict__ step_st,
         double *__restrict__ lnprob_st, double *__restrict__ part, float *__restrict__ surv32,
-        const double *__restrict__ thr_cull, const int32_t *__restrict__ act, int nact) {
+        const double *__restrict__ thr_cull, const int32_t *__restrict__ act, int nact,
+        const int32_t *__restrict__ nact_dev) {
+    // continuation launches: the list of stars still iterating and its length may have been
+    // put together on the device (k_fflux_decide); the launch has a fixed size and its
+    // workgroups share the NCHUNK * nact * CONT_P segment pieces in turns
+    if (!FIRST && nact_dev) nact = *nact_dev;
+    if (!FIRST && nact <= 0) return;
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
@@ -756,10 +782,12 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                         *__restrict__ r_scale = rec.plane(2), *__restrict__ r_av = rec.plane(3),
                         *__restrict__ r_rv = rec.plane(4);
     typename std::conditional<FIRST, ItemWalk, SegWalk>::type wk;
+    const int nunit = FIRST ? 1 : NCHUNK * nact * CONT_P;
+    for (int unit = FIRST ? 0 : blockIdx.x; unit < nunit; unit += gridDim.x) {
     if constexpr (FIRST)
         wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
     else
-        wk.init(wbase, nstar, act, nact);
+        wk.init(wbase, nstar, act, nact, unit);
     int32_t i_nxt = lane_model(wk.item);
     while (!wk.done()) {
         const int item = wk.item;
@@ -897,13 +925,16 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             out[2] = M;
         }
     }
+    }
 }
 
-// Per-star flux decision over the star's work items (one workgroup per star).
+// Per-star flux decision over the star's work items (one workgroup per star).  The stars that
+// iterate on are counted in n_unconv and, where `act` is given, listed there (the next
+// continuation launch walks their segments without a host round trip).
 __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
                                const double *__restrict__ part, double ln_sub,
                                int32_t *__restrict__ k2state, double *__restrict__ maxsurv,
-                               int32_t *__restrict__ n_unconv) {
+                               int32_t *__restrict__ n_unconv, int32_t *__restrict__ act) {
     __shared__ double sm[3][4];
     const int s = blockIdx.x;
     if (k2state[s] < 0) return;
@@ -946,7 +977,8 @@ __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
     maxsurv[s] = v[2];
     if (v[1] > v[0] + ln_sub) {      // lerr > ltol (fitting.py:798-799)
         k2state[s] += 1;
-        atomicAdd(n_unconv, 1);
+        const int q = atomicAdd(n_unconv, 1);
+        if (act) act[q] = s;
     } else {
         k2state[s] = -k2state[s] - 1;
     }

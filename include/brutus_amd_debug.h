@@ -40,6 +40,11 @@ int brutus_debug_galprior_mc(const brutus_post_params *params, int n,
                              const double *d_feh, const double *d_loga, double *d_out,
                              void *stream);
 
+/* Measurement aid: brutus_fit_batch calls of this process so far and how many of them had to
+ * be repeated by the host-driven driver (a star with more than eight magnitude sweeps, a flux
+ * phase longer than the device-driven call's continuation rounds).  Needs no GPU. */
+int brutus_debug_fit_stats(int64_t *calls, int64_t *repeated);
+
 /* Measurement aid: out[i] = (double)in[i] for n elements, i.e. exactly 4n bytes
  * read (4 B/lane) and 8n bytes written (8 B/lane) -- the access widths of the
  * fused scan -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be calibrated

@@ -189,6 +189,50 @@ def test_many_sweeps_star_is_not_an_error():
     assert max(k1s) > 8, k1s      # the case the old 8-sweep cap rejected
 
 
+def _fit_stats():
+    import ctypes as C
+    from brutus_amd import _lib
+    a, b = C.c_int64(0), C.c_int64(0)
+    _lib.lib().brutus_debug_fit_stats(C.byref(a), C.byref(b))
+    return a.value, b.value
+
+
+@pytest.mark.parametrize("kw", [dict(), dict(rvlim=(3.32, 3.32)), dict(ltol=1e-3),
+                                dict(rvlim=(3.32, 3.32), ltol=1e-3),
+                                dict(rv_gauss=(3.32, 5.), ltol=3e-3)],
+                         ids=["default", "rv_pinned", "ltol", "rv_pinned_ltol", "many_sweeps"])
+def test_device_driven_call_equals_host_driven_call(kw):
+    """brutus_fit_batch decides its follow-up launches on the device (which stars need the
+    exact K1 probe / their float32 planes redone / further flux iterations) and is seen by
+    the host once, at its end; BRUTUS_FIT_HOSTDRIVEN=1 selects round 3's driver with a host
+    decision after every stage.  Same kernels, same records, bit for bit -- also when the
+    device-driven call has to hand a batch back (a star with more than eight sweeps)."""
+    from brutus_amd import fitting, synth
+    models, _, _ = synth.make_mist_like_grid(60000, 12, seed=8)
+    st = synth.make_stars(models, 48, seed=31)
+    grid = fitting.DeviceGrid(models)
+    params = _params(kw)
+    eng = fitting._Engine(grid, max_batch=48)
+    c0, r0 = _fit_stats()
+    dev = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"], params)
+    c1, r1 = _fit_stats()
+    with _Env(BRUTUS_FIT_HOSTDRIVEN=1):
+        host = eng.fit_batch(st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"], params)
+    assert c1 >= c0 + 1          # (+1 more when the record buffers had to grow)
+    k1 = np.array([r["K1"] for r in host])
+    k2 = np.array([r["K2"] for r in host])
+    # the device-driven call covers K1 <= 8 and K2 <= 6; beyond that the batch is repeated
+    assert (r1 - r0 >= 1) == bool(k1.max() > 8 or k2.max() > 6), (k1.max(), k2.max(), r1 - r0)
+    if "rv_gauss" in kw:
+        assert k1.max() > 8
+    elif "ltol" in kw:
+        assert (k2 > 2).any(), k2               # the continuation rounds were exercised
+    for s, (a, b) in enumerate(zip(dev, host)):
+        assert a["K1"] == b["K1"] and a["K2"] == b["K2"], s
+        for k in ("sel", "lnlike", "chi2", "scale", "av", "rv", "icov"):
+            assert np.array_equal(a[k], b[k]), (s, k)
+
+
 def test_record_buffer_growth():
     """Record buffers too small for a batch -- below the candidate slots, then below
     candidates + derived records: `fit_batch_device` reports BRUTUS_ENOMEM with the sizes it

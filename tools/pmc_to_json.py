@@ -70,7 +70,9 @@ def main():
     rows.append({"kernel": "__total__", "config": config, "batch": batch,
                  "read_bytes_per_launch": round(trd), "write_bytes_per_launch": round(twr),
                  "hbm_bytes_per_launch": round(trd + twr)})
-    json.dump({"commit": os.environ.get("PMC_COMMIT", "unknown"),
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    json.dump({"commit": os.environ.get("PMC_COMMIT", "unknown"), "csrc_sha16": bench.csrc_sha16(),
                "source": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) on "
                          "tools/pmc_workload.py; counters in KiB, corrected with k_calib_stream; bytes per brutus_fit_batch call",
                "fetch_correction": f_fac, "write_correction": w_fac, "rows": rows},
