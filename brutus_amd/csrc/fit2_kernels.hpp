@@ -717,7 +717,10 @@ k_cmp_count32(int64_t nmodel, int ntile, const float *__restrict__ plane,
     const int t0 = (int)((int64_t)ntile * c / NCHUNK), t1 = (int)((int64_t)ntile * (c + 1) / NCHUNK);
     const double th = thr[s];
     int n = 0;
-    constexpr int U = 8;      // tiles in flight per lane (one 4-byte load each: latency-bound otherwise)
+#ifndef CNT_U
+#define CNT_U 16
+#endif
+    constexpr int U = CNT_U;      // tiles in flight per lane (one 4-byte load each: latency-bound otherwise)
     for (int tb = t0; tb < t1; tb += U) {
         float v[U];
 #pragma unroll
@@ -777,7 +780,10 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
     const int64_t cbase = cand_off[s];
     int32_t *queue = bandq + (int64_t)s * nmodel + (int64_t)t0 * TILE;
     int n = 0, nd = 0;
-    constexpr int U = 4;      // tiles in flight per lane
+#ifndef CLS_U
+#define CLS_U 12
+#endif
+    constexpr int U = CLS_U;      // tiles in flight per lane
     for (int tb = t0; tb < t1; tb += U) {
         float v32[U];
 #pragma unroll

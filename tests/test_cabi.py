@@ -55,6 +55,25 @@ def test_library_exports_nothing_outside_its_prefix():
     assert not helpers, helpers[:10]
 
 
+def test_hot_kernels_do_not_spill():
+    """Registers and scratch of the hot kernels as built (tools/kernel_resources.py reads the
+    code object's metadata): the 8- and 12-band instantiations of the scan kernels keep
+    everything in registers.  A spill does not fail anything -- it costs 25 % of a kernel,
+    silently (it happened to k_fflux for one commit of round 4)."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources
+    from brutus_amd import _lib
+    ks = kernel_resources.kernels(_lib.LIB_PATH)
+    hot = [n for n in ks if re.match(r"k_(fflux|derive|pre32|top|sel_band)<(8|12),", n)]
+    assert len(hot) >= 20, sorted(ks)[:10]
+    bad = {n: ks[n] for n in hot if ks[n]["scratch"] != 0 or ks[n]["vgpr"] > 256}
+    assert not bad, bad
+    # occupancy steps the measurements in DESIGN.md rest on: four waves per SIMD for the
+    # float32 pass, two for the float64 list kernels
+    assert ks["k_pre32<12, true, 4>"]["vgpr"] <= 128 and ks["k_pre32<12, false, 4>"]["vgpr"] <= 128
+
+
 def test_abi_version_and_queries():
     from brutus_amd import _lib
     L = _lib.lib()
