@@ -1250,7 +1250,7 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int
     if (int rc = launch_prep(nstar, nfilt, d_flux, d_err, d_mask, d_parallax, d_parallax_err,
                              has_parallax, w, d_ndim, st))
         return rc;
-    const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
+    const int max_iter = params->max_iter > 0 ? params->max_iter : 65536;
     int rc = dispatch_pipeline(padded_nb(nfilt), d_grid_soa, nmodel, nstar, p, max_iter, w, h_k1,
                                h_k2, st, tm, d_av_init, d_rv_init);
     if (rc) return rc;
@@ -1282,7 +1282,7 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
     if (int rc = launch_prep(nstar, nfilt, d_flux, d_err, d_mask, d_parallax, d_parallax_err,
                              has_parallax, w, d_ndim, st))
         return rc;
-    const int max_iter = params->max_iter > 0 ? params->max_iter : 256;
+    const int max_iter = params->max_iter > 0 ? params->max_iter : 65536;
     int rc = dispatch_fit(padded_nb(nfilt), nfilt, d_grid_soa, nmodel, nstar, p, max_iter, w,
                           capacity, d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,
                           h_counts, st, tm);

@@ -76,70 +76,81 @@ __device__ __forceinline__ void gram_sweep(const Gram &G, double S, const DevPar
     logwt = -0.5 * chi2;
 }
 
-// MLE quantities as mle_eval, with F = F0 * 10^(-0.4 av R) through fast_exp10, in ONE pass
-// over the bands (round 4).  fitting.py:526-561 forms the residuals res = d - s F after the
-// scale s is known and sums products of res; written out in moments of (d, F) that do not
-// depend on s -- with u = R F, v = dR F, c = -0.4 ln 10 --
-//   S1 = sum F d / V      S2 = sum F^2 / V                       s = max(S1 / S2, 1e-20)
-//   A1 = sum R F d / V    A2 = sum R F^2 / V    A3 = sum R^2 F^2 / V
-//   B1 = sum dR F d / V   B2 = sum dR F^2 / V   B3 = sum dR^2 F^2 / V   B4 = sum dR F F0 / V
-//   chi2   = D2 - s (2 S1 - s S2)            (D2 = sum d^2 / V, StarPrep)
-//   a_num  = c s (A1 - s A2)                 r_num  = c s (B1 - s B2)
-//   a_den  = (c s)^2 A3                      r_den  = (c s)^2 B3
-//   sa_mix = c (2 s A2 - A1)                 sr_mix = c (2 s B2 - B1)
-//   ar_mix = c s (2 s B2 - B1 - s B4)
-// 11 multiply-adds per band behind the exponential instead of 18 in two loops, and the twelve
-// fluxes need not stay in registers for a second loop.  The differences cancel against sums
-// of the size of D2 = sum (S/N)^2: absolute error ~1e-16 D2 on chi2 (1e-12 at S/N 100 in
-// twelve bands) and ~1e-16 on a step, far inside the 1e-8 the kernels are held to.
+// MLE quantities as mle_eval, with F = F0 * 10^(-0.4 av R) through fast_exp10.
 template <int NB, bool TBL>
 __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[NB],
                                          const StarPrep &sp, const DevParams &p, double av,
                                          double rv, const double *__restrict__ tbl, Mle &o) {
     const double fac = -0.92103403719761827361;
     const double mav = -0.4 * av;
-    double S1 = 0., S2 = 0., A1 = 0., A2 = 0., A3 = 0., B1 = 0., B2 = 0., B3 = 0., B4 = 0.;
+    double F[NB];
+    double s_num = 0., s_den = 0.;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
-        const double D0 = (double)c.dr[j];
-        const double R = fma(rv, D0, (double)c.r0[j]);
+        const double R = (double)c.r0[j] + rv * (double)c.dr[j];
         const double f = F0[j] * (TBL ? fast_exp10(mav * R, tbl) : poly_exp10(mav * R));
-        const double d = sp.d[j];
+        F[j] = f;
         const double fw = f * sp.iV[j];
-        S1 = fma(d, fw, S1);
-        S2 = fma(f, fw, S2);
-        const double Rfw = R * fw, Dfw = D0 * fw;
-        A1 = fma(Rfw, d, A1);
-        B1 = fma(Dfw, d, B1);
-        const double t2 = Rfw * f, t3 = Dfw * f;
-        A2 += t2;
-        B2 += t3;
-        A3 = fma(R, t2, A3);
-        B3 = fma(D0, t3, B3);
-        B4 = fma(Dfw, F0[j], B4);
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
     }
-    double s = S1 / S2;
+    double s = s_num / s_den;
     if (s <= 1e-20) s = 1e-20;
+    // fitting.py:526-561 with the constant factors taken out of the band sums: with
+    // u = R F, v = dR F (unscaled), res = d - s F, t = s F - res = 2 s F - d,
+    //   sa_mix = c sum u t / V           sr_mix = c sum v t / V          (c = -0.4 ln 10)
+    //   a_den = (c s)^2 sum u^2 / V      r_den = (c s)^2 sum v^2 / V
+    //   a_num = c s sum u res / V        r_num = c s sum v res / V
+    //   ar_mix = c s sum v (s (F - F0) - res) / V = c s sum v (t - s F0) / V
+    // 16 operations per band instead of 24; same quantities to rounding (~1e-16).
+    double SA = 0., SR = 0., AR = 0., AA = 0., RR = 0., AN = 0., RN = 0., chi2 = 0.;
+    const double s2 = s + s;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double iv = sp.iV[j];
+        const double D0 = (double)c.dr[j];
+        const double R0 = (double)c.r0[j] + rv * D0;
+        const double u = R0 * F[j], v = D0 * F[j];
+        const double res = fma(-s, F[j], sp.d[j]);
+        const double t = fma(s2, F[j], -sp.d[j]);
+        const double q = fma(-s, F0[j], t);
+        const double rw = res * iv, uw = u * iv, vw = v * iv;
+        chi2 = fma(res, rw, chi2);
+        AN = fma(u, rw, AN);
+        RN = fma(v, rw, RN);
+        AA = fma(u, uw, AA);
+        RR = fma(v, vw, RR);
+        SA = fma(uw, t, SA);
+        SR = fma(vw, t, SR);
+        AR = fma(vw, q, AR);
+    }
     const double cs = fac * s, cs2 = cs * cs;
-    const double SA = fma(s + s, A2, -A1), SR = fma(s + s, B2, -B1);
-    double a_den = cs2 * A3, r_den = cs2 * B3;
+    double a_den = cs2 * AA, r_den = cs2 * RR;
+    const double a_num = cs * AN, r_num = cs * RN;
+    const double sa_mix = fac * SA, sr_mix = fac * SR, ar_mix = cs * AR;
     o.a_ss = a_den;
     o.r_ss = r_den;
-    o.a_num = cs * fma(-s, A2, A1);
-    o.r_num = cs * fma(-s, B2, B1);
+    o.a_num = a_num;
+    o.r_num = r_num;
     a_den += p.av_ivar;
     r_den += p.rv_ivar;
     a_den += p.a_reg;
     r_den += p.r_reg;
     o.scale = s;
-    o.chi2 = fma(-s, fma(-s, S2, S1 + S1), sp.D2);
-    o.i00 = S2;
-    o.i01 = fac * SA;
-    o.i02 = fac * SR;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = sa_mix;
+    o.i02 = sr_mix;
     o.i11 = a_den;
-    o.i12 = cs * fma(-s, B4, SR);
+    o.i12 = ar_mix;
     o.i22 = r_den;
 }
+
+// (Round 4 tried the MLE in ONE pass over the bands -- moments of (d, F) that do not depend on
+// the scale, chi2 = D2 - s (2 S1 - s S2) etc.: 8 % fewer float64 instructions, no flux array
+// held for a second loop -- and dropped it: no measurable gain (k_fflux 1.63 vs 1.62-1.68 ms),
+// and the moments cancel against D2 = sum (S/N)^2, which costs four-band stars with
+// chi2 ~ 1e-3 six digits of ln chi2 (3e-9 relative on lnl instead of 1e-13).)
 
 // ---- pinned Rv (rvlim[0] == rvlim[1] == rv_gauss[0], BASELINE configs[1]) ----
 // The Rv step of every sweep is clamped to zero, so R_j = r0_j + rv dr_j is a
@@ -199,49 +210,61 @@ __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)
                                             const double *__restrict__ tbl, Mle &o) {
     const double fac = -0.92103403719761827361;
     const double mav = -0.4 * av;
-    double S1 = 0., S2 = 0., A1 = 0., A2 = 0., A3 = 0., B1 = 0., B2 = 0., B3 = 0., B4 = 0.;
+    double F[NB];
+    double s_num = 0., s_den = 0.;
 #pragma unroll
     for (int j = 0; j < NB; ++j) {
         const double f = F0[j] * (TBL ? fast_exp10(mav * R[j], tbl) : poly_exp10(mav * R[j]));
-        const double d = sp.d[j];
+        F[j] = f;
         const double fw = f * sp.iV[j];
-        S1 = fma(d, fw, S1);
-        S2 = fma(f, fw, S2);
-        const double Rfw = R[j] * fw;
-        A1 = fma(Rfw, d, A1);
-        const double t2 = Rfw * f;
-        A2 += t2;
-        A3 = fma(R[j], t2, A3);
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    // (sums with the constant factors taken out, see mle_fast)
+    double SA = 0., SR = 0., AR = 0., AA = 0., RR = 0., AN = 0., RN = 0., chi2 = 0.;
+    const double s2 = s + s;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        const double iv = sp.iV[j];
+        const double u = R[j] * F[j];
+        const double res = fma(-s, F[j], sp.d[j]);
+        const double t = fma(s2, F[j], -sp.d[j]);
+        const double rw = res * iv, uw = u * iv;
+        chi2 = fma(res, rw, chi2);
+        AN = fma(u, rw, AN);
+        AA = fma(u, uw, AA);
+        SA = fma(uw, t, SA);
         if (FULL) {
-            const double D0 = (double)c.dr[j];
-            const double Dfw = D0 * fw;
-            B1 = fma(Dfw, d, B1);
-            const double t3 = Dfw * f;
-            B2 += t3;
-            B3 = fma(D0, t3, B3);
-            B4 = fma(Dfw, F0[j], B4);
+            const double v = (double)c.dr[j] * F[j];
+            const double q = fma(-s, F0[j], t);
+            const double vw = v * iv;
+            RN = fma(v, rw, RN);
+            RR = fma(v, vw, RR);
+            SR = fma(vw, t, SR);
+            AR = fma(vw, q, AR);
         }
     }
-    double s = S1 / S2;
-    if (s <= 1e-20) s = 1e-20;
     const double cs = fac * s, cs2 = cs * cs;
-    const double SA = fma(s + s, A2, -A1), SR = fma(s + s, B2, -B1);
-    double a_den = cs2 * A3, r_den = cs2 * B3;
+    double a_den = cs2 * AA, r_den = cs2 * RR;
+    const double a_num = cs * AN, r_num = cs * RN;
+    const double sa_mix = fac * SA, sr_mix = fac * SR, ar_mix = cs * AR;
     o.a_ss = a_den;
     o.r_ss = r_den;
-    o.a_num = cs * fma(-s, A2, A1);
-    o.r_num = cs * fma(-s, B2, B1);
+    o.a_num = a_num;
+    o.r_num = r_num;
     a_den += p.av_ivar;
     r_den += p.rv_ivar;
     a_den += p.a_reg;
     r_den += p.r_reg;
     o.scale = s;
-    o.chi2 = fma(-s, fma(-s, S2, S1 + S1), sp.D2);
-    o.i00 = S2;
-    o.i01 = fac * SA;
-    o.i02 = fac * SR;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = sa_mix;
+    o.i02 = sr_mix;
     o.i11 = a_den;
-    o.i12 = cs * fma(-s, B4, SR);
+    o.i12 = ar_mix;
     o.i22 = r_den;
 }
 
@@ -764,13 +787,10 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     double *__restrict__ r_lnl = rec.plane(0), *__restrict__ r_chi2 = rec.plane(1),
                         *__restrict__ r_scale = rec.plane(2), *__restrict__ r_av = rec.plane(3),
                         *__restrict__ r_rv = rec.plane(4);
-    typename std::conditional<FIRST, ItemWalk, SegWalk>::type wk;
-    const int nunit = FIRST ? 1 : NCHUNK * nact * CONT_P;
-    for (int unit = FIRST ? 0 : blockIdx.x; unit < nunit; unit += gridDim.x) {
-    if constexpr (FIRST)
-        wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
-    else
-        wk.init(wbase, nstar, act, nact, unit);
+    // (the walk as a generic lambda: the opening launch instantiates it once, without the
+    // loop over work units around it -- with the loop in one body the opening kernel's
+    // register allocation went from 248 VGPRs to 256 + 180 bytes of scratch, 1.65 -> 2.2 ms)
+    auto walk = [&](auto &wk) {
     int32_t i_nxt = lane_model(wk.item);
     while (!wk.done()) {
         const int item = wk.item;
@@ -908,6 +928,18 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             out[2] = M;
         }
     }
+    };
+    if constexpr (FIRST) {
+        ItemWalk wk;
+        wk.init(wbase, nstar, blockIdx.x & 7, blockIdx.x >> 3, (gridDim.x + 7 - (blockIdx.x & 7)) >> 3);
+        walk(wk);
+    } else {
+        const int nunit = NCHUNK * nact * CONT_P;
+        for (int unit = blockIdx.x; unit < nunit; unit += gridDim.x) {
+            SegWalk wk;
+            wk.init(wbase, nstar, act, nact, unit);
+            walk(wk);
+        }
     }
 }
 

@@ -59,7 +59,7 @@ typedef struct brutus_params {
     double init_thresh;    /* logl_initthresh                                     */
     double wt_thresh;      /* lnpost first cut; only used by brutus_fit_batch     */
     int32_t dim_prior;     /* logl_dim_prior                                      */
-    int32_t max_iter;      /* safety cap on mag sweeps / flux iterations (0=256)  */
+    int32_t max_iter;      /* safety cap on mag sweeps / flux iterations (0 = 65536: the reference has none) */
 } brutus_params;
 
 int brutus_abi_version(void);

@@ -49,19 +49,34 @@ def test_hip_matches_reference(case):
 
 @pytest.mark.gpu
 def test_hip_config5_size_vs_oracle():
-    """BASELINE configs[4]: 5k objects, 12 bands, 15 x 2000 isochrone table."""
+    """BASELINE configs[4] at its own size -- 5 000 objects, 12 bands, the full 15 x 2 000
+    isochrone table -- against the oracle (reference cluster.py:336-414).  The per-object
+    mixture log-likelihoods are independent of each other (the catalogue only meets in the
+    final sum), so the oracle, whose (Ncmd, Nobj, Nb) temporaries are 1 GB per slice at this
+    size, is evaluated in object chunks of 250 and its chunk totals are added up."""
     from brutus_amd import cluster
     from oracle import brutus_oracle as O
     iso, phot, err, par, perr = make_cluster_data(5000, 12, 5)
     a = cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par,
                                   parallax_err=perr, return_lnls=True)
-    eep = np.linspace(202., 808., 400)     # oracle on a thinner table (memory)
-    b = cluster.isochrone_loglike(THETA, iso, phot, err, parallax=par,
-                                  parallax_err=perr, return_lnls=True, eep_grid=eep)
-    c = O.isochrone_loglike(THETA, iso, phot, err, parallax=par,
-                            parallax_err=perr, return_lnls=True, eep_grid=eep)
-    assert relerr(c[1], b[1]) < 1e-9
     assert np.isfinite(a[0]) and a[1].shape == (5000,)
+    tot, mix = 0., []
+    for lo in range(0, 5000, 250):
+        sl = slice(lo, lo + 250)
+        c = O.isochrone_loglike(THETA, iso, phot[sl], err[sl], parallax=par[sl],
+                                parallax_err=perr[sl], return_lnls=True)
+        tot += c[0]
+        mix.append(c[1])
+    mix = np.concatenate(mix)
+    assert relerr(mix, a[1]) < 1e-9
+    assert abs(a[0] - tot) < 1e-9 * abs(tot)
+    # without the dimensionality prior the outlier term spans the whole catalogue
+    # (cluster.py:304-322), so there a 250-object catalogue of its own is compared
+    sl = slice(1000, 1250)
+    kw = dict(parallax=par[sl], parallax_err=perr[sl], return_lnls=True, dim_prior=False)
+    b = cluster.isochrone_loglike(THETA, iso, phot[sl], err[sl], **kw)
+    c = O.isochrone_loglike(THETA, iso, phot[sl], err[sl], **kw)
+    assert relerr(c[1], b[1]) < 1e-9
 
 
 @pytest.mark.gpu

@@ -150,6 +150,62 @@ def test_high_signal_to_noise_and_sharp_posteriors():
         _vs_full_grid(grid, st, dict(rvlim=rvlim), tol=1e-8, audit_frac=0.5)
 
 
+ADVERSARIAL = [
+    ("sn1e3", 12, dict(frac=1e-3)),
+    ("sn1e4", 12, dict(frac=1e-4)),
+    ("sn1e4_parallax", 12, dict(frac=1e-4, perr=1e-3)),
+    ("four_bands", 12, dict(nkeep=4)),
+    ("four_bands_sn1e3", 12, dict(nkeep=4, frac=1e-3)),
+    ("bands24", 24, dict()),
+    ("bands32_sn1e3", 32, dict(frac=1e-3)),
+    ("faint_30mag", 12, dict(shift=30.)),
+    ("bright_30mag", 12, dict(shift=-30.)),
+    ("avlim_open", 12, dict(kw=dict(avlim=(0., 100.)))),
+    ("avlim_open_sn1e3_pinned", 12, dict(frac=1e-3, kw=dict(avlim=(0., 100.), rvlim=(3.32, 3.32)))),
+    ("negative_flux", 12, dict(neg=True)),
+]
+
+
+@pytest.mark.parametrize("case", ADVERSARIAL, ids=[c[0] for c in ADVERSARIAL])
+def test_float32_proof_bound_adversarial(case):
+    """`Star32::eps` is a formula with hand-picked constants; a model it wrongly "proves"
+    below a threshold would silently drop out of the output.  Shapes chosen against it --
+    photometry at S/N 10^3 - 10^4 (the float32 chi2 cancels against sum (S/N)^2), precise
+    parallaxes, four-band stars, 24 / 32 bands, stars 30 mag fainter / brighter than the
+    grid (scale 1e-12 / 1e12), the Av range wide open, negative fluxes: in every case the
+    run-time audit max|float32 - float64| stays below eps AND the selected sets, K1, K2
+    equal the float64 full-grid pipeline + host cut (`_vs_full_grid` asserts both)."""
+    from brutus_amd import fitting, synth
+    name, nb, o = case
+    models, _, _ = synth.make_mist_like_grid(30000, nb, seed=17)
+    S = 8
+    st = synth.make_stars(models, S, seed=23, min_frac_err=min(0.02, o.get("frac", 0.02)))
+    if "frac" in o:
+        # (the drawn fluxes keep their 2 % scatter about the model: at these errors no model
+        # of a 30k grid fits, chi2 ~ 1e5 - 1e7 and the flux phase runs for hundreds to
+        # thousands of damped iterations, like the reference's uncapped while loop does)
+        st["err"] = o["frac"] * np.abs(st["flux"])
+    if "perr" in o:
+        st["parallax_err"] = np.where(np.isfinite(st["parallax_err"]), o["perr"], np.nan)
+    if "nkeep" in o:
+        rng = np.random.RandomState(6)
+        for i in range(S):
+            st["mask"][i] = False
+            st["mask"][i, rng.choice(nb, size=o["nkeep"], replace=False)] = True
+    if "shift" in o:
+        f = 10. ** (-0.4 * o["shift"])
+        st["flux"] *= f
+        st["err"] *= f
+        st["parallax"] = np.full(S, np.nan)
+        st["parallax_err"] = np.full(S, np.nan)
+    if o.get("neg"):
+        st["flux"][::2, 1] = -np.abs(st["flux"][::2, 1]) * 0.3
+        st["flux"][1::3, 7] = -np.abs(st["flux"][1::3, 7])
+    grid = fitting.DeviceGrid(models)
+    tol = 1e-7 if o.get("frac", 1.) <= 1e-3 else 1e-9     # (chi2 up to 1e9 at S/N 1e4)
+    _vs_full_grid(grid, st, o.get("kw", dict()), tol=tol, audit_frac=1.0)
+
+
 def test_random_order_grid_and_tiny_shapes():
     """A grid without any index locality, and shapes around the tile / chunk sizes."""
     from brutus_amd import fitting, synth

@@ -680,6 +680,7 @@ def test_fit_orion_catalogue_vs_reference_golden():
         if noise:
             exempt.append(i)
     print("objects whose PSD decision is rounding noise in the reference itself:", exempt)
+    assert len(exempt) <= 2, exempt          # (one object of the 1 642 on record: number 17)
 
 
 def test_cabi_error_codes():
