@@ -9,7 +9,7 @@ kernel layout (108 MB at 750k x 12) and of the static prior vector.
 """
 import numpy as np
 
-__all__ = ["shard_range", "broadcast_grid", "broadcast_array", "gather_rows",
+__all__ = ["shard_range", "shard_bounds", "broadcast_grid", "broadcast_array", "gather_rows",
            "fit_sharded"]
 
 
@@ -19,6 +19,18 @@ def shard_range(n, rank, world):
     base, rem = divmod(int(n), int(world))
     lo = rank * base + min(rank, rem)
     return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_bounds(n, world, rank0_share=1.0):
+    """[lo, hi) of every rank.  `rank0_share` < 1 gives rank 0 -- which also receives and
+    writes everybody's rows -- that fraction of an equal share (0: rank 0 only writes);
+    1.0 is `shard_range`."""
+    n, world = int(n), int(world)
+    if world == 1 or rank0_share >= 1.:
+        return [shard_range(n, r, world) for r in range(world)]
+    n0 = int(round(max(0., float(rank0_share)) * n / (world - 1 + max(0., float(rank0_share)))))
+    rest = [shard_range(n - n0, r, world - 1) for r in range(world - 1)]
+    return [(0, n0)] + [(n0 + a, n0 + b) for a, b in rest]
 
 
 def broadcast_grid(grid, nmodel, nfilt, device, src=0):
@@ -75,36 +87,54 @@ def gather_rows(local_rows, dst=0):
 
 
 def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
-                seed0=0, rng="philox", chunk=256, **fit_kwargs):
+                seed0=0, rng="philox", chunk=256, rank0_share=1.0, queue_depth=4, **fit_kwargs):
     """`BruteForce.fit` over all ranks of the default process group.
 
-    Every rank fits the contiguous shard `shard_range(Ndata, rank, world)` on
-    its own GPU (no collective on the data path).  The rows go to rank 0 in
-    bounded pieces: in round k every rank packs its next `chunk` objects into ONE
-    fixed-size byte block -- a structured array with the file's own dtypes
-    (`h5io.ResultsFile.row_dtype`), 18 KB per object at the defaults -- and the blocks
-    are gathered on rank 0 over a gloo SIDE GROUP (`dist.new_group(backend="gloo")`:
-    host memory to host memory; nothing is pickled and nothing passes through RCCL,
-    whose default group would stage pickled bytes in device buffers).  Rank 0 hands the
-    blocks to the asynchronous `ResultsFile` writer at their catalogue positions -- row
-    `lo_r + k * chunk + j`, the mapping of reference fitting.py:1734-1748 -- and nothing
-    else is kept: no rank ever holds more than `chunk` finished rows, rank 0 no more
-    than a few rounds of `world * chunk`, whatever the catalogue size.  With
-    `running_io=True` (default) the file on disk is current up to the last flush, so a
-    crash loses at most the rounds in flight.
+    Every rank fits the contiguous shard `shard_bounds(Ndata, world, rank0_share)[rank]` on
+    its own GPU (no collective on the data path) and hands its finished rows to rank 0 in
+    bounded pieces, WITHOUT the ranks ever waiting for each other's fits:
+
+    * the fit (`BruteForce._fit`, this thread) packs every `chunk` finished objects into one
+      block -- a structured array with the file's own dtypes (`h5io.ResultsFile.row_dtype`,
+      18 KB per object at the defaults) -- and puts it into a bounded queue
+      (`queue_depth` blocks: the only back-pressure is a writer slower than the fits);
+    * a hand-off thread per rank drains that queue over a gloo SIDE GROUP
+      (`dist.new_group(backend="gloo")`: host memory to host memory, nothing is pickled and
+      nothing passes through RCCL): a round is one tiny `all_gather` of headers
+      `(rows, first row, done, failed)` followed by point-to-point sends of exactly the
+      rows that are ready -- a rank with nothing ready sends nothing and holds nobody up,
+      so rank 0's shard, its unpacking and the writer's thread no longer sit in every other
+      rank's critical path (round 3 gathered fixed blocks in lock-step from the fit loop);
+    * rank 0's hand-off thread gives the blocks to the asynchronous `ResultsFile` writer at
+      their catalogue positions -- row `lo_r + ...`, the mapping of reference
+      fitting.py:1734-1748.  No rank holds more than `queue_depth * chunk` finished rows,
+      rank 0 no more than a round of `world * chunk` on top, whatever the catalogue size.
+
+    A failure anywhere -- a fit, the writer (its errors are sticky), a hand-off -- is
+    announced in the next round's headers; every rank then stops its generator and raises,
+    none is left waiting in a collective.  The side group is destroyed on the way out.
+
+    With `running_io=True` (default) the file on disk is current up to the last flush and
+    `model_idx` is the last dataset of a block to be written, so a crash leaves the rows in
+    flight unfitted (-99), never half-written.
 
     Object `i` draws from its own stream keyed `seed0 + i`, so the file is
     identical for any number of ranks (the reference's single sequential
     stream, fitting.py:2039-2053, would make results depend on the sharding):
     `rng="philox"` (default) uses `rng.PhiloxRandomState(seed0 + i)`, which
     lets `lnpost` run on the GPU for the built-in priors; `rng="numpy"` uses
-    `numpy.random.RandomState(seed0 + i)` and the host stage (optionally
-    spread over `bf.host_workers` processes).
+    `numpy.random.RandomState(seed0 + i)` (device `lnpost` as well; the host stage,
+    optionally spread over `bf.host_workers` processes, for user prior hooks).
 
     `fit_kwargs` are `BruteForce.fit` keyword arguments (`lnprior_ext` arrays
     are sliced to each rank's shard; `resume` is not supported here).  Returns
-    the number of objects this rank fitted.
+    the number of objects this rank fitted; `fit_sharded.last_stats` holds this rank's
+    timings (`fit_s`: until its last row was packed, `total_s`).
     """
+    import queue
+    import threading
+    import time
+    import torch
     import torch.distributed as dist
     from . import h5io
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -129,7 +159,8 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
      lndustprior, av_gauss, wt_thresh, _) = bf._setup(
         data, data_err, data_mask, data_labels, **skw)
     Ndata = data.shape[0]
-    lo, hi = shard_range(Ndata, rank, world)
+    bounds = shard_bounds(Ndata, world, rank0_share)
+    lo, hi = bounds[rank]
     fkw = {k: v for k, v in kw.items()
            if k not in ("phot_offsets", "apply_agewt", "apply_grad", "mag_max",
                         "merr_max", "parallax", "parallax_err", "data_coords",
@@ -142,7 +173,8 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         fkw["lnprior_ext"] = {k: np.asarray(v)[lo:hi] for k, v in lnprior_ext.items()}
     par = kw.get("parallax")
     perr = kw.get("parallax_err")
-    gen = bf._fit(
+    t_start = time.time()
+    gen = iter(()) if hi == lo else bf._fit(
         data[lo:hi], data_err[lo:hi], data_mask[lo:hi],
         parallax=None if par is None else np.asarray(par)[lo:hi],
         parallax_err=None if perr is None else np.asarray(perr)[lo:hi],
@@ -151,53 +183,138 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
         Ndraws=Ndraws, return_distreds=save_dar_draws,
         seed0=seed0 + lo,
         rstate_per_object="philox" if rng == "philox" else None, **fkw)
-    bounds = [shard_range(Ndata, r, world) for r in range(world)]
-    nround = (max(b - a for a, b in bounds) + chunk - 1) // chunk
-    import torch
     out = None
     if rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
                                data_labels, save_dar_draws,
                                running_io=running_io)
     rowdt, positions = h5io.ResultsFile.row_dtype(Ndraws, save_dar_draws)
+    rowbytes = rowdt.itemsize
     side = dist.new_group(backend="gloo") if world > 1 else None     # host-to-host hand-off
-    nbytes = 8 + chunk * rowdt.itemsize
-    try:
-        for k in range(nround):
-            # this rank's next piece (may be empty), packed: [count i64][chunk rows]
-            block = np.zeros(nbytes, dtype=np.uint8)
-            rows = block[8:].view(rowdt)
-            n = 0
-            with np.errstate(over="ignore"):
-                for n in range(chunk + 1):
-                    if n == chunk:
-                        break
+    q = queue.Queue(maxsize=max(1, int(queue_depth)))
+    abort = threading.Event()
+    failure = {"local": None, "remote": None}
+
+    def hand_off():
+        """Drains the queue: header round, then the rows that are ready (see above)."""
+        done = False
+        try:
+            while True:
+                item = None
+                if not done and failure["local"] is None:
                     try:
-                        res = next(gen)
-                    except StopIteration:
-                        break
-                    for name, pos in positions:
-                        rows[name][n] = res[pos]
-            block[:8].view(np.int64)[0] = n
-            if world == 1:
-                parts = [block]
-            else:
-                mine = torch.from_numpy(block)
-                got = ([torch.empty(nbytes, dtype=torch.uint8) for _ in range(world)]
-                       if rank == 0 else None)
-                dist.gather(mine, got, dst=0, group=side)
-                parts = [g.numpy() for g in got] if rank == 0 else ()
-            if rank == 0:
-                for r, part in enumerate(parts):
-                    cnt = int(part[:8].view(np.int64)[0])
-                    if cnt:
-                        prow = part[8:].view(rowdt)[:cnt]
-                        out.write_block(bounds[r][0] + k * chunk,
-                                        {name: prow[name] for name, _ in positions})
+                        item = q.get(timeout=0.02)
+                    except queue.Empty:
+                        pass
+                n, start, block = 0, 0, None
+                if item is not None:
+                    if item[0] == "rows":
+                        _, start, n, block = item
+                    elif item[0] == "done":
+                        done = True
+                    else:
+                        failure["local"] = failure["local"] or RuntimeError(item[1])
+                hdr = torch.tensor([n, start, 1 if done else 0,
+                                    0 if failure["local"] is None else 1], dtype=torch.int64)
+                if world > 1:
+                    hdrs = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
+                    dist.all_gather(hdrs, hdr, group=side)
+                    hdrs = torch.stack(hdrs).numpy()
+                else:
+                    hdrs = hdr.numpy()[None, :]
+                bad = np.flatnonzero(hdrs[:, 3])
+                if bad.size:
+                    if failure["local"] is None:
+                        failure["remote"] = RuntimeError(
+                            "fit_sharded: rank(s) %s failed; this rank stops too"
+                            % ", ".join(str(int(b)) for b in bad))
+                    return
+                try:
+                    if rank == 0:
+                        got = []
+                        for r in range(world):       # every payload is received before any is
+                            nr = int(hdrs[r, 0])     # written: a failing write strands no sender
+                            if nr == 0:
+                                continue
+                            if r == 0:
+                                rows = block[:nr]
+                            else:
+                                buf = torch.empty(nr * rowbytes, dtype=torch.uint8)
+                                dist.recv(buf, src=r, group=side)
+                                rows = buf.numpy().view(rowdt)
+                            got.append((int(hdrs[r, 1]), rows))
+                        for first, rows in got:
+                            out.write_block(first, {name: rows[name] for name, _ in positions})
+                    elif n:
+                        dist.send(torch.from_numpy(block[:n].view(np.uint8).reshape(-1)), dst=0,
+                                  group=side)
+                except BaseException as e:           # announced in the next round's headers
+                    failure["local"] = e
+                    continue
+                if np.all(hdrs[:, 2] == 1) and not np.any(hdrs[:, 0]):
+                    return
+        except BaseException as e:                   # the collective itself failed
+            failure["local"] = failure["local"] or e
+        finally:
+            if failure["local"] is not None or failure["remote"] is not None:
+                abort.set()
+
+    def put(item):
+        while True:
+            if abort.is_set():
+                raise failure["remote"] or failure["local"] or RuntimeError("fit_sharded aborted")
+            try:
+                q.put(item, timeout=0.05)
+                return
+            except queue.Full:
+                continue
+
+    th = threading.Thread(target=hand_off, name="brutus-shard-handoff", daemon=True)
+    th.start()
+    fit_error = None
+    t_fit = None
+    try:
+        try:
+            start = lo
+            exhausted = False
+            while not exhausted:
+                block = np.zeros(chunk, dtype=rowdt)
+                n = 0
+                with np.errstate(over="ignore"):
+                    while n < chunk:
+                        try:
+                            res = next(gen)
+                        except StopIteration:
+                            exhausted = True
+                            break
+                        for name, pos in positions:
+                            block[name][n] = res[pos]
+                        n += 1
+                if n:
+                    put(("rows", start, n, block))
+                    start += n
+            t_fit = time.time() - t_start
+            put(("done",))
+        except BaseException as e:
+            fit_error = e
+            if not abort.is_set():                   # tell the others, whatever the queue holds
+                failure["local"] = failure["local"] or e
+        th.join()
     finally:
         if hasattr(gen, "close"):
             gen.close()                     # shuts the scan-ahead helper thread down
+        close_error = None
         if out is not None:
-            out.close()
+            try:
+                out.close()
+            except BaseException as e:      # (sticky writer error: reported below)
+                close_error = e
+        if side is not None:
+            dist.destroy_process_group(side)
+    err = fit_error or failure["local"] or failure["remote"] or close_error
+    if err is not None:
+        raise err
+    fit_sharded.last_stats = {"fit_s": t_fit, "total_s": time.time() - t_start,
+                              "objects": hi - lo}
     dist.barrier()
     return hi - lo

@@ -1,4 +1,4 @@
-"""`parallel.fit_sharded` with the real kernels: two and three ranks (all on
+"""`parallel.fit_sharded` with the real kernels: two, three and four ranks (all on
 cuda:0 over gloo -- RCCL refuses two ranks on one device -- so that it runs on
 a one-GPU box) must produce the file an unsharded run produces."""
 import os
@@ -20,7 +20,7 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("world", [2, 3, 4])
 def test_fit_sharded_equals_unsharded(world):
     env = dict(os.environ, BRUTUS_BENCH_ONE_DEVICE="1", BRUTUS_BENCH_BACKEND="gloo",
                MASTER_ADDR="127.0.0.1")
