@@ -537,7 +537,7 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     // longer than FLUX_ROUNDS continuations -- raises a flag, and the batch is done again by
     // the HOST-DRIVEN driver below (round 3's: a host decision after the float32 pass and after
     // every flux launch; each one idles the stream for a round trip).
-    constexpr int FLUX_ROUNDS = 4;
+    const int FLUX_ROUNDS = env_int("BRUTUS_FLUX_ROUNDS", 4);       // (development switch)
     if (device_driven) {
         HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(int32_t) * 8, st));
         if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm, 1)) return rc;
@@ -2127,8 +2127,10 @@ int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *
 
 int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes, void *stream) {
     if (!d_in || !d_out || nbytes < 16 || (nbytes & 15)) return fail(BRUTUS_EINVAL, "bad calibration arguments");
-    hipLaunchKernelGGL(k_calib_copy16, dim3(8192), dim3(TILE), 0, (hipStream_t)stream,
-                       (const float4 *)d_in, (float4 *)d_out, nbytes / 16);
+    const int64_t n = nbytes / 16;
+    if ((n + TILE - 1) / TILE > 0x7fffffff) return fail(BRUTUS_EINVAL, "calibration buffer too large");
+    hipLaunchKernelGGL(k_calib_copy16, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(TILE), 0,
+                       (hipStream_t)stream, (const calib_f4 *)d_in, (calib_f4 *)d_out, n);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -573,15 +573,12 @@ k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ns
       const float *__restrict__ part32, double *__restrict__ part, float *__restrict__ aud) {
     __shared__ double slot[4][G];
     __shared__ double s_tbl[64];
-    stage_exp_table(s_tbl);
-    __syncthreads();
     const int g0 = blockIdx.y * G;
     const int ng = min(G, nrun - g0);
     const int t0 = blockIdx.x * F2_T;
     const int t1 = min(ntile, t0 + F2_T);
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (lane < G) slot[wv][lane] = -INFINITY;      // wave-private row: no barrier needed
     bool hot[G];
     bool anyhot = false;
 #pragma unroll
@@ -594,6 +591,15 @@ k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ns
             anyhot = anyhot || hot[g];
         }
     }
+    // (all but a few per cent of the workgroups end here: before the table staging, its
+    // barrier and everything else -- a launch is ~12 000 workgroups for some hundred hot ones)
+    if (!anyhot) {
+        if ((int)threadIdx.x < ng) part[(int64_t)blockIdx.x * nstar + star_ids[g0 + threadIdx.x]] = -INFINITY;
+        return;
+    }
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    if (lane < G) slot[wv][lane] = -INFINITY;      // wave-private row: no barrier needed
     // nominee masks of the block's tiles for its hot stars: all float32 values are requested
     // first (clamped addresses, no guards: every load of the batch is in flight at once;
     // one guarded load per (tile, star) made each a round trip of its own), the masks wait

@@ -513,11 +513,15 @@ __global__ void k_calib_stream(const float *__restrict__ in, double *__restrict_
         out[i] = (double)in[i];
 }
 
-// the guide's reference stream: 16 B per lane in, 16 B per lane out
-__global__ void k_calib_copy16(const float4 *__restrict__ in, float4 *__restrict__ out, int64_t n) {
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-         i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = in[i];
+// the guide's reference stream: 16 B per lane in, 16 B per lane out.  One element per lane,
+// workgroups in address order, non-temporal accesses: the shape that reaches the guide's
+// 6.3 TB/s on this pool (profiles/r04_stream_sweep.txt: 6.1 - 6.5 TB/s; the grid-stride loop
+// over 8 192 workgroups that rounds 1-3 measured with reaches 4.5 - 5.0 with the same bytes).
+typedef float calib_f4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(TILE)
+k_calib_copy16(const calib_f4 *__restrict__ in, calib_f4 *__restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * TILE + threadIdx.x;
+    if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
 __global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__ y, int64_t n) {
