@@ -174,9 +174,10 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     L = _lib.lib()
 
     # ---- per-object terms that move with theta (cluster.py:292-325) ---------------
-    chi2_p = np.zeros(Nobjs)
     if ds.pmask is not None:
-        chi2_p[ds.pmask] = (ds.par[ds.pmask] - 1e3 / dist) ** 2 * ds.par_ivar[ds.pmask]
+        chi2_p = (ds.par0 - 1e3 / dist) ** 2 * ds.ivar0
+    else:
+        chi2_p = np.zeros(Nobjs)
     ln_fin = np.log(cluster_prob * (1. - fout))
     ln_fout = np.log(1. - cluster_prob * (1. - fout))
 
@@ -230,10 +231,14 @@ class _Dataset(object):
 def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
     from scipy.stats import chi2 as chisquare
     from .fitting import _torch
-    # the reference's data check comes before anything touches the device (cluster.py:296)
-    if np.any(np.sum(np.isfinite(phot) & np.isfinite(err), axis=1) == 0):
-        raise ValueError("At least one object has no valid data entries!")
-    torch_ = _torch()
+    def check():    # the reference's data check comes before anything is computed (cluster.py:296)
+        if np.any(np.sum(np.isfinite(phot) & np.isfinite(err), axis=1) == 0):
+            raise ValueError("At least one object has no valid data entries!")
+    try:
+        torch_ = _torch()
+    except Exception:
+        check()     # (no GPU: the argument error still comes first)
+        raise
     # (the RESOLVED device: `device=None` follows the current device of each call)
     dev_key = str(torch_.device(device if device is not None
                                 else "cuda:%d" % torch_.cuda.current_device()))
@@ -241,8 +246,9 @@ def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
            _fingerprint(parallax_err), bool(dim_prior), dev_key)
     if cache:
         ds = _lru_get(_DATA_CACHE, key)
-        if ds is not None:
+        if ds is not None:          # (a cached catalogue passed the check below when it came in)
             return ds
+    check()
     Nobjs = phot.shape[0]
     ds = _Dataset()
     ds.phot_mask = np.isfinite(phot) & np.isfinite(err)
@@ -259,6 +265,9 @@ def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
         ds.pmask = np.isfinite(ds.par) & np.isfinite(perr)
         with np.errstate(all="ignore"):
             ds.par_ivar = 1. / perr ** 2
+            # (zeros where there is no parallax: the per-call term needs no masked indexing)
+            ds.par0 = np.where(ds.pmask, ds.par, 0.)
+            ds.ivar0 = np.where(ds.pmask, ds.par_ivar, 0.)
             ds.lnorm_p[ds.pmask] = np.log(2. * np.pi * perr[ds.pmask] ** 2)
         phot_n = phot_n + ds.pmask
     with warnings.catch_warnings(), np.errstate(all="ignore"):
