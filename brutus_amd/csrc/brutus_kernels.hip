@@ -30,7 +30,8 @@
 // turns the masked max-step test (fitting.py:246-264) into two plain maxima.
 
 #include <hip/hip_runtime.h>
-#include <hipcub/hipcub.hpp>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_segmented_radix_sort.hpp>
 #include <math.h>
 #include <stdarg.h>
 #include <stdint.h>
@@ -40,6 +41,7 @@
 #include <stdlib.h>
 
 #include <atomic>
+#include <map>
 #include <mutex>
 #include <string>
 #include <type_traits>
@@ -1386,7 +1388,7 @@ int brutus_offsets_weights(int nobj, int nsamps, int nfilt, int64_t nmodel, cons
 }
 
 namespace {
-// [vals | sorted | segment offsets | hipCUB scratch]
+// [vals | sorted | segment offsets | rocPRIM scratch]
 struct OffsetsWs {
     double *vals, *sorted;
     int32_t *seg;
@@ -1404,9 +1406,9 @@ static int carve_offsets(char *base, int n, int nmc, OffsetsWs &w) {
     off += align_up(sizeof(int32_t) * ((size_t)nmc + 1));
     w.tmp = base + off;
     w.tmp_bytes = 0;
-    hipError_t e = hipcub::DeviceSegmentedRadixSort::SortKeys(
-        nullptr, w.tmp_bytes, (const double *)nullptr, (double *)nullptr, (int)nv, nmc,
-        (const int32_t *)nullptr, (const int32_t *)nullptr);
+    hipError_t e = rocprim::segmented_radix_sort_keys(
+        nullptr, w.tmp_bytes, (const double *)nullptr, (double *)nullptr, (unsigned int)nv,
+        (unsigned int)nmc, (const int32_t *)nullptr, (const int32_t *)nullptr);
     if (e != hipSuccess) return -1;
     off += align_up(w.tmp_bytes);
     w.bytes = off;
@@ -1432,7 +1434,7 @@ int brutus_offsets_bootstrap(int band, int nobj, int nsamps, int nfilt, int n, i
     if (!d_subset || !d_cdf_obj || !d_u || !d_flux || !d_cdf || !d_phot || !d_workspace || !d_meds)
         return fail(BRUTUS_EINVAL, "NULL device pointer");
     OffsetsWs w;
-    if (carve_offsets((char *)d_workspace, n, nmc, w)) return fail(BRUTUS_EHIP, "hipCUB sizing failed");
+    if (carve_offsets((char *)d_workspace, n, nmc, w)) return fail(BRUTUS_EHIP, "rocPRIM sizing failed");
     if (workspace_bytes < w.bytes) return fail(BRUTUS_ENOMEM, "photometric-offset workspace too small");
     hipStream_t st = (hipStream_t)stream;
     const int64_t nv = (int64_t)n * nmc;
@@ -1440,9 +1442,9 @@ int brutus_offsets_bootstrap(int band, int nobj, int nsamps, int nfilt, int n, i
     hipLaunchKernelGGL(k_po_boot, dim3((unsigned)((nv + PO_T - 1) / PO_T)), dim3(PO_T), 0, st, band,
                        nobj, nsamps, nfilt, n, nmc, d_subset, d_cdf_obj, d_u, d_flux, d_cdf, d_phot,
                        w.vals);
-    HIP_TRY(hipcub::DeviceSegmentedRadixSort::SortKeys(w.tmp, w.tmp_bytes, (const double *)w.vals,
-                                                       w.sorted, (int)nv, nmc, w.seg, w.seg + 1, 0,
-                                                       64, st));
+    HIP_TRY(rocprim::segmented_radix_sort_keys(w.tmp, w.tmp_bytes, (const double *)w.vals, w.sorted,
+                                               (unsigned int)nv, (unsigned int)nmc, w.seg, w.seg + 1,
+                                               0, 64, st));
     hipLaunchKernelGGL(k_po_median, dim3((nmc + 255) / 256), dim3(256), 0, st, n, nmc, w.sorted,
                        d_meds);
     HIP_TRY(hipGetLastError());
@@ -1538,12 +1540,12 @@ static int clip_to_nsel_max(PostWs &w, int64_t cap, int64_t a, int64_t n, int64_
     const unsigned nb = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_iota32, dim3(nb), dim3(256), 0, st, w.sort_in, n);
     size_t need = 0;
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(nullptr, need, w.rp.lnp + a, w.sort_keys,
-                                                         w.sort_in, w.sort_perm, (int)n, 0, 64, st));
+    HIP_TRY(rocprim::radix_sort_pairs_desc(nullptr, need, w.rp.lnp + a, w.sort_keys, w.sort_in,
+                                           w.sort_perm, (size_t)n, 0, 64, st));
     if (need > w.sort_tmp_bytes)
         return fail(BRUTUS_ENOMEM, "radix-sort scratch too small (%zu > %zu)", need, w.sort_tmp_bytes);
-    HIP_TRY(hipcub::DeviceRadixSort::SortPairsDescending(w.sort_tmp, need, w.rp.lnp + a, w.sort_keys,
-                                                         w.sort_in, w.sort_perm, (int)n, 0, 64, st));
+    HIP_TRY(rocprim::radix_sort_pairs_desc(w.sort_tmp, need, w.rp.lnp + a, w.sort_keys, w.sort_in,
+                                           w.sort_perm, (size_t)n, 0, 64, st));
     const unsigned kb = (unsigned)((keep + 255) / 256);
     // permute every per-record array through the (now free) lnp1-sized scratch
     double *tmp = w.lnp1;

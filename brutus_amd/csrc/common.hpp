@@ -127,6 +127,63 @@ __device__ __forceinline__ void block_max_store3(double a, double b, double c, d
     __syncthreads();
 }
 
+// ---------------------------------------------------------------------------
+// wave64 / workgroup prefix sums on the DPP data path (no LDS inside a wave)
+// ---------------------------------------------------------------------------
+// One step of a wave-wide inclusive scan: v + (v of the lane `ctrl` names), lanes the DPP
+// pattern leaves without a source add 0.  gfx9 DPP controls: row_shr:n = 0x110 + n (within
+// rows of 16 lanes), row_bcast:15 = 0x142 (lane 15 of a row to the next row, row mask 0xa),
+// row_bcast:31 = 0x143 (lane 31 to rows 2 and 3, row mask 0xc).
+template <int CTRL, int ROWMASK>
+__device__ __forceinline__ int dpp_i32(int x) {
+    return __builtin_amdgcn_update_dpp(0, x, CTRL, ROWMASK, 0xf, false);
+}
+template <class T, int CTRL, int ROWMASK>
+__device__ __forceinline__ T dpp_take(T v) {
+    static_assert(sizeof(T) == 4 || sizeof(T) == 8, "32- or 64-bit values");
+    if constexpr (sizeof(T) == 4) {
+        const int r = dpp_i32<CTRL, ROWMASK>(__builtin_bit_cast(int, v));
+        return __builtin_bit_cast(T, r);
+    } else {
+        const long long b = __builtin_bit_cast(long long, v);
+        const int lo = dpp_i32<CTRL, ROWMASK>((int)b), hi = dpp_i32<CTRL, ROWMASK>((int)(b >> 32));
+        const long long r = ((long long)hi << 32) | (unsigned int)lo;
+        return __builtin_bit_cast(T, r);      // (all-zero bits = 0 for integers and for +0.0)
+    }
+}
+template <class T>
+__device__ __forceinline__ T wave_inclusive_sum(T v) {
+    v += dpp_take<T, 0x111, 0xf>(v);
+    v += dpp_take<T, 0x112, 0xf>(v);
+    v += dpp_take<T, 0x114, 0xf>(v);
+    v += dpp_take<T, 0x118, 0xf>(v);
+    v += dpp_take<T, 0x142, 0xa>(v);
+    v += dpp_take<T, 0x143, 0xc>(v);
+    return v;
+}
+// Exclusive prefix sum over a workgroup of NT threads (NT / 64 waves); `slot` is LDS scratch
+// of NT / 64 + 1 values.  Returns this thread's exclusive prefix, `total` = the sum over the
+// workgroup.  Two barriers; `slot` may be reused after the call returns on every thread of
+// the NEXT call's first barrier (callers in a loop are safe: the second barrier here orders it).
+template <class T, int NT>
+__device__ __forceinline__ T block_exclusive_sum(T v, T *slot, T &total) {
+    constexpr int NW = NT / 64;
+    const T inc = wave_inclusive_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();                       // (slot free: everybody is past the previous use)
+    if (lane == 63) slot[w] = inc;
+    __syncthreads();
+    T pre = T(0), tot = T(0);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const T x = slot[q];
+        if (q < w) pre += x;
+        tot += x;
+    }
+    total = tot;
+    return pre + (inc - v);
+}
+
 template <int NB>
 struct Coef {
     float m[NB], r0[NB], dr[NB];

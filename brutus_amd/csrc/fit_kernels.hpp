@@ -466,12 +466,8 @@ __global__ void __launch_bounds__(BRUTUS_MAX_BATCH)
 k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
     constexpr int NT = BRUTUS_MAX_BATCH;
     constexpr int EPT = NCHUNK;                       // entries per lane at the full batch
-    typedef hipcub::BlockScan<int64_t, NT> Scan64;
-    typedef hipcub::BlockScan<int32_t, NT> Scan32;
-    __shared__ union {
-        typename Scan64::TempStorage a;
-        typename Scan32::TempStorage b;
-    } tmp;
+    __shared__ int64_t s_slot64[NT / 64 + 1];
+    __shared__ int32_t s_slot32[NT / 64 + 1];
     const OffsetsJob job = blockIdx.x == 0 ? job0 : job1;
     const int64_t *__restrict__ counts = job.counts;
     const int total = nstar * NCHUNK;
@@ -485,8 +481,8 @@ k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
             r[k] = k < ept && e0 + k < total ? counts[e0 + k] : 0;
             sum += r[k];
         }
-        int64_t pre, all;
-        Scan64(tmp.a).ExclusiveSum(sum, pre, all);
+        int64_t all;
+        int64_t pre = block_exclusive_sum<int64_t, NT>(sum, s_slot64, all);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             if (k < ept && e0 + k < total) {
@@ -509,8 +505,8 @@ k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
             r[k] = k < ept && e < total ? (int32_t)((counts[(int64_t)q * NCHUNK + c] + TILE - 1) / TILE) : 0;
             sum += r[k];
         }
-        int32_t pre, all;
-        Scan32(tmp.b).ExclusiveSum(sum, pre, all);
+        int32_t all;
+        int32_t pre = block_exclusive_sum<int32_t, NT>(sum, s_slot32, all);
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
             if (k < ept && e0 + k < total) job.wbase[e0 + k] = pre;
@@ -528,8 +524,7 @@ __global__ void __launch_bounds__(TILE)
 k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ mask,
               const int64_t *__restrict__ offsets, int64_t capacity,
               int32_t *__restrict__ out_idx) {
-    typedef hipcub::BlockScan<int, TILE> Scan;
-    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ int s_slot[TILE / 64 + 1];
     __shared__ unsigned long long s_word[TILE];
     __shared__ int s_pre[TILE];
     const int s = blockIdx.y, c = blockIdx.x;
@@ -542,8 +537,8 @@ k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ 
         const int nt = min(TILE / 4, t1 - tb);
         const unsigned long long word =
             (int)threadIdx.x < 4 * nt ? row[(int64_t)tb * 4 + threadIdx.x] : 0ull;
-        int pre, tot;
-        Scan(s_scan).ExclusiveSum(__popcll(word), pre, tot);
+        int tot;
+        const int pre = block_exclusive_sum<int, TILE>(__popcll(word), s_slot, tot);
         s_word[threadIdx.x] = word;
         s_pre[threadIdx.x] = pre;
         __syncthreads();
@@ -1018,8 +1013,7 @@ k_rec_index(int64_t nmodel, int ntile, int nstar, const unsigned long long *__re
             const int64_t *__restrict__ cand_off, int64_t capacity,
             int32_t *__restrict__ rec_idx, int32_t *__restrict__ rec_slot,
             int32_t *__restrict__ der_idx) {
-    typedef hipcub::BlockScan<unsigned long long, TILE> Scan;
-    __shared__ typename Scan::TempStorage s_scan;
+    __shared__ unsigned long long s_slot[TILE / 64 + 1];
     __shared__ unsigned long long s_word[3][TILE];
     __shared__ unsigned long long s_pre[TILE];
     const int s = blockIdx.y, c = blockIdx.x;
@@ -1037,11 +1031,11 @@ k_rec_index(int64_t nmodel, int ntile, int nstar, const unsigned long long *__re
         const int64_t a = row + (int64_t)tb * 4 + (in ? threadIdx.x : 0);
         unsigned long long wm = mask[a], wd = dmask[a], wc = cmask[a];
         if (!in) wm = wd = wc = 0ull;
-        unsigned long long pre, tot;
-        Scan(s_scan).ExclusiveSum((unsigned long long)__popcll(wm) |
-                                      ((unsigned long long)__popcll(wd) << 20) |
-                                      ((unsigned long long)__popcll(wc) << 40),
-                                  pre, tot);
+        unsigned long long tot;
+        const unsigned long long pre = block_exclusive_sum<unsigned long long, TILE>(
+            (unsigned long long)__popcll(wm) | ((unsigned long long)__popcll(wd) << 20) |
+                ((unsigned long long)__popcll(wc) << 40),
+            s_slot, tot);
         s_word[0][threadIdx.x] = wm;
         s_word[1][threadIdx.x] = wd;
         s_word[2][threadIdx.x] = wc;

@@ -15,7 +15,7 @@
 //   k_po_flux    lane = (object, draw): flux of all bands, leave-one-out ln-likelihoods
 //   k_po_cdf     workgroup = (object, band): normalised cumulative weights
 //   k_po_boot    lane = (round, slot): two binary searches, one ratio
-//   segmented radix sort of the rounds (hipCUB) + k_po_median
+//   segmented radix sort of the rounds (rocPRIM) + k_po_median
 #pragma once
 
 namespace {
@@ -83,10 +83,8 @@ __global__ void __launch_bounds__(PO_T)
 k_po_cdf(int nobj, int nsamps, const double *__restrict__ weights,
          const uint8_t *__restrict__ use, const uint8_t *__restrict__ mask_fit,
          double *__restrict__ cdf) {
-    typedef hipcub::BlockScan<double, PO_T> Scan;
-    typedef hipcub::BlockReduce<double, PO_T> Reduce;
-    __shared__ typename Scan::TempStorage s_scan;
-    __shared__ typename Reduce::TempStorage s_red;
+    __shared__ double s_slot[PO_T / 64 + 1];
+    __shared__ double s_red[PO_T / 64];
     __shared__ double s_bc;
     const int o = blockIdx.x, b = blockIdx.y;
     if (!use[(int64_t)b * nobj + o]) return;
@@ -100,8 +98,13 @@ k_po_cdf(int nobj, int nsamps, const double *__restrict__ weights,
             const double v = row[k];
             m = v > m ? v : m;
         }
-        m = Reduce(s_red).Reduce(m, hipcub::Max());
-        if (threadIdx.x == 0) s_bc = m;
+        m = wave_max(m);
+        if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = m;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int q = 1; q < PO_T / 64; ++q) m = s_red[q] > m ? s_red[q] : m;
+            s_bc = m;
+        }
         __syncthreads();
         mx = s_bc;
         if (!(mx > -INFINITY)) mx = 0.;
@@ -111,9 +114,8 @@ k_po_cdf(int nobj, int nsamps, const double *__restrict__ weights,
         const int k = k0 + threadIdx.x;
         double v = 0.;
         if (k < nsamps) v = fit ? exp(row[k] - mx) * w[k] : w[k];
-        double inc, tot;
-        __syncthreads();
-        Scan(s_scan).InclusiveSum(v, inc, tot);
+        double tot;
+        const double inc = block_exclusive_sum<double, PO_T>(v, s_slot, tot) + v;
         if (k < nsamps) row[k] = carry + inc;
         carry += tot;
     }
