@@ -8,19 +8,21 @@ done on the device (k_finalize); these host versions serve the public API and
 the Monte Carlo stage of `lnpost`, which acts on selected models only.
 """
 import os
+import warnings
 
 import numpy as np
 
 from .galprior import (gal_lnprior, logn_disk, logn_halo, logp_age_from_feh,   # noqa: F401
                        logp_feh)
 
-# the reference's `brutus.pdf.__all__` (pdf.py:30-35) minus `bin_pdfs_distred` (plot binning,
-# SURVEY section 2: out of scope), plus the table type of the Bayestar-free dust interface
+# the reference's `brutus.pdf.__all__` (pdf.py:30-35), plus the table type of the Bayestar-free
+# dust interface
 __all__ = ["imf_lnprior", "ps1_MrLF_lnprior", "parallax_lnprior",
            "scale_parallax_lnprior", "parallax_to_scale",
            "logn_disk", "logn_halo",
            "logp_feh", "logp_age_from_feh",
            "gal_lnprior", "dust_lnprior",
+           "bin_pdfs_distred",
            "LOSTable"]
 
 
@@ -221,3 +223,110 @@ def dust_lnprior(dists, coord, avs, dustfile=None, offset=0., scale=1., smooth=1
     if not return_components:
         return lnprior
     return lnprior, (av_mean, av_err)
+
+
+def bin_pdfs_distred(data, cdf=False, ebv=False, dist_type='distance_modulus',
+                     lndistprior=None, coord=None, avlim=(0., 6.), rvlim=(1., 8.),
+                     parallaxes=None, parallax_errors=None, Nr=100,
+                     bins=(750, 300), span=None, smooth=0.01, rstate=None,
+                     verbose=False):
+    """Binned 2-D (distance, reddening) posteriors of a set of fitted objects, the input of
+    the line-of-sight fits and of `plotting.dist_vs_red`; same arguments and return values as
+    reference `pdf.bin_pdfs_distred` (pdf.py:843-1113).  Host numpy: it acts on the few
+    hundred draws per object that `fit()` wrote.
+
+    `data` is `(dists, reds, dreds)` as saved by `fit(save_dar_draws=True)`, each
+    `(Nobj, Nsamps)`, or `(scales, avs, rvs, covs_sar)`, from which `Nr` realisations per draw
+    are regenerated with `utils.draw_sar` and re-weighted by the distance prior
+    `lndistprior(dists, coord)` (default: the Galactic prior) and the parallax likelihood.
+    Returns `(binned_vals (Nobj, Nxbin, Nybin) float32, xedges, yedges)`; every object's
+    histogram is divided by `Nsamps` and smoothed with a Gaussian whose width along the
+    distance axis is capped by the object's parallax error.
+    """
+    import sys
+    from scipy.ndimage import gaussian_filter
+    from scipy.special import logsumexp
+    from .utils import draw_sar
+    nobjs, nsamps = np.shape(data[0])[:2]
+    if rstate is None:
+        rstate = getattr(np, "random_intel", np.random)
+    if dist_type not in ('parallax', 'scale', 'distance', 'distance_modulus'):
+        raise ValueError("The provided `dist_type` is not valid.")
+    regenerate = len(data) != 3
+    if regenerate and lndistprior is None and coord is None:
+        raise ValueError("`coord` must be passed if the default distance "
+                         "prior was used.")
+    if lndistprior is None:
+        lndistprior = gal_lnprior
+    parallaxes = (np.full(nobjs, np.nan) if parallaxes is None
+                  else np.asarray(parallaxes, dtype=np.float64))
+    parallax_errors = (np.full(nobjs, np.nan) if parallax_errors is None
+                       else np.asarray(parallax_errors, dtype=np.float64))
+
+    # bin edges: reddening along y, the chosen distance measure along x
+    if span is None:
+        avlims, dlims = avlim, 10. ** (np.array([4., 19.]) / 5. - 2.)
+    else:
+        avlims, dlims = span
+    dlims = np.asarray(dlims, dtype=np.float64)
+    try:
+        xbin, ybin = bins
+    except TypeError:
+        xbin = ybin = bins
+    to_x = {'scale': lambda d: 1. / d ** 2, 'parallax': lambda d: 1. / d,
+            'distance': lambda d: d, 'distance_modulus': lambda d: 5. * np.log10(d) + 10.}[dist_type]
+    xlims = to_x(dlims[::-1]) if dist_type in ('scale', 'parallax') else to_x(dlims)
+    ylims = avlims
+    xbins = np.linspace(xlims[0], xlims[1], xbin + 1)
+    ybins = np.linspace(ylims[0], ylims[1], ybin + 1)
+    dx, dy = xbins[1] - xbins[0], ybins[1] - ybins[0]
+    xspan, yspan = xlims[1] - xlims[0], ylims[1] - ylims[0]
+    # smoothing widths: a fraction of the span below 1, a number of bins from 1 on
+    try:
+        sx, sy = smooth[0], smooth[1]
+    except (TypeError, IndexError):
+        sx = sy = smooth
+    xsmooth = sx * xspan if sx < 1 else sx * dx
+    ysmooth = sy * yspan if sy < 1 else sy * dy
+
+    binned = np.zeros((nobjs, xbin, ybin), dtype='float32')
+    xedges, yedges = xbins, ybins
+    for i in range(nobjs):
+        if verbose:
+            sys.stderr.write('\rBinning object {0}/{1}'.format(i + 1, nobjs))
+        if not regenerate:
+            d = np.array(data[0][i], dtype=np.float64)
+            y = np.array(data[1][i], dtype=np.float64)
+            if ebv:
+                y = y / np.asarray(data[2][i], dtype=np.float64)
+            weights = None
+        else:
+            sd, ad, rd = draw_sar(data[0][i], data[1][i], data[2][i], data[3][i], ndraws=Nr,
+                                  avlim=avlim, rvlim=rvlim, rstate=rstate)
+            with np.errstate(all="ignore"):
+                pd = np.sqrt(sd)
+                d = 1. / pd
+                lnp = np.array(lndistprior(d, coord[i]), dtype=np.float64)
+                lnp = lnp + parallax_lnprior(pd, parallaxes[i], parallax_errors[i])
+                w = np.exp(lnp - logsumexp(lnp, axis=1)[:, None])
+                w /= w.sum(axis=1)[:, None]
+            weights = w.reshape(-1)
+            y = ad.reshape(-1)
+            if ebv:
+                y = y / rd.reshape(-1)
+            d = d.reshape(-1)
+        with np.errstate(all="ignore"):
+            H, xedges, yedges = np.histogram2d(to_x(d), y, bins=(xbins, ybins), weights=weights)
+        # the parallax caps the smoothing along the distance axis
+        p1 = np.array([parallaxes[i] + parallax_errors[i],
+                       max(parallaxes[i] - parallax_errors[i], 1e-10)])
+        with warnings.catch_warnings(), np.errstate(all="ignore"):
+            warnings.simplefilter("ignore")
+            cap = abs(np.diff({'scale': p1 ** 2, 'parallax': p1, 'distance': 1. / p1,
+                               'distance_modulus': 5. * np.log10(1. / p1)}[dist_type])[0]) / 2.
+        xs = min(cap, xsmooth) if np.isfinite(cap) else xsmooth
+        binned[i] = gaussian_filter((H / nsamps).astype('float32'), (xs / dx, ysmooth / dy))
+    if cdf:
+        for i in range(nobjs):
+            binned[i] = binned[i].cumsum(axis=0)
+    return binned, xedges, yedges

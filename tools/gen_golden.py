@@ -506,6 +506,49 @@ def gen_dust():
     print("dust done")
 
 
+def gen_bin_pdfs():
+    """`pdf.bin_pdfs_distred` (pdf.py:843-1113) on saved draws and on regenerated ones, every
+    distance type, E(B-V), CDF, both forms of `smooth` / `bins` / `span`."""
+    rng = np.random.RandomState(77)
+    nobj, ns = 5, 40
+    dists = 10. ** rng.normal(0.2, 0.15, size=(nobj, ns))
+    reds = np.abs(rng.normal(1.2, 0.5, size=(nobj, ns)))
+    dreds = rng.normal(3.3, 0.2, size=(nobj, ns))
+    scales = 1. / dists ** 2
+    covs = np.zeros((nobj, ns, 3, 3))
+    for i in range(nobj):
+        for k in range(ns):
+            A = rng.normal(size=(3, 3)) * np.array([0.05 * scales[i, k], 0.1, 0.05])[:, None]
+            covs[i, k] = A @ A.T + np.diag([1e-6 * scales[i, k] ** 2, 1e-4, 1e-4])
+    par = 1. / np.median(dists, axis=1) + rng.normal(size=nobj) * 0.05
+    perr = np.full(nobj, 0.05)
+    par[1] = np.nan
+    perr[3] = np.nan
+    coord = np.stack([rng.uniform(0, 360, nobj), rng.uniform(-60, 60, nobj)], axis=1)
+    prior = lambda d, c: galprior(d, c)
+    cases = [
+        ("dm", dict()),
+        ("par_cdf", dict(dist_type="parallax", cdf=True, bins=24)),
+        ("scale_ebv", dict(dist_type="scale", ebv=True, bins=(30, 12), smooth=(2., 0.05))),
+        ("dist_span", dict(dist_type="distance", span=((0., 4.), (0.3, 6.)), bins=(28, 16), smooth=1.5)),
+    ]
+    res = dict(dists=dists, reds=reds, dreds=dreds, scales=scales, covs=covs, parallaxes=par,
+               parallax_errors=perr, coord=coord, names=np.array([c[0] for c in cases]))
+    for name, kw in cases:
+        kw = dict(kw)
+        kw.setdefault("bins", (36, 18))
+        b, xe, ye = P.bin_pdfs_distred((dists.copy(), reds.copy(), dreds.copy()), parallaxes=par,
+                                       parallax_errors=perr, **kw)
+        res["saved_%s" % name], res["saved_%s_x" % name], res["saved_%s_y" % name] = b, xe, ye
+        b, xe, ye = P.bin_pdfs_distred((scales.copy(), reds.copy(), dreds.copy(), covs.copy()),
+                                       lndistprior=prior, coord=coord, parallaxes=par,
+                                       parallax_errors=perr, Nr=12, rstate=np.random.RandomState(5),
+                                       **kw)
+        res["regen_%s" % name], res["regen_%s_x" % name], res["regen_%s_y" % name] = b, xe, ye
+    np.savez_compressed(os.path.join(OUT, "bin_pdfs.npz"), **res)
+    print("wrote bin_pdfs.npz")
+
+
 def gen_psd():
     """`lnpost` on a crafted set of precision matrices whose inverse is NOT positive
     definite, so that the repair loop of reference fitting.py:1039-1065 runs on purpose:
@@ -574,6 +617,8 @@ if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)
     which = sys.argv[1:] or ["loglike", "fit", "helpers", "setup", "galprior",
                              "cluster"]
+    if "binpdfs" in which:
+        gen_bin_pdfs()
     if "init" in which:
         gen_loglike_init()
     if "cdf" in which:
