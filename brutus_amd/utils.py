@@ -10,8 +10,12 @@ from math import lgamma, log
 
 import numpy as np
 
-__all__ = ["_inverse3", "_chisquare_logpdf", "sample_multivariate_normal",
-           "magnitude", "inv_magnitude"]
+__all__ = ["_function_wrapper", "_adjoint3", "_inverse_transpose3", "_inverse3", "_dot3",
+           "_isPSD", "_chisquare_logpdf", "_truncnorm_pdf", "_truncnorm_logpdf", "_get_seds",
+           "fetch_isos", "fetch_tracks", "fetch_dustmaps", "fetch_grids", "fetch_offsets",
+           "fetch_nns", "load_models", "load_offsets", "quantile", "draw_sar",
+           "sample_multivariate_normal", "magnitude", "inv_magnitude", "luptitude",
+           "inv_luptitude", "add_mag", "get_seds", "phot_loglike", "photometric_offsets"]
 
 
 def _inverse3(A):
@@ -468,3 +472,161 @@ def _photometric_offsets_device(phot, err, mask, models, idxs, reds, dreds, dist
         ratios = (ratios * prior_std ** 2 + prior_mean * ratios_err ** 2) / var
         ratios_err = ratios_err * prior_std / np.sqrt(var)
     return ratios, ratios_err, nratio
+
+
+# ---------------------------------------------------------------------------
+# the rest of `brutus.utils.__all__` (utils.py:28-38): small host helpers of the reference's
+# scripts and notebooks, restated so that `from brutus_amd.utils import ...` finds every
+# name the reference exports.  None of them is on the grid-likelihood path.
+# ---------------------------------------------------------------------------
+class _function_wrapper(object):
+    """Picklable `x -> func(x, *args, **kwargs)` (reference utils.py:43-68; the emcee idiom):
+    an exception inside `func` is reported with the arguments, then re-raised."""
+
+    def __init__(self, func, args, kwargs, name='input'):
+        self.func, self.args, self.kwargs, self.name = func, args, kwargs, name
+
+    def __call__(self, x):
+        try:
+            return self.func(x, *self.args, **self.kwargs)
+        except Exception:
+            import traceback
+            print("Exception while calling {0} function:".format(self.name))
+            print("  params:", x)
+            print("  args:", self.args)
+            print("  kwargs:", self.kwargs)
+            print("  exception:")
+            traceback.print_exc()
+            raise
+
+
+def _dot3(A, B):
+    """Row-wise dot products over the last axis (utils.py:86-93)."""
+    return np.einsum('...i,...i->...', A, B)
+
+
+def _adjoint3(A):
+    """Adjugate-transpose of a stack of 3x3 matrices: row i = cross product of the two rows
+    after it, cyclically (utils.py:71-83)."""
+    A = np.asarray(A)
+    out = np.empty_like(A)
+    out[..., 0, :] = np.cross(A[..., 1, :], A[..., 2, :])
+    out[..., 1, :] = np.cross(A[..., 2, :], A[..., 0, :])
+    out[..., 2, :] = np.cross(A[..., 0, :], A[..., 1, :])
+    return out
+
+
+def _inverse_transpose3(A):
+    """Inverse-transpose of a stack of 3x3 matrices (utils.py:96-105): adjugate-transpose over
+    the mean of its three row dots with `A`."""
+    adj = _adjoint3(A)
+    return adj / _dot3(adj, A).mean(axis=-1)[..., None, None]
+
+
+def _isPSD(A):
+    """True if `A` has a Cholesky factor (utils.py:117-127)."""
+    try:
+        np.linalg.cholesky(A)
+    except np.linalg.LinAlgError:
+        return False
+    return True
+
+
+def _truncnorm_terms(x, a, b, loc, scale):
+    from math import erf, sqrt
+    lo, hi = scale * a + loc, scale * b + loc          # bounds in the units of x
+    z = (x - loc) / scale
+    mass = erf(b / sqrt(2.)) - erf(a / sqrt(2.))         # 2 (Phi(b) - Phi(a))
+    outside = np.logical_or(x < lo, x > hi)
+    return z, mass, outside
+
+
+def _truncnorm_pdf(x, a, b, loc=0.0, scale=1.0):
+    """pdf of a normal (`loc`, `scale`) truncated to `[a, b]` standard deviations, like
+    `scipy.stats.truncnorm.pdf` (utils.py:179-229)."""
+    z, mass, outside = _truncnorm_terms(x, a, b, loc, scale)
+    ans = np.exp(-0.5 * z ** 2) / np.sqrt(2. * np.pi) / (scale * 0.5 * mass)
+    if isinstance(x, (float, int)):
+        return 0 if outside else ans
+    ans[outside] = 0
+    return ans
+
+
+def _truncnorm_logpdf(x, a, b, loc=0.0, scale=1.0):
+    """ln of `_truncnorm_pdf` (utils.py:232-283)."""
+    z, mass, outside = _truncnorm_terms(x, a, b, loc, scale)
+    ans = np.subtract(-log(np.sqrt(2. * np.pi)) - 0.5 * np.square(z),
+                      log(scale / 2.) + log(mass))
+    if isinstance(x, (float, int)):
+        return -np.inf if outside else ans
+    ans[outside] = -np.inf
+    return ans
+
+
+def _get_seds(mag_coeffs, av, rv, return_flux=False):
+    """The reference's numba kernel (utils.py:286-347) as a host function:
+    `(seds, rvecs, drvecs)` of `(Nmodel, Nband, 3)` coefficients at per-model `av`, `rv`."""
+    return get_seds(mag_coeffs, av=av, rv=rv, return_flux=return_flux, return_rvec=True,
+                    return_drvec=True)
+
+
+def quantile(x, q, weights=None):
+    """(Weighted) sample quantiles (utils.py:718-762): `numpy.percentile` without weights,
+    else the inverse of the cumulative weights of the sorted samples."""
+    x, q = np.atleast_1d(x), np.atleast_1d(q)
+    if np.any(q < 0.0) or np.any(q > 1.0):
+        raise ValueError("Quantiles must be between 0. and 1.")
+    if weights is None:
+        return np.percentile(x, list(100.0 * q))
+    weights = np.atleast_1d(weights)
+    if len(x) != len(weights):
+        raise ValueError("Dimension mismatch: len(weights) != len(x).")
+    order = np.argsort(x)
+    cdf = np.cumsum(weights[order])[:-1]
+    cdf = np.append(0, cdf / cdf[-1])
+    return np.interp(q, cdf, x[order]).tolist()
+
+
+def luptitude(phot, err, skynoise=1., zeropoints=1.):
+    """asinh magnitudes and their errors (utils.py:978-1017)."""
+    mag = -2.5 / np.log(10.) * (np.arcsinh(phot / (2. * skynoise)) + np.log(skynoise / zeropoints))
+    mag_err = np.sqrt(np.square(2.5 * np.log10(np.e) * err)
+                      / (np.square(2. * skynoise) + np.square(phot)))
+    return mag, mag_err
+
+
+def inv_luptitude(mag, err, skynoise=1., zeropoints=1.):
+    """Inverse of `luptitude` (utils.py:1020-1059)."""
+    phot = (2. * skynoise) * np.sinh(np.log(10.) / -2.5 * mag - np.log(skynoise / zeropoints))
+    phot_err = np.sqrt((np.square(2. * skynoise) + np.square(phot)) * np.square(err)) \
+        / (2.5 * np.log10(np.e))
+    return phot, phot_err
+
+
+def add_mag(mag1, mag2, f1=1., f2=1.):
+    """Magnitude of `f1 flux(mag1) + f2 flux(mag2)` (utils.py:1062-1086)."""
+    return -2.5 * np.log10(f1 * 10 ** (-0.4 * mag1) + f2 * 10 ** (-0.4 * mag2))
+
+
+def _no_download(what):
+    def fetch(target_dir=".", *args, **kwargs):
+        raise NotImplementedError(
+            "brutus_amd.utils.%s: downloading %s from the Harvard Dataverse (reference "
+            "utils.py:363-517, via pooch) is outside this package's scope -- fetch the file with "
+            "the reference package or by hand and pass its path to load_models / load_offsets"
+            % (fetch.__name__, what))
+    return fetch
+
+
+fetch_isos = _no_download("the MIST isochrone file")
+fetch_isos.__name__ = "fetch_isos"
+fetch_tracks = _no_download("the MIST evolutionary tracks")
+fetch_tracks.__name__ = "fetch_tracks"
+fetch_dustmaps = _no_download("the Bayestar dust map")
+fetch_dustmaps.__name__ = "fetch_dustmaps"
+fetch_grids = _no_download("a pre-computed model grid")
+fetch_grids.__name__ = "fetch_grids"
+fetch_offsets = _no_download("the photometric offsets file")
+fetch_offsets.__name__ = "fetch_offsets"
+fetch_nns = _no_download("the bolometric-correction network")
+fetch_nns.__name__ = "fetch_nns"

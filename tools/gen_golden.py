@@ -549,6 +549,43 @@ def gen_bin_pdfs():
     print("wrote bin_pdfs.npz")
 
 
+def gen_utils_misc():
+    """The small helpers of `brutus.utils.__all__` (utils.py:43-127, 179-347, 718-762, 978-1086)."""
+    rng = np.random.RandomState(12)
+    A = rng.normal(size=(7, 3, 3))
+    B = rng.normal(size=(7, 3, 3))
+    spd = A @ np.transpose(A, (0, 2, 1)) + 0.1 * np.eye(3)
+    notpd = spd.copy()
+    notpd[:, 0, 0] = -1.
+    x = np.linspace(-4., 6., 41)
+    coeffs = rng.normal(size=(9, 5, 3)).astype(np.float32).astype(np.float64)
+    av, rv = rng.uniform(0, 2, 9), rng.uniform(2, 5, 9)
+    samp, wts = rng.normal(size=200), rng.uniform(size=200)
+    q = np.array([0.025, 0.16, 0.5, 0.84, 0.975])
+    phot, err = 10. ** rng.normal(-8, 1, size=(6, 4)), 10. ** rng.normal(-9.5, 0.3, size=(6, 4))
+    phot[0, 0] = -1e-9
+    lm, le = U.luptitude(phot, err, skynoise=2e-9, zeropoints=3.)
+    res = dict(
+        A=A, B=B, adj=U._adjoint3(A), invT=U._inverse_transpose3(A), dot=U._dot3(A, B),
+        spd=spd, notpd=notpd,
+        psd=np.array([U._isPSD(m) for m in spd] + [U._isPSD(m) for m in notpd]),
+        x=x, tn_pdf=U._truncnorm_pdf(x.copy(), -1.5, 2.5, loc=1., scale=1.7),
+        tn_logpdf=U._truncnorm_logpdf(x.copy(), -1.5, 2.5, loc=1., scale=1.7),
+        tn_scalar=np.array([U._truncnorm_pdf(0.3, -1.5, 2.5, 1., 1.7), U._truncnorm_pdf(9., -1.5, 2.5, 1., 1.7),
+                            U._truncnorm_logpdf(0.3, -1.5, 2.5, 1., 1.7), U._truncnorm_logpdf(9., -1.5, 2.5, 1., 1.7)]),
+        coeffs=coeffs, av=av, rv=rv, samp=samp, wts=wts, q=q,
+        quant=np.asarray(U.quantile(samp, q)), quant_w=np.asarray(U.quantile(samp, q, weights=wts)),
+        phot=phot, err=err, lup=lm, lup_err=le,
+        add=U.add_mag(np.linspace(10, 20, 7), np.linspace(21, 9, 7), f1=0.7, f2=1.3))
+    for k, rf in (("mag", False), ("flux", True)):
+        sd, rvc, drv = U._get_seds(coeffs, av, rv, return_flux=rf)
+        res["seds_" + k], res["rvecs_" + k], res["drvecs_" + k] = sd, rvc, drv
+    ip, ie = U.inv_luptitude(lm, le, skynoise=2e-9, zeropoints=3.)
+    res["ilup"], res["ilup_err"] = ip, ie
+    np.savez_compressed(os.path.join(OUT, "utils_misc.npz"), **res)
+    print("wrote utils_misc.npz")
+
+
 def gen_psd():
     """`lnpost` on a crafted set of precision matrices whose inverse is NOT positive
     definite, so that the repair loop of reference fitting.py:1039-1065 runs on purpose:
@@ -619,6 +656,8 @@ if __name__ == "__main__":
                              "cluster"]
     if "binpdfs" in which:
         gen_bin_pdfs()
+    if "utilsmisc" in which:
+        gen_utils_misc()
     if "init" in which:
         gen_loglike_init()
     if "cdf" in which:
