@@ -537,8 +537,8 @@ template <int NB, bool RVF, bool FULL>
 __device__ __forceinline__ void mle_at(const Tile64<NB, RVF> &t, const StarPrep &sp,
                                        const DevParams &p, double av, double rv,
                                        const double *__restrict__ tbl, Mle &m) {
-    if constexpr (RVF) mle_fast_rf<NB, true, FULL>(t.c, t.R, t.F0, sp, p, av, tbl, m);
-    else mle_fast<NB, true>(t.c, t.F0, sp, p, av, rv, tbl, m);
+    if constexpr (RVF) mle_fast_rf<NB, true, FULL ? 2 : 0>(t.c, t.R, t.F0, sp, p, av, tbl, m);
+    else mle_fast<NB, true, FULL ? 2 : 0>(t.c, t.F0, sp, p, av, rv, tbl, m);
 }
 
 __device__ __forceinline__ void audit(float *__restrict__ aud, int s, float f32v, double f64v,
@@ -565,7 +565,7 @@ __device__ __forceinline__ int64_t mword(int s, int ntile, int t, int w) {
 // and that holds no NaN lane is skipped outright.
 // part[(bx * nstar + s)] = block maximum (-inf if no nominee)
 template <int NB, bool RVF, int G>
-__global__ void __launch_bounds__(TILE, 2)
+__global__ void __launch_bounds__(TILE, top_waves(NB))
 k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
       const int32_t *__restrict__ star_ids, const StarPrep *__restrict__ stars, DevParams p,
       const int32_t *__restrict__ k1, int ntile, int mode, const float *__restrict__ plane32,
@@ -853,7 +853,7 @@ k_sel_classify(int64_t nmodel, int ntile, const Star32 *__restrict__ s32,
 // workgroup is shared in turns by the SB_Z workgroups of its column.
 constexpr int SB_C = 8, SB_Z = 8;
 template <int NB, bool RVF>
-__global__ void __launch_bounds__(TILE, 2)
+__global__ void __launch_bounds__(TILE, band_waves(NB))
 k_sel_band(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ntile,
            const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
            const float *__restrict__ lnpr32, const double *__restrict__ thr_sel,

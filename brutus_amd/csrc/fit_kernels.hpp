@@ -77,7 +77,10 @@ __device__ __forceinline__ void gram_sweep(const Gram &G, double S, const DevPar
 }
 
 // MLE quantities as mle_eval, with F = F0 * 10^(-0.4 av R) through fast_exp10.
-template <int NB, bool TBL>
+// LV: how much of it the caller uses -- 0: scale, chi2, i00 and the Av step sums (a_num, a_ss);
+// 1: + the Rv step sums (r_num, r_ss); 2: everything (the precision matrix's mixed terms are
+// only ever read from the LAST evaluation of a model, the one that is stored).
+template <int NB, bool TBL, int LV = 2>
 __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[NB],
                                          const StarPrep &sp, const DevParams &p, double av,
                                          double rv, const double *__restrict__ tbl, Mle &o) {
@@ -112,17 +115,21 @@ __device__ __forceinline__ void mle_fast(const Coef<NB> &c, const double (&F0)[N
         const double R0 = (double)c.r0[j] + rv * D0;
         const double u = R0 * F[j], v = D0 * F[j];
         const double res = fma(-s, F[j], sp.d[j]);
-        const double t = fma(s2, F[j], -sp.d[j]);
-        const double q = fma(-s, F0[j], t);
         const double rw = res * iv, uw = u * iv, vw = v * iv;
         chi2 = fma(res, rw, chi2);
         AN = fma(u, rw, AN);
-        RN = fma(v, rw, RN);
         AA = fma(u, uw, AA);
-        RR = fma(v, vw, RR);
-        SA = fma(uw, t, SA);
-        SR = fma(vw, t, SR);
-        AR = fma(vw, q, AR);
+        if (LV >= 1) {
+            RN = fma(v, rw, RN);
+            RR = fma(v, vw, RR);
+        }
+        if (LV >= 2) {
+            const double t = fma(s2, F[j], -sp.d[j]);
+            const double q = fma(-s, F0[j], t);
+            SA = fma(uw, t, SA);
+            SR = fma(vw, t, SR);
+            AR = fma(vw, q, AR);
+        }
     }
     const double cs = fac * s, cs2 = cs * cs;
     double a_den = cs2 * AA, r_den = cs2 * RR;
@@ -201,9 +208,9 @@ __device__ __forceinline__ void gram_sweep_rf(const GramR &G, double S, const De
     logwt = -0.5 * chi2;
 }
 
-// mle_fast with R given.  FULL = false leaves out the Rv sums (i02, i12, i22,
-// r_num, r_ss), which only the reported precision matrix needs.
-template <int NB, bool TBL, bool FULL>
+// mle_fast with R given.  LV < 2 leaves out the Rv sums and the mixed terms (i01, i02, i12,
+// i22, r_num, r_ss), which only the reported precision matrix needs.
+template <int NB, bool TBL, int LV>
 __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)[NB],
                                             const double (&F0)[NB], const StarPrep &sp,
                                             const DevParams &p, double av,
@@ -230,16 +237,16 @@ __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)
         const double iv = sp.iV[j];
         const double u = R[j] * F[j];
         const double res = fma(-s, F[j], sp.d[j]);
-        const double t = fma(s2, F[j], -sp.d[j]);
         const double rw = res * iv, uw = u * iv;
         chi2 = fma(res, rw, chi2);
         AN = fma(u, rw, AN);
         AA = fma(u, uw, AA);
-        SA = fma(uw, t, SA);
-        if (FULL) {
+        if (LV >= 2) {
+            const double t = fma(s2, F[j], -sp.d[j]);
             const double v = (double)c.dr[j] * F[j];
             const double q = fma(-s, F0[j], t);
             const double vw = v * iv;
+            SA = fma(uw, t, SA);
             RN = fma(v, rw, RN);
             RR = fma(v, vw, RR);
             SR = fma(vw, t, SR);
@@ -266,6 +273,168 @@ __device__ __forceinline__ void mle_fast_rf(const Coef<NB> &c, const double (&R)
     o.i11 = a_den;
     o.i12 = ar_mix;
     o.i22 = r_den;
+}
+
+// ---- more than 16 bands: the per-band arrays do not fit the register file ----
+// With F0, R and F held per lane (2 * NB registers each) the list kernels, built for two
+// workgroups per CU (256 registers), spill from 24 bands up: k_fflux<24> 256 VGPRs + 700-1000
+// bytes of scratch, 10.4 ms per 128 stars against 2.2 ms at 16 bands.  Two remedies, measured
+// per 128 stars on configs[1] / configs[2] (round 4, same box):
+//  (1) ONE workgroup per CU -- a wave per SIMD, 512 registers: what does not fit the 256
+//      architectural ones sits in accumulation registers, a one-instruction move away,
+//      instead of scratch memory;
+//  (2) the WIDE form, which holds only the model's coefficients (3 * NB float32): the flux
+//      F_j = 10^(-0.4 (m_j + av R_j)) comes from ONE exponential of the whole magnitude (no F0
+//      array), R_j = r0_j + rv dr_j is recomputed where it is used (one fma), and the fluxes go
+//      through a lane-private column of LDS (`Fc[j * TILE]`: NB * 2 KiB per workgroup)
+//      between the two passes over the bands.  The accesses are volatile: the compiler
+//      otherwise forwards the stores to the loads and is back to NB live registers.  LV 2
+//      costs one more exponential per band (F0 for ar_mix).
+//   24 bands  k_fflux  narrow x2 10.4 / 4.12   wide x2 2.91 / 1.69   wide x1 3.55 / 2.02   narrow x1 2.66 / 1.75
+//             k_derive narrow x2  6.5 / 4.35   wide x2 4.03 / 2.96   wide x1 2.69 / 2.21   narrow x1 2.56 / 2.04
+//   32 bands  k_fflux  narrow x2 16.0 / 6.66   wide x2 4.87 / 2.03   wide x1 3.20 / 1.67   narrow x1 4.86 / 4.84
+//             k_derive narrow x2 14.7 / 8.53   wide x2 9.48 / 5.77   wide x1 3.76 / 2.88   narrow x1 4.87 / 2.71
+// hence: 24 bands narrow, 32 bands wide, both at one workgroup per CU (configs[1] / [2] at
+// 24 bands 6.6k / 11.1k -> 16.8k / 18.9k stars/s, at 32 bands 3.6k / 5.8k -> 12.1k / 12.9k).
+#ifndef BRUTUS_WIDE_FROM
+#define BRUTUS_WIDE_FROM 25
+#endif
+constexpr bool wide_bands(int nb) { return nb >= BRUTUS_WIDE_FROM; }
+#ifndef BRUTUS_LIST_OCC1_FROM
+#define BRUTUS_LIST_OCC1_FROM 17
+#endif
+constexpr int list_waves(int nb) { return nb >= BRUTUS_LIST_OCC1_FROM ? 1 : 2; }
+// (the tile kernels of fit2_kernels.hpp likewise: k_sel_band from 24 bands -- 0.16 -> 0.10,
+// 0.27 -> 0.13 ms --, k_top at 32 -- 2.19 -> 1.27 ms; k_top<24> is faster with two: 0.68
+// against 0.87 ms)
+constexpr int top_waves(int nb) { return nb > 24 ? 1 : 2; }
+constexpr int band_waves(int nb) { return nb > 16 ? 1 : 2; }
+// (an LDS pointer by address space: a volatile access through a generic pointer is a FLAT one)
+typedef __attribute__((address_space(3))) volatile double *LdsColumn;
+// float32 -> float64 where it is used, every time: left to itself the compiler converts the
+// 3 * NB coefficients once and keeps them as doubles -- 6 * NB registers.  The conversion is
+// an asm with a second, unused operand `after`: conversions with different `after` are
+// different values, so nothing is merged across passes.  `after` can also hold the
+// scheduler back -- a running sum as of the end of the previous group of WIDE_GROUP bands:
+// a group's arithmetic cannot start before the previous group's sums exist -- which pays at two
+// workgroups per CU and costs at one, where the wave is alone on its SIMD and wants every
+// independent chain it can get (32 bands, k_fflux: groups of 4 3.70 / 1.87 ms, of 8 3.42 / 1.87,
+// none 3.20 / 1.67): the default group is the whole band loop.  (A scheduling barrier instead
+// pins only itself and the other ordered operations; the arithmetic floats around it.)
+#ifndef BRUTUS_WIDE_GROUP
+#define BRUTUS_WIDE_GROUP 32
+#endif
+__device__ __forceinline__ double wide_f64(float x, double after) {
+    double r;
+    asm("v_cvt_f64_f32_e32 %0, %1" : "=v"(r) : "v"(x), "v"(after));
+    return r;
+}
+#define WIDE_ANCHOR(var, sum) if (j % BRUTUS_WIDE_GROUP == 0 && j) var = (sum)
+
+template <int NB, int LV>
+__device__ __forceinline__ void mle_wide(const Coef<NB> &c, const StarPrep &sp,
+                                         const DevParams &p, double av, double rv,
+                                         const double *__restrict__ tbl, LdsColumn Fc,
+                                         Mle &o) {
+    const double fac = -0.92103403719761827361;
+    const double mav = -0.4 * av;
+    double s_num = 0., s_den = 0.;
+    double after = mav;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        WIDE_ANCHOR(after, s_den);
+        const double R = fma(rv, wide_f64(c.dr[j], after), wide_f64(c.r0[j], after));
+        const double f = fast_exp10(fma(mav, R, -0.4 * wide_f64(c.m[j], after)), tbl);
+        Fc[j * TILE] = f;
+        const double fw = f * sp.iV[j];
+        s_num += sp.d[j] * fw;
+        s_den += f * fw;
+    }
+    double s = s_num / s_den;
+    if (s <= 1e-20) s = 1e-20;
+    double SA = 0., SR = 0., AR = 0., AA = 0., RR = 0., AN = 0., RN = 0., chi2 = 0.;
+    const double s2 = s + s;
+    after = s;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        WIDE_ANCHOR(after, chi2);
+        const double iv = sp.iV[j];
+        const double f = Fc[j * TILE];
+        const double D0 = wide_f64(c.dr[j], after);
+        const double u = fma(rv, D0, wide_f64(c.r0[j], after)) * f;
+        const double res = fma(-s, f, sp.d[j]);
+        const double rw = res * iv, uw = u * iv;
+        chi2 = fma(res, rw, chi2);
+        AN = fma(u, rw, AN);
+        AA = fma(u, uw, AA);
+        if (LV >= 1) {
+            const double v = D0 * f;
+            const double vw = v * iv;
+            RN = fma(v, rw, RN);
+            RR = fma(v, vw, RR);
+            if (LV >= 2) {
+                const double t = fma(s2, f, -sp.d[j]);
+                const double q = fma(-s, fast_exp10(-0.4 * wide_f64(c.m[j], after), tbl), t);
+                SA = fma(uw, t, SA);
+                SR = fma(vw, t, SR);
+                AR = fma(vw, q, AR);
+            }
+        }
+    }
+    const double cs = fac * s, cs2 = cs * cs;
+    double a_den = cs2 * AA, r_den = cs2 * RR;
+    o.a_ss = a_den;
+    o.r_ss = r_den;
+    o.a_num = cs * AN;
+    o.r_num = cs * RN;
+    a_den += p.av_ivar;
+    r_den += p.rv_ivar;
+    a_den += p.a_reg;
+    r_den += p.r_reg;
+    o.scale = s;
+    o.chi2 = chi2;
+    o.i00 = s_den;
+    o.i01 = fac * SA;
+    o.i02 = fac * SR;
+    o.i11 = a_den;
+    o.i12 = cs * AR;
+    o.i22 = r_den;
+}
+
+// gram_init_rf with R recomputed per band (no R array)
+template <int NB>
+__device__ __forceinline__ void gram_init_rf_wide(const Coef<NB> &c, double rv,
+                                                  const StarPrep &sp, GramR &G) {
+    double uR = 0., RR = 0., yR = 0., uy = 0., yy = 0.;
+    double after = rv;
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        WIDE_ANCHOR(after, yy);
+        const double w = sp.iW[j];
+        const double R = fma(rv, wide_f64(c.dr[j], after), wide_f64(c.r0[j], after));
+        const double y = sp.g[j] - wide_f64(c.m[j], after);
+        const double Rw = R * w, yw = y * w;
+        uR += Rw;
+        RR += R * Rw;
+        yR += R * yw;
+        uy += yw;
+        yy += y * yw;
+    }
+    G.uR = uR; G.RR = RR; G.yR = yR; G.uy = uy; G.yy = yy;
+}
+
+// The MLE of the list kernels in whichever form the band count calls for.  NR / NF: lengths of
+// the caller's R and F0 arrays (1 where the form at hand does not keep them).
+// FULL: the evaluation whose results are stored; otherwise only what the next step needs.
+template <int NB, bool RVF, bool FULL, int NR, int NF>
+__device__ __forceinline__ void mle_list(const Coef<NB> &c, const double (&R)[NR],
+                                         const double (&F0)[NF], LdsColumn Fc,
+                                         const StarPrep &sp, const DevParams &p, double av,
+                                         double rv, const double *__restrict__ tbl, Mle &o) {
+    constexpr int LV = FULL ? 2 : RVF ? 0 : 1;
+    if constexpr (wide_bands(NB)) mle_wide<NB, LV>(c, sp, p, av, rv, tbl, Fc, o);
+    else if constexpr (RVF) mle_fast_rf<NB, true, LV>(c, R, F0, sp, p, av, tbl, o);
+    else mle_fast<NB, true, LV>(c, F0, sp, p, av, rv, tbl, o);
 }
 
 // F0 of model i from the band-major table (coalesced) / of one model from its row.
@@ -751,7 +920,7 @@ struct RecPlanes {
 // M = max final lnprob.  Entries at or beyond the record capacity are skipped (the host
 // sees ncand > capacity and reports BRUTUS_ENOMEM).
 template <int NB, bool RVF, bool FIRST>
-__global__ void __launch_bounds__(TILE, 2)
+__global__ void __launch_bounds__(TILE, list_waves(NB))
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
         const int32_t *__restrict__ k2state, const int32_t *__restrict__ cand_idx,
@@ -768,6 +937,9 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
+    constexpr bool WIDE = wide_bands(NB);
+    __shared__ double s_F[WIDE ? NB * TILE : 1];        // the lanes' flux columns (mle_wide)
+    const LdsColumn Fc = (LdsColumn)s_F + (WIDE ? threadIdx.x : 0);
     // (the launch kind is a template parameter: the opening launch then carries no
     // state-reload path and its two iterations unroll)
     constexpr int niter = FIRST ? 2 : 1;
@@ -812,22 +984,23 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
         if (go) {
             Coef<NB> c;
             gather_coef<NB>(grid, nmodel_pad, i, c);
-            double F0[NB];
+            double F0[WIDE ? 1 : NB];
             // (table-driven in both instantiations: the general kernel ran the table-free
             // degree-13 form until round 3 -- 19 instead of 15 operations per exponential --
             // for the sake of registers it turned out not to need: 215 -> 223 VGPRs, still
             // two waves per SIMD, k_fflux 1.12 -> 1.00 ms per 128 stars on configs[2])
-            compute_F0_tbl<NB>(c, s_tbl, F0);
+            if constexpr (!WIDE) compute_F0_tbl<NB>(c, s_tbl, F0);
             double av, rv, step, lnl_old;
-            double R[RVF ? NB : 1];
-            if constexpr (RVF) coef_R<NB>(c, p.rv_mean, R);
+            double R[RVF && !WIDE ? NB : 1];
+            if constexpr (RVF && !WIDE) coef_R<NB>(c, p.rv_mean, R);
             if constexpr (FIRST) {
                 av = p.av_mean;
                 rv = p.rv_mean;
                 const int K = k1[s];
                 if constexpr (RVF) {
                     GramR G;
-                    gram_init_rf<NB>(c, R, sp, G);
+                    if constexpr (WIDE) gram_init_rf_wide<NB>(c, p.rv_mean, sp, G);
+                    else gram_init_rf<NB>(c, R, sp, G);
                     // (a single sweep would do, see k_k1probe; the loop form keeps this
                     // kernel's register allocation below the spill line)
                     for (int k = 0; k < K; ++k) {
@@ -850,8 +1023,7 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 step = step_st[q];
                 lnl_old = -0.5 * r_chi2[q];
             }
-            if constexpr (RVF) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
-            else mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+            mle_list<NB, RVF, false>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
             if constexpr (FIRST) {
                 go = cull_stat(sp, m) > thr_cull[s];
                 if (go) surv32[o] = surv_tag(q - cand_off[s]);     // a failed candidate keeps its lnprob~
@@ -864,14 +1036,19 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
                 av += dav;
                 if constexpr (RVF) {
                     // the Rv step is clamped to zero; only the stored MLE needs the Rv sums
-                    if (it + 1 < niter) mle_fast_rf<NB, true, false>(c, R, F0, sp, p, av, s_tbl, m);
-                    else mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+                    if (it + 1 < niter) mle_list<NB, RVF, false>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
+                    else mle_list<NB, RVF, true>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
                 } else {
                     double drv = (m.r_num + (p.rv_mean - rv) * p.rv_ivar) / (m.r_ss + p.rv_ivar) * step;
                     if (drv < p.rvmin - rv) drv = p.rvmin - rv;
                     if (drv > p.rvmax - rv) drv = p.rvmax - rv;
                     rv += drv;
-                    mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                    // (16 bands: the opening kernel, at the edge of the register file, spills 420
+                    // bytes with a shorter evaluation of its own for the first iteration
+                    // -- 1.29 -> 3.28 ms -- and keeps the one full form)
+                    constexpr bool SHORT_FIRST = NB != 16;
+                    if (SHORT_FIRST && it + 1 < niter) mle_list<NB, RVF, false>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
+                    else mle_list<NB, RVF, true>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
                 }
                 lnl_new = -0.5 * m.chi2;
                 dl = fabs(lnl_new - lnl_old);
@@ -1076,7 +1253,7 @@ k_rec_index(int64_t nmodel, int ntile, int nstar, const unsigned long long *__re
 // ncand + list position: every record plane receives full lines.  Persistent workgroups
 // over chunk-major work items like k_fflux; no barrier in the loop.
 template <int NB, bool RVF>
-__global__ void __launch_bounds__(TILE, 2)
+__global__ void __launch_bounds__(TILE, list_waves(NB))
 k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
          const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
          const int32_t *__restrict__ der_idx, const int32_t *__restrict__ wbase,
@@ -1085,6 +1262,9 @@ k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
     __syncthreads();
+    constexpr bool WIDE = wide_bands(NB);
+    __shared__ double s_F[WIDE ? NB * TILE : 1];
+    const LdsColumn Fc = (LdsColumn)s_F + (WIDE ? threadIdx.x : 0);
     auto lane_model = [&](int item) -> int32_t {
         if (item < 0) return 0;
         const ItemGeom ig = items[item];
@@ -1133,18 +1313,22 @@ k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
         Mle m;
         if (wave_live) {
             const StarPrep &sp = stars[s];
-            double F0[NB];
-            compute_F0_tbl<NB>(c, s_tbl, F0);
+            double F0[WIDE ? 1 : NB];
+            if constexpr (!WIDE) compute_F0_tbl<NB>(c, s_tbl, F0);
             double av = p.av_mean, rv = p.rv_mean;
             const int K = k1[s];
             if constexpr (RVF) {
-                double R[NB];
-                coef_R<NB>(c, rv, R);
+                double R[WIDE ? 1 : NB];
                 GramR G;
-                gram_init_rf<NB>(c, R, sp, G);
+                if constexpr (WIDE) {
+                    gram_init_rf_wide<NB>(c, rv, sp, G);
+                } else {
+                    coef_R<NB>(c, rv, R);
+                    gram_init_rf<NB>(c, R, sp, G);
+                }
                 double a_, c_;
                 if (K > 0) gram_sweep_rf(G, sp.S, p, av, a_, c_);       // one solve is exact (see k_k1probe)
-                mle_fast_rf<NB, true, true>(c, R, F0, sp, p, av, s_tbl, m);
+                mle_list<NB, true, true>(c, R, F0, Fc, sp, p, av, rv, s_tbl, m);
             } else {
                 Gram G;
                 gram_init<NB>(c, sp, G);
@@ -1152,7 +1336,8 @@ k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
                     double a_, b_, c_;
                     gram_sweep(G, sp.S, p, av, rv, a_, b_, c_);
                 }
-                mle_fast<NB, true>(c, F0, sp, p, av, rv, s_tbl, m);
+                const double R1[1] = {0.};
+                mle_list<NB, false, true>(c, R1, F0, Fc, sp, p, av, rv, s_tbl, m);
             }
             o_lnl = final_lnl<RVF>(sp, p, m.chi2, false);
             o_av = av;

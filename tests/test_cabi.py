@@ -69,6 +69,12 @@ def test_hot_kernels_do_not_spill():
     assert len(hot) >= 20, sorted(ks)[:10]
     bad = {n: ks[n] for n in hot if ks[n]["scratch"] != 0 or ks[n]["vgpr"] > 256}
     assert not bad, bad
+    # 24 / 32 bands: built for one workgroup per CU (512 registers); what is left in scratch
+    # stays small -- at two workgroups these kernels carried 500-1700 bytes and ran 3-4x slower
+    wide = [n for n in ks if re.match(r"k_(fflux|derive|sel_band)<(24|32),", n)]
+    assert len(wide) >= 16
+    bad = {n: ks[n] for n in wide if ks[n]["scratch"] > 128}
+    assert not bad, bad
     # occupancy steps the measurements in DESIGN.md rest on: four waves per SIMD for the
     # float32 pass, two for the float64 list kernels
     assert ks["k_pre32<12, true, 4>"]["vgpr"] <= 128 and ks["k_pre32<12, false, 4>"]["vgpr"] <= 128
