@@ -109,12 +109,17 @@ SIGNATURES = {
     "brutus_debug_copy": (C.c_int, [_vp, _sz, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "brutus_debug_sizeof_star32": (C.c_int, []),
     "brutus_cluster_points": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "brutus_cluster_points_grid": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "brutus_offsets_weights": (C.c_int, [_i32, _i32, _i32, _i64] + [_vp] * 12 + [_i32, _vp, _vp, _vp]),
     "brutus_offsets_workspace_bytes": (C.c_size_t, [_i32, _i32]),
     "brutus_offsets_bootstrap": (C.c_int, [_i32] * 6 + [_vp] * 7 + [C.c_size_t, _vp, _vp]),
     "brutus_cluster_workspace_bytes": (_sz, [_i32]),
     "brutus_cluster_lnl": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                      _vp, _i32, _vp, _sz, _vp, _vp]),
+    "brutus_cluster_chunks": (C.c_int, []),
+    "brutus_cluster_lnl_part": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                          _vp, _i32, _vp, _sz, _i32, _i32, _vp]),
+    "brutus_cluster_lnl_merge": (C.c_int, [_i32, _i32, _vp, _sz, _vp, _vp]),
 }
 
 

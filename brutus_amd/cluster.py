@@ -184,32 +184,45 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     with torch.cuda.device(dev):
         up = lambda a, dt=np.float64: torch.from_numpy(
             np.ascontiguousarray(a, dtype=dt)).to(dev)
+        # ---- the objects' side of the kernel, on its way before the plug-in is asked ----
+        t_ln = None
+        if np.all(Xb == 1.):
+            t_d, t_iv, t_ln = ds.t_d, ds.t_iv, ds.t_ln0
+        else:                                  # multiplicative offsets (cluster.py:327-333)
+            phot_t, err_t = phot * Xb, err * Xb
+            with np.errstate(all="ignore"):
+                ivar = np.where(ds.phot_mask, 1. / err_t ** 2, 0.)
+                lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + ds.lnorm_p
+            t_d, t_iv = up(np.where(ds.phot_mask, phot_t, 0.)), up(ivar)
+            t_ln = up(lnorm)
+        ds.h_cp.numpy()[...] = chi2_p
+        t_cp = ds.t_cp.copy_(ds.h_cp, non_blocking=True)
+        stream = _stream_ptr(torch)
+        ws, ws_n = ds.ws.data_ptr(), ds.ws.numel()
+        obj_args = (t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
+                    ds.t_n.data_ptr(), 1 if dim_prior else 0, ws, ws_n)
+
+        def part(t_flux, t_lnw, npts, chunk_lo, chunk_n):
+            """The sum over `npts` points as partials in chunks [chunk_lo, chunk_lo + chunk_n)."""
+            _lib.check(L.brutus_cluster_lnl_part(
+                Nobjs, Nbands, npts, t_flux.data_ptr() if npts else None,
+                t_lnw.data_ptr() if npts else None, *obj_args, chunk_lo, chunk_n, stream))
+
         # ---- isochrone points of every SMF slice (cluster.py:336-366) -------------
-        tab = _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf,
-                           eep_grid, mini_bound, eep_binary_max, Nbands, dev, torch, L, up,
-                           cache)
+        tab, nchunk = _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid,
+                                   grad_smf, eep_grid, mini_bound, eep_binary_max, Nbands, dev,
+                                   torch, L, up, cache, part)
         if tab is None:
             lnl = np.full(Nobjs, -np.inf)
         else:
-            t_flux, t_lnw = tab
-            t_ln = None
-            if np.all(Xb == 1.):
-                t_d, t_iv, t_ln = ds.t_d, ds.t_iv, ds.t_ln0
-            else:                                  # multiplicative offsets (cluster.py:327-333)
-                phot_t, err_t = phot * Xb, err * Xb
-                with np.errstate(all="ignore"):
-                    ivar = np.where(ds.phot_mask, 1. / err_t ** 2, 0.)
-                    lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + ds.lnorm_p
-                t_d, t_iv = up(np.where(ds.phot_mask, phot_t, 0.)), up(ivar)
-            ds.h_cp.numpy()[...] = chi2_p
-            t_cp = ds.t_cp.copy_(ds.h_cp, non_blocking=True)
-            if t_ln is None:
-                t_ln = up(lnorm)
-            _lib.check(L.brutus_cluster_lnl(
-                Nobjs, Nbands, t_lnw.numel(), t_flux.data_ptr(), t_lnw.data_ptr(),
-                t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
-                ds.t_n.data_ptr(), 1 if dim_prior else 0, ds.ws.data_ptr(), ds.ws.numel(),
-                ds.out.data_ptr(), _stream_ptr(torch)))
+            if nchunk:      # the pieces were summed while the plug-in worked on the next one
+                _lib.check(L.brutus_cluster_lnl_merge(Nobjs, nchunk, ws, ws_n,
+                                                      ds.out.data_ptr(), stream))
+            else:           # a table met before
+                t_flux, t_lnw = tab
+                _lib.check(L.brutus_cluster_lnl(
+                    Nobjs, Nbands, t_lnw.numel(), t_flux.data_ptr(), t_lnw.data_ptr(),
+                    *obj_args, ds.out.data_ptr(), stream))
             ds.h_out.copy_(ds.out, non_blocking=True)
             torch.cuda.current_stream().synchronize()
             lnl = ds.h_out.numpy()
@@ -322,12 +335,28 @@ def _staging(nrow, nb, dev, torch):
     return st
 
 
+# The plug-in is asked for a few secondary-mass-fraction slices at a time; while it works on
+# the next group the device turns the previous one into fluxes and sums it (a group = one
+# host -> device copy from page-locked memory and two launches).  Measured with the synthetic
+# table plug-in of the benchmark (0.27 ms for all 15 slices; device 0.4 ms per call), whole
+# calls per second: 1 group 1 206, 2 groups 1 300, 3 groups 1 255, 5 groups 1 096 -- every
+# group costs the host ~0.03 ms (one more plug-in call, copy, two launches), and the device
+# chain, not the plug-in, is the longer one from 2 groups on.  A plug-in that takes
+# milliseconds per slice (the MIST / neural-net isochrones) hides the device entirely with
+# any number of groups > 1; BRUTUS_CLUSTER_PIPELINE sets it.
+_PIPELINE_GROUPS = 2
+
+
 def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf, eep_grid,
-                 mini_bound, eep_binary_max, Nbands, dev, torch, L, up, cache):
+                 mini_bound, eep_binary_max, Nbands, dev, torch, L, up, cache, part):
     """Device-resident isochrone points `(flux (Npts, Nbands), lnw (Npts))` of all
     secondary-mass-fraction slices, or None if no slice has a usable point
-    (cluster.py:336-366).  The plug-in's magnitudes go to the device as they are;
-    `brutus_cluster_points` turns them into fluxes and drops the all-NaN points."""
+    (cluster.py:336-366), and the number of partial-sum chunks filled on the way: a table
+    met before comes back from the cache with 0 chunks (the caller sums it in one go), a new
+    one is built group by group -- the plug-in's magnitudes go to the device as they are,
+    `brutus_cluster_points` turns them into fluxes and drops the all-NaN points, `part`
+    (brutus_cluster_lnl_part) sums the group into its share of the chunks."""
+    import os
     from .fitting import _stream_ptr
     key = (id(isochrone), getattr(isochrone, "cache_token", None), feh, loga, av, rv, dist,
            None if corr_coef is None else tuple(corr_coef), smf_grid.tobytes(),
@@ -335,70 +364,115 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     if cache:
         tab = _lru_get(_TABLE_CACHE, key)
         if tab is not None:
-            return tab[0]
+            return tab[0], 0
     kw = dict(feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, dist=dist,
               mini_bound=mini_bound, eep_binary_max=eep_binary_max, corr_params=corr_coef)
     nsmf, neep = len(smf_grid), len(eep_grid)
+    nrow = nsmf * neep
+    ngroup = max(1, min(nsmf, int(os.environ.get("BRUTUS_CLUSTER_PIPELINE", _PIPELINE_GROUPS))))
+    nchunk = L.brutus_cluster_chunks()
+    stage = _staging(nrow, Nbands, dev, torch)
+    h_mags = stage.h_mags.numpy().reshape(nsmf, neep, Nbands)
+    h_lnw = stage.h_lnw.numpy().reshape(nsmf, neep)
+    grid_hook = hasattr(isochrone, "get_seds_grid")
+    if grid_hook and stage.hook_out.get(type(isochrone)) is None:   # does the hook take `out=`?
+        import inspect
+        stage.hook_out[type(isochrone)] = \
+            "out" in inspect.signature(isochrone.get_seds_grid).parameters
+    if cache:      # a cached table keeps its tensors; without the cache one pair is reused
+        t_flux = torch.empty((nrow, Nbands), dtype=torch.float64, device=dev)
+        t_lnw = torch.empty(nrow, dtype=torch.float64, device=dev)
+    else:
+        if getattr(stage, "t_flux", None) is None:
+            stage.t_flux = torch.empty((nrow, Nbands), dtype=torch.float64, device=dev)
+            stage.t_lnw = torch.empty(nrow, dtype=torch.float64, device=dev)
+        t_flux, t_lnw = stage.t_flux, stage.t_lnw
+    if stage.src is None or len(stage.src) != ngroup or tuple(stage.h_lng.shape) != (ngroup, neep):
+        stage.src, stage.t_src, stage.srckey = [None] * ngroup, [None] * ngroup, [None] * ngroup
+        stage.h_lng = torch.empty((ngroup, neep), dtype=torch.float64).pin_memory()
+        stage.d_lng = torch.empty((ngroup, neep), dtype=torch.float64, device=dev)
+    smfkey = smf_grid.tobytes()
+    if getattr(stage, "smfkey", None) != smfkey:
+        with np.errstate(all="ignore"):
+            stage.smfkey, stage.d_lnsmf = smfkey, up(np.log(grad_smf))
+    d_lnsmf, mini0, d_lng, posb, pos = stage.d_lnsmf, None, None, None, None
+    late = eep_grid > eep_binary_max                    # evolved stars: first slice only
+    lateb = late.tobytes()
+    ln_gsmf = np.log(grad_smf)
+    stream = _stream_ptr(torch)
+    off = 0
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
-        stage = _staging(nsmf * neep, Nbands, dev, torch)
-        h_mags = stage.h_mags.numpy().reshape(nsmf, neep, Nbands)
-        if hasattr(isochrone, "get_seds_grid"):
-            if stage.hook_out.get(type(isochrone)) is None:     # does the hook take `out=`?
-                import inspect
-                stage.hook_out[type(isochrone)] = \
-                    "out" in inspect.signature(isochrone.get_seds_grid).parameters
-            if stage.hook_out[type(isochrone)]:                 # straight into pinned memory
-                mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid, out=h_mags, **kw)
+        for g in range(ngroup):
+            a, b = nsmf * g // ngroup, nsmf * (g + 1) // ngroup
+            c0, c1 = nchunk * g // ngroup, nchunk * (g + 1) // ngroup
+            if grid_hook:
+                if stage.hook_out[type(isochrone)]:             # straight into pinned memory
+                    mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid[a:b], out=h_mags[a:b],
+                                                         **kw)
+                else:
+                    mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid[a:b], **kw)
+                mags = np.asarray(mags, dtype=np.float64)
+                mini = np.asarray(mini, dtype=np.float64)
+                if not np.shares_memory(mags, h_mags):
+                    h_mags[a:b] = mags
             else:
-                mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid, **kw)
-            mags = np.asarray(mags, dtype=np.float64)
-            mini = np.asarray(mini, dtype=np.float64)
-        else:
-            mags = h_mags
-            mini = np.empty((nsmf, neep))
-            for i, smf in enumerate(smf_grid):
-                seds, params, _ = isochrone.get_seds(smf=smf, **kw)
-                mags[i] = seds
-                mini[i] = params['mini']
-        # the one sizeable host -> device copy of a call starts now, from page-locked
-        # memory, and runs under the host arithmetic below
-        if mags is not h_mags:
-            h_mags[...] = mags
-        stage.d_mags.copy_(stage.h_mags, non_blocking=True)
-        late = eep_grid > eep_binary_max                    # evolved stars: first slice only
-        if mini.ndim == 1:      # one mass grid for all slices: 2 000 logarithms, not 30 000
-            gmini = np.gradient(mini)
-            lng = np.where(gmini > 0., np.log(gmini), -np.inf)
-            keep = np.repeat((gmini > 0.)[None, :], nsmf, axis=0)
-            lnw = lng[None, :] + np.log(grad_smf)[:, None]
-        else:
-            gmini = np.gradient(mini, axis=1)
-            keep = gmini > 0.
-            lnw = np.where(keep, np.log(gmini) + np.log(grad_smf)[:, None], -np.inf)
-        keep[1:, late] = False
-        lnw[1:, late] = -np.inf
-    tab = None
-    src = np.flatnonzero(keep).astype(np.int32)
-    if src.size:
-        stage.h_lnw.numpy()[...] = lnw.reshape(-1)
-        stage.d_lnw.copy_(stage.h_lnw, non_blocking=True)
-        if stage.src is None or not np.array_equal(stage.src, src):
-            stage.src, stage.t_src = src, up(src, np.int32)     # the kept rows rarely change
-        t_src = stage.t_src
-        if cache:      # a cached table keeps its tensors; without the cache one pair is reused
-            t_flux = torch.empty((src.size, Nbands), dtype=torch.float64, device=dev)
-            t_lnw = torch.empty(src.size, dtype=torch.float64, device=dev)
-        else:
-            if getattr(stage, "t_flux", None) is None:
-                stage.t_flux = torch.empty((nsmf * neep, Nbands), dtype=torch.float64, device=dev)
-                stage.t_lnw = torch.empty(nsmf * neep, dtype=torch.float64, device=dev)
-            t_flux, t_lnw = stage.t_flux[:src.size], stage.t_lnw[:src.size]
-        _lib.check(L.brutus_cluster_points(src.size, Nbands, t_src.data_ptr(),
-                                           stage.d_mags.data_ptr(), stage.d_lnw.data_ptr(),
-                                           t_flux.data_ptr(), t_lnw.data_ptr(),
-                                           _stream_ptr(torch)))
-        tab = (t_flux, t_lnw)
+                mini = np.empty((b - a, neep))
+                for i in range(a, b):
+                    seds, params, _ = isochrone.get_seds(smf=smf_grid[i], **kw)
+                    h_mags[i] = seds
+                    mini[i - a] = params['mini']
+            # the group's host -> device copy starts now, from page-locked memory, and runs
+            # under the host arithmetic below
+            stage.d_mags[a * neep:b * neep].copy_(stage.h_mags[a * neep:b * neep], non_blocking=True)
+            if mini.ndim == 1:
+                # one mass grid for all slices: 2 000 logarithms per call, the (slice, EEP) table
+                # of weights is formed on the device and the kept rows are looked up, not rebuilt
+                if mini0 is None or not (mini is mini0 or np.array_equal(mini, mini0)):
+                    mini0 = mini
+                    gmini = np.gradient(mini)
+                    pos = gmini > 0.
+                    h_lng = stage.h_lng.numpy()[g]
+                    h_lng[...] = -np.inf
+                    np.log(gmini, out=h_lng, where=pos)
+                    d_lng = stage.d_lng[g]
+                    d_lng.copy_(stage.h_lng[g], non_blocking=True)
+                    posb = pos.tobytes()
+                srckey = (posb, a, b, lateb)
+                if stage.srckey[g] != srckey:
+                    keep = np.repeat(pos[None, :], b - a, axis=0)
+                    keep[(1 if a == 0 else 0):, late] = False        # (slice 0 keeps its evolved stars)
+                    src = (np.flatnonzero(keep) + a * neep).astype(np.int32)
+                    stage.src[g], stage.t_src[g], stage.srckey[g] = src, up(src, np.int32), srckey
+                n = stage.src[g].size
+                if n:
+                    _lib.check(L.brutus_cluster_points_grid(
+                        n, Nbands, neep, stage.t_src[g].data_ptr(), stage.d_mags.data_ptr(),
+                        d_lng.data_ptr(), d_lnsmf.data_ptr(), t_flux[off:].data_ptr(),
+                        t_lnw[off:].data_ptr(), stream))
+            else:
+                gmini = np.gradient(mini, axis=1)
+                keep = gmini > 0.
+                lnw = np.where(keep, np.log(gmini) + ln_gsmf[a:b, None], -np.inf)
+                first = 1 if a == 0 else 0                  # (slice 0 keeps its evolved stars)
+                keep[first:, late] = False
+                lnw[first:, late] = -np.inf
+                src = (np.flatnonzero(keep) + a * neep).astype(np.int32)
+                n = src.size
+                if n:
+                    h_lnw[a:b] = lnw
+                    stage.d_lnw[a * neep:b * neep].copy_(stage.h_lnw[a * neep:b * neep],
+                                                         non_blocking=True)
+                    if stage.src[g] is None or not np.array_equal(stage.src[g], src):
+                        stage.src[g], stage.t_src[g] = src, up(src, np.int32)   # (rarely changes)
+                    stage.srckey[g] = None
+                    _lib.check(L.brutus_cluster_points(
+                        n, Nbands, stage.t_src[g].data_ptr(), stage.d_mags.data_ptr(),
+                        stage.d_lnw.data_ptr(), t_flux[off:].data_ptr(), t_lnw[off:].data_ptr(),
+                        stream))
+            part(t_flux[off:off + n], t_lnw[off:off + n], n, c0, c1 - c0)
+            off += n
+    tab = (t_flux[:off], t_lnw[:off]) if off else None
     if cache:      # (the plug-in object is kept alive with its tables: `id` stays unique)
         _lru_put(_TABLE_CACHE, key, (tab, isochrone), _TABLE_CACHE_MAX)
-    return tab
+    return tab, nchunk

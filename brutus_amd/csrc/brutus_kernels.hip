@@ -1302,28 +1302,32 @@ size_t brutus_cluster_workspace_bytes(int nobj) {
     return 2 * align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS);
 }
 
-int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
-                       const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
-                       const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
-                       int dim_prior, void *d_workspace, size_t workspace_bytes, double *d_lnl,
-                       void *stream) {
+int brutus_cluster_chunks(void) { return CLUSTER_CHUNKS; }
+
+int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                            const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
+                            const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
+                            int dim_prior, void *d_workspace, size_t workspace_bytes, int chunk_lo,
+                            int chunk_n, void *stream) {
     const int nb = padded_nb(nfilt);
-    if (nobj <= 0 || npts <= 0 || nb < 0)
+    if (nobj <= 0 || npts < 0 || nb < 0)
         return fail(BRUTUS_EINVAL, "bad cluster dimensions (nobj=%d, npts=%d, nfilt=%d)", nobj,
                     npts, nfilt);
-    if (!d_pts_flux || !d_pts_lnw || !d_phot || !d_ivar || !d_chi2_p || !d_lnorm || !d_ndim ||
-        !d_workspace || !d_lnl)
+    if (chunk_lo < 0 || chunk_n < 1 || chunk_lo + chunk_n > CLUSTER_CHUNKS)
+        return fail(BRUTUS_EINVAL, "bad chunk range [%d, %d) of %d", chunk_lo, chunk_lo + chunk_n,
+                    CLUSTER_CHUNKS);
+    if ((npts > 0 && (!d_pts_flux || !d_pts_lnw)) || !d_phot || !d_ivar || !d_chi2_p ||
+        !d_lnorm || !d_ndim || !d_workspace)
         return fail(BRUTUS_EINVAL, "NULL device pointer");
     if (workspace_bytes < brutus_cluster_workspace_bytes(nobj))
         return fail(BRUTUS_ENOMEM, "cluster workspace too small");
-    double *pm = (double *)d_workspace;
-    double *ps = (double *)((char *)d_workspace + align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS));
+    double *pm = (double *)d_workspace + (size_t)chunk_lo * nobj;
+    double *ps = (double *)((char *)d_workspace + align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS)) +
+                 (size_t)chunk_lo * nobj;
     hipStream_t st = (hipStream_t)stream;
-    static const int want_chunks = env_int("BRUTUS_CLUSTER_CHUNKS", CLUSTER_CHUNKS);
-    const int use_chunks = want_chunks < 1 ? 1 : (want_chunks > CLUSTER_CHUNKS ? CLUSTER_CHUNKS : want_chunks);
-    const int ppb = (npts + use_chunks - 1) / use_chunks;
-    const int nchunk = (npts + ppb - 1) / ppb;
-    const dim3 g((nobj + CL_T - 1) / CL_T, nchunk);
+    // every chunk of the range is written: one without points holds (-inf, 0)
+    const int ppb = npts > 0 ? (npts + chunk_n - 1) / chunk_n : 1;
+    const dim3 g((nobj + CL_T - 1) / CL_T, chunk_n);
     Timer tm(st);
     tm.begin("k_cluster");
 #define BRUTUS_CL(N)                                                                              \
@@ -1343,11 +1347,39 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
     }
 #undef BRUTUS_CL
     tm.end();
-    hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + CM_O - 1) / CM_O), dim3(CM_O * CM_J), 0, st, nobj,
-                       nchunk, pm, ps, d_lnl);
     HIP_TRY(hipGetLastError());
     tm.collect();
     return 0;
+}
+
+int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t workspace_bytes,
+                             double *d_lnl, void *stream) {
+    if (nobj <= 0 || nchunk < 1 || nchunk > CLUSTER_CHUNKS || !d_workspace || !d_lnl)
+        return fail(BRUTUS_EINVAL, "bad cluster merge (nobj=%d, nchunk=%d)", nobj, nchunk);
+    if (workspace_bytes < brutus_cluster_workspace_bytes(nobj))
+        return fail(BRUTUS_ENOMEM, "cluster workspace too small");
+    double *pm = (double *)d_workspace;
+    double *ps = (double *)((char *)d_workspace + align_up(sizeof(double) * (size_t)nobj * CLUSTER_CHUNKS));
+    hipLaunchKernelGGL(k_cluster_merge, dim3((nobj + CM_O - 1) / CM_O), dim3(CM_O * CM_J), 0,
+                       (hipStream_t)stream, nobj, nchunk, pm, ps, d_lnl);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                       const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
+                       const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
+                       int dim_prior, void *d_workspace, size_t workspace_bytes, double *d_lnl,
+                       void *stream) {
+    if (npts <= 0) return fail(BRUTUS_EINVAL, "bad cluster dimensions (npts=%d)", npts);
+    if (!d_lnl) return fail(BRUTUS_EINVAL, "NULL device pointer");
+    static const int want_chunks = env_int("BRUTUS_CLUSTER_CHUNKS", CLUSTER_CHUNKS);
+    const int use_chunks = want_chunks < 1 ? 1 : (want_chunks > CLUSTER_CHUNKS ? CLUSTER_CHUNKS : want_chunks);
+    const int rc = brutus_cluster_lnl_part(nobj, nfilt, npts, d_pts_flux, d_pts_lnw, d_phot, d_ivar,
+                                           d_chi2_p, d_lnorm, d_ndim, dim_prior, d_workspace,
+                                           workspace_bytes, 0, use_chunks, stream);
+    if (rc) return rc;
+    return brutus_cluster_lnl_merge(nobj, use_chunks, d_workspace, workspace_bytes, d_lnl, stream);
 }
 
 int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const double *d_mags,
@@ -1356,8 +1388,22 @@ int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const d
     if (npts <= 0 || nfilt <= 0) return fail(BRUTUS_EINVAL, "bad point-table dimensions");
     if (!d_mags || !d_lnw_in || !d_pts_flux || !d_pts_lnw) return fail(BRUTUS_EINVAL, "NULL device pointer");
     hipLaunchKernelGGL(k_cluster_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0,
-                       (hipStream_t)stream, npts, nfilt, d_src, d_mags, d_lnw_in, d_pts_flux,
-                       d_pts_lnw);
+                       (hipStream_t)stream, npts, nfilt, d_src, d_mags, d_lnw_in, 0,
+                       (const double *)nullptr, d_pts_flux, d_pts_lnw);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_cluster_points_grid(int64_t npts, int nfilt, int neep, const int32_t *d_src,
+                               const double *d_mags, const double *d_lnw_eep,
+                               const double *d_lnw_smf, double *d_pts_flux, double *d_pts_lnw,
+                               void *stream) {
+    if (npts <= 0 || nfilt <= 0 || neep <= 0) return fail(BRUTUS_EINVAL, "bad point-table dimensions");
+    if (!d_mags || !d_lnw_eep || !d_lnw_smf || !d_pts_flux || !d_pts_lnw)
+        return fail(BRUTUS_EINVAL, "NULL device pointer");
+    hipLaunchKernelGGL(k_cluster_points, dim3((unsigned)((npts + 255) / 256)), dim3(256), 0,
+                       (hipStream_t)stream, npts, nfilt, d_src, d_mags, d_lnw_eep, neep, d_lnw_smf,
+                       d_pts_flux, d_pts_lnw);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -128,9 +128,12 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
 // as does one the host marked so.  Replaces fifteen host-side 10**x passes per call.
 // `src` (may be null = identity) lists the table rows the host kept, in order: the
 // output is the compact point list.
+// `neep` > 0: the weight of table row r is lnw_in[r % neep] + lnw_smf[r / neep] -- one
+// initial-mass grid for all slices (ln d mini per EEP, ln d smf per slice) --, else lnw_in[r].
 __global__ void k_cluster_points(int64_t npts, int nb, const int32_t *__restrict__ src,
                                  const double *__restrict__ mags,
-                                 const double *__restrict__ lnw_in, double *__restrict__ flux,
+                                 const double *__restrict__ lnw_in, int neep,
+                                 const double *__restrict__ lnw_smf, double *__restrict__ flux,
                                  double *__restrict__ lnw) {
     const int64_t c = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= npts) return;
@@ -141,7 +144,8 @@ __global__ void k_cluster_points(int64_t npts, int nb, const int32_t *__restrict
         any = any || isfinite(m);
         flux[c * nb + b] = exp10(-0.4 * m);
     }
-    lnw[c] = any ? lnw_in[r] : -INFINITY;
+    const double w = neep > 0 ? lnw_in[r % neep] + lnw_smf[r / neep] : lnw_in[r];
+    lnw[c] = any ? w : -INFINITY;
 }
 
 // Merge of the per-chunk (max, sum) pairs of every object.  Lane (o, j), j < CM_J, folds the

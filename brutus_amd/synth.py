@@ -198,7 +198,10 @@ class TableIsochrone(object):
         eep = self.eep_grid if eep is None else np.asarray(eep, dtype=float)
         if eep is self.eep_grid or (eep.shape == self.eep_grid.shape
                                     and np.array_equal(eep, self.eep_grid)):
-            base = self._stack if ks == list(range(len(self.mags))) else self._stack[ks]
+            if ks == list(range(ks[0], ks[0] + len(ks))):       # consecutive slices: a view
+                base = self._stack[ks[0]:ks[0] + len(ks)]
+            else:
+                base = self._stack[ks]
             mini = self.mini
         else:
             base = np.empty((len(ks), eep.size, self.rvec.size))

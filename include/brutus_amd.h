@@ -289,6 +289,14 @@ int brutus_set_mt_jump(const uint32_t *h_polys, int npoly, int64_t stride0,
 int brutus_cluster_points(int64_t npts, int nfilt, const int32_t *d_src, const double *d_mags,
                           const double *d_lnw_in, double *d_pts_flux, double *d_pts_lnw,
                           void *stream);
+/* The same where all slices share one initial-mass grid (the reference's isochrones do:
+ * `mini` depends on EEP, [Fe/H] and age, not on the mass fraction): the weight of table row
+ * r is d_lnw_eep[r % neep] + d_lnw_smf[r / neep] = ln(d mini) + ln(d smf) (-inf for an EEP
+ * the caller drops), formed here instead of in a host array of nrow values per call. */
+int brutus_cluster_points_grid(int64_t npts, int nfilt, int neep, const int32_t *d_src,
+                               const double *d_mags, const double *d_lnw_eep,
+                               const double *d_lnw_smf, double *d_pts_flux,
+                               double *d_pts_lnw, void *stream);
 size_t brutus_cluster_workspace_bytes(int nobj);
 int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        const double *d_pts_lnw, const double *d_phot,
@@ -296,6 +304,23 @@ int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        const double *d_lnorm, const int32_t *d_ndim,
                        int dim_prior, void *d_workspace, size_t workspace_bytes,
                        double *d_lnl, void *stream);
+/* The same in pieces, for a caller that gets the isochrone points a few slices at a time
+ * (the reference asks its plug-in once per secondary-mass-fraction slice, cluster.py:346-366)
+ * and wants the device to work on one piece while the host prepares the next: the sum over
+ * points is kept as brutus_cluster_chunks() partial (max, sum) pairs per object in the
+ * workspace; `_part` fills the chunks [chunk_lo, chunk_lo + chunk_n) from ITS npts points
+ * (npts = 0: they hold "no point"), `_merge` folds the first nchunk chunks into d_lnl.
+ * brutus_cluster_lnl = one `_part` over all chunks + `_merge`.  Every chunk below nchunk
+ * must have been filled by a `_part` call on the same stream. */
+int brutus_cluster_chunks(void);
+int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                            const double *d_pts_lnw, const double *d_phot,
+                            const double *d_ivar, const double *d_chi2_p,
+                            const double *d_lnorm, const int32_t *d_ndim, int dim_prior,
+                            void *d_workspace, size_t workspace_bytes, int chunk_lo,
+                            int chunk_n, void *stream);
+int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t workspace_bytes,
+                             double *d_lnl, void *stream);
 
 /* ---- utils.photometric_offsets (reference utils.py:1218-1400) ------------------------
  * The per-band bootstrap of model / data flux ratios over the resampled fits of many

@@ -168,6 +168,85 @@ def test_batched_plugin_hook_and_caches_change_nothing():
     assert abs(v1[0] - v0[0]) > 1e-3 and relerr(v1_ref[1], v1[1]) < 1e-12
 
 
+@pytest.mark.gpu
+def test_pipelined_groups_change_nothing(monkeypatch):
+    """The point table is built and summed a few mass-fraction slices at a time
+    (`brutus_cluster_lnl_part` per group, `brutus_cluster_lnl_merge` at the end) while the
+    plug-in works on the next group: 1, 2, 3, 4 and 15 groups, with and without the batched
+    hook, and the one-go sum of the cached table all give the same per-object values."""
+    from brutus_amd import cluster, synth
+
+    class NoHook(object):
+        def __init__(self, iso):
+            self.iso = iso
+
+        def get_seds(self, **kw):
+            return self.iso.get_seds(**kw)
+
+    iso = synth.TableIsochrone(nbands=12, neep=2000)
+    phot, err, par, perr = synth.make_cluster(iso, 900, seed=4)
+    kw = dict(parallax=par, parallax_err=perr, return_lnls=True)
+    monkeypatch.setenv("BRUTUS_CLUSTER_PIPELINE", "1")
+    ref = cluster.isochrone_loglike(THETA, iso, phot, err, cache=False, **kw)
+    for groups in (2, 3, 4, 15):
+        monkeypatch.setenv("BRUTUS_CLUSTER_PIPELINE", str(groups))
+        for plug in (iso, NoHook(iso)):
+            got = cluster.isochrone_loglike(THETA, plug, phot, err, cache=False, **kw)
+            assert relerr(ref[1], got[1]) < 1e-12, (groups, type(plug).__name__)
+        cluster.clear_caches()
+        first = cluster.isochrone_loglike(THETA, iso, phot, err, **kw)      # in pieces
+        again = cluster.isochrone_loglike(THETA, iso, phot, err, **kw)      # cached table, one go
+        assert relerr(ref[1], first[1]) < 1e-12 and relerr(ref[1], again[1]) < 1e-12
+    # an isochrone none of whose points survives the mass bound: -inf for every object
+    dead = cluster.isochrone_loglike(THETA, iso, phot, err, mini_bound=1e9, cache=False, **kw)
+    none = cluster.isochrone_loglike(THETA, iso, phot, err, mini_bound=1e9, cache=False,
+                                     **dict(kw, return_lnls=False))
+    assert np.all(np.isfinite(dead[1])) and dead[0] == none      # (the outlier term alone)
+
+
+@pytest.mark.gpu
+def test_cluster_lnl_in_parts_equals_one_call():
+    """C ABI: `brutus_cluster_lnl_part` over three uneven pieces of the point list (one of
+    them empty) + `brutus_cluster_lnl_merge` against one `brutus_cluster_lnl` call."""
+    import torch
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(8)
+    nobj, nb, npts = 700, 12, 5000
+    dev = torch.device("cuda:0")
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    flux = rng.uniform(0.5, 2., size=(npts, nb))
+    flux[rng.uniform(size=flux.shape) < 0.01] = np.nan
+    lnw = rng.normal(size=npts)
+    phot = rng.uniform(0.5, 2., size=(nobj, nb))
+    ivar = rng.uniform(100., 900., size=(nobj, nb)) * (rng.uniform(size=(nobj, nb)) > 0.1)
+    t = [up(flux), up(lnw), up(phot), up(ivar), up(rng.uniform(0., 3., nobj)),
+         up(rng.normal(size=nobj)), up(rng.randint(1, 14, nobj), np.int32)]
+    ws = torch.empty(L.brutus_cluster_workspace_bytes(nobj), dtype=torch.uint8, device=dev)
+    nchunk = L.brutus_cluster_chunks()
+    assert nchunk == 256
+    for dim_prior in (1, 0):
+        one = torch.empty(nobj, dtype=torch.float64, device=dev)
+        _lib.check(L.brutus_cluster_lnl(nobj, nb, npts, *[x.data_ptr() for x in t], dim_prior,
+                                        ws.data_ptr(), ws.numel(), one.data_ptr(), None))
+        one = one.cpu().numpy()
+        parts = torch.empty(nobj, dtype=torch.float64, device=dev)
+        for (a, b), (c0, c1) in zip(((0, 1700), (1700, 1700), (1700, npts)),
+                                    ((0, 100), (100, 101), (101, nchunk))):
+            _lib.check(L.brutus_cluster_lnl_part(
+                nobj, nb, b - a, t[0][a:].data_ptr() if b > a else None,
+                t[1][a:].data_ptr() if b > a else None, *[x.data_ptr() for x in t[2:]],
+                dim_prior, ws.data_ptr(), ws.numel(), c0, c1 - c0, None))
+        _lib.check(L.brutus_cluster_lnl_merge(nobj, nchunk, ws.data_ptr(), ws.numel(),
+                                              parts.data_ptr(), None))
+        torch.cuda.synchronize()
+        assert relerr(one, parts.cpu().numpy()) < 1e-13
+    with pytest.raises(ValueError, match="chunk range"):
+        _lib.check(L.brutus_cluster_lnl_part(
+            nobj, nb, 10, t[0].data_ptr(), t[1].data_ptr(), *[x.data_ptr() for x in t[2:]], 1,
+            ws.data_ptr(), ws.numel(), 250, 10, None))
+
+
 def test_cache_keys_follow_content_not_identity():
     """The cluster caches are keyed by address, layout and a digest of the CONTENT of the
     catalogue arrays (CPU-only check of the helpers): an in-place edit, a copy, a view with
