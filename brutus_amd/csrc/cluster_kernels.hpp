@@ -19,20 +19,36 @@ namespace {
 // and k is an integer, so the power is a square root and up to four multiplications
 // instead of a logarithm; only e^(-chi2/2) is tracked against a running maximum.
 constexpr int CL_T = 256;      // objects per workgroup: four waves share one staged sub-slice
+#ifndef BRUTUS_CL_U
+#define BRUTUS_CL_U 4
+#endif
+constexpr int CL_U = BRUTUS_CL_U;   // points per step of the online sum
+#ifndef BRUTUS_CL_OCC
+#define BRUTUS_CL_OCC 1
+#endif
+
+// A point whose term must not count -- weight 0: dropped by the caller, without a finite band, or
+// padding -- is staged with fluxes of DEAD_FLUX: its chi2 overflows and is clamped to CHI2_MAX
+// like any non-finite chi2, so that x = -chi2 / 2 can never become the running maximum and
+// e^x is 0.  With that every term T_u is finite and >= 0 and the loop needs no "is it finite"
+// selects (cluster.py:394 drops the non-finite terms; so does a factor e^-5e17).  CHI2_MAX to the
+// largest power the kernel takes (15.5: 33 measurements) stays finite.
+constexpr double CL_DEAD_FLUX = 1e150, CL_CHI2_MAX = 1e18;
 
 template <int NB>
-__global__ void __launch_bounds__(CL_T)
+__global__ void __launch_bounds__(CL_T, NB <= 12 ? BRUTUS_CL_OCC : 1)
 k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
           const double *__restrict__ pts_lnw, const double *__restrict__ phot,
           const double *__restrict__ ivar, const double *__restrict__ chi2_p,
           const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
           int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
     // This workgroup's slice of the point table goes through LDS in sub-slices of
-    // SUB points, each staged as [point][NB fluxes (0 beyond nb) | lnw | "has a NaN
+    // SUB points, each staged as [point][NB fluxes (0 beyond nb) | weight | "has a NaN
     // band"]: the loop then reads it with broadcast ds_reads instead of a chain of
-    // dependent scalar loads.
+    // dependent scalar loads.  A sub-slice is padded to a multiple of CL_U points with
+    // weight 0.
     constexpr int STRIDE = NB + 2;
-    constexpr int SUB = 24576 / (STRIDE * 8);          // 24 KB per workgroup
+    constexpr int SUB = (24576 / (STRIDE * 8)) / CL_U * CL_U;          // 24 KB per workgroup
     __shared__ double s_pts[SUB * STRIDE];
     __shared__ double s_tbl[64];
     stage_exp_table(s_tbl);
@@ -56,78 +72,104 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     const bool odd = n2 & 1, neg = n2 < 0;
     const int mp = neg ? 0 : n2 >> 1;                         // whole powers of chi2
     const bool p1 = mp & 1, p2 = mp & 2, p4 = mp & 4, p8 = mp & 8;
-    double m = -INFINITY, ssum = 0.;
+    // wave-uniform: does any object of this wave need 1 / sqrt(chi2) (fewer than two
+    // measurements) or chi2^8 (eighteen or more)?  Hardly ever; the common path skips both.
+    const bool any_neg = __any(neg && odd), any_p8 = __any(p8);
+    // (a finite stand-in for "no term yet": e^(M0 - anything) = 0 without a select)
+    constexpr double M0 = -1e300;
+    double m = M0, ssum = 0.;
     for (int q0 = p0; q0 < p1_; q0 += SUB) {
         const int np = min(SUB, p1_ - q0);
+        const int npu = (np + CL_U - 1) / CL_U * CL_U;
         __syncthreads();                                   // previous sub-slice fully consumed
-        for (int c = threadIdx.x; c < np; c += CL_T) {
-            const double *src = pts_flux + (int64_t)(q0 + c) * nb;
-            bool hole = false;
+        for (int c = threadIdx.x; c < npu; c += CL_T) {
+            const bool real = c < np;
+            const double *src = pts_flux + (int64_t)(q0 + (real ? c : 0)) * nb;
+            const double w = real ? exp(pts_lnw[q0 + c]) : 0.;       // weight (0 for a dropped point)
+            const bool dead = !(w > 0.) || !(w < INFINITY);
+            bool hole = false, any = false;
             for (int b = 0; b < NB; ++b) {
                 const double v = b < nb ? src[b] : 0.;
                 hole = hole || (v != v);
-                s_pts[c * STRIDE + b] = v;
+                any = any || (b < nb && v == v);
+                s_pts[c * STRIDE + b] = dead ? CL_DEAD_FLUX : v;
             }
-            s_pts[c * STRIDE + NB] = exp(pts_lnw[q0 + c]);       // weight (0 for a dropped point)
-            s_pts[c * STRIDE + NB + 1] = hole ? 1. : 0.;
+            // (a point all of whose bands are NaN would have chi2 = chi2_p; the caller gives it
+            // weight 0, cluster_points does, and so does this)
+            if (!any && !dead)
+                for (int b = 0; b < NB; ++b) s_pts[c * STRIDE + b] = CL_DEAD_FLUX;
+            s_pts[c * STRIDE + NB] = dead || !any ? 0. : w;
+            s_pts[c * STRIDE + NB + 1] = hole && any && !dead ? 1. : 0.;
         }
         __syncthreads();
-        for (int c = 0; c < np; ++c) {
-            const double *f = s_pts + c * STRIDE;
-            double fb[NB];
-    #pragma unroll
-            for (int b = 0; b < NB; ++b) fb[b] = f[b];
-            double chi2 = 0.;
-            // nansum (cluster.py:381): d and iv are finite (masked bands carry iv = 0),
-            // so a term is NaN exactly when the point lacks band b -- rare, and the
-            // same for every lane
-            if (f[NB + 1] == 0.) {
-    #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const double t = d[b] - fb[b];
-                    chi2 += t * t * iv[b];
+        for (int c = 0; c < npu; c += CL_U) {
+            // CL_U points at a time: their terms T_u e^{x_u}, x_u = -chi2_u / 2, join the running
+            // sum against ONE new maximum -- one exponential per point, of a non-positive
+            // argument, plus one per step for the old sum, and no select on which of the two
+            // is the larger
+            double x[CL_U], T[CL_U];
+            double mn = m;
+#pragma unroll
+            for (int u = 0; u < CL_U; ++u) {
+                const double *f = s_pts + (c + u) * STRIDE;
+                double fb[NB];
+#pragma unroll
+                for (int b = 0; b < NB; ++b) fb[b] = f[b];
+                double chi2 = 0.;
+                // nansum (cluster.py:381): d and iv are finite (masked bands carry iv = 0),
+                // so a term is NaN exactly when the point lacks band b -- rare, and the
+                // same for every lane
+                if (f[NB + 1] == 0.) {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const double t = d[b] - fb[b];
+                        chi2 += t * t * iv[b];
+                    }
+                } else {
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const double t = d[b] - fb[b];
+                        const double term = t * t * iv[b];
+                        chi2 += term == term ? term : 0.;
+                    }
                 }
-            } else {
-    #pragma unroll
-                for (int b = 0; b < NB; ++b) {
-                    const double t = d[b] - fb[b];
-                    const double term = t * t * iv[b];
-                    chi2 += term == term ? term : 0.;
+                chi2 = fmin(chi2 + cp, CL_CHI2_MAX);        // (a NaN -- inf * 0 of a dead point -- too)
+                // w chi2^(n2 / 2)
+                double rt;
+                if (any_neg) {
+                    double sq, rsq;
+                    fast_sqrt_rsqrt(chi2, sq, rsq);
+                    rt = neg ? (chi2 > 0. ? rsq : 0.) : sq;     // (chi2^-1/2 at 0: +inf, dropped)
+                } else {
+                    rt = fast_sqrt(chi2);
                 }
+                double Tu = f[NB] * (odd ? rt : 1.);
+                const double c2 = chi2 * chi2, c4 = c2 * c2;
+                Tu = p1 ? Tu * chi2 : Tu;
+                Tu = p2 ? Tu * c2 : Tu;
+                Tu = p4 ? Tu * c4 : Tu;
+                if (any_p8) Tu = p8 ? Tu * (c4 * c4) : Tu;
+                T[u] = Tu;
+                x[u] = -0.5 * chi2;
+                // (a term that vanishes -- T = 0 with chi2 = 0 and a positive power -- may set
+                // the maximum: it only rescales the others, by e^-(their chi2 / 2))
+                mn = fmax(mn, x[u]);
             }
-            chi2 += cp;
-            // w chi2^(n2 / 2)
-            double sq, rsq;
-            fast_sqrt_rsqrt(chi2, sq, rsq);
-            double T = f[NB] * (odd ? (neg ? rsq : sq) : 1.);
-            const double c2 = chi2 * chi2, c4 = c2 * c2;
-            T = p1 ? T * chi2 : T;
-            T = p2 ? T * c2 : T;
-            T = p4 ? T * c4 : T;
-            T = p8 ? T * (c4 * c4) : T;
-            // a non-finite or vanishing term contributes nothing (cluster.py:394)
-            const bool fin = T > 0. && T < INFINITY;
-            // online sum against the running maximum of -chi2/2, one exponential per point
-            const double x = -0.5 * chi2;
-            const double dx = x - m;
-            const double e = fast_exp_bf(-fabs(dx), s_tbl);
-            const bool up = fin && dx > 0.;
-            ssum = up ? fma(ssum, e, T) : (fin ? fma(T, e, ssum) : ssum);
-            m = up ? x : m;
+            const double scale = fast_exp_fin(m - mn, s_tbl);
+            double add = 0.;
+#pragma unroll
+            for (int u = 0; u < CL_U; ++u) add = fma(T[u], fast_exp_fin(x[u] - mn, s_tbl), add);
+            ssum = fma(ssum, scale, add);
+            m = mn;
         }
     }
-    m += c0;          // (-inf stays -inf: no point with a finite term)
+    m = ssum > 0. ? m + c0 : -INFINITY;          // (no point with a positive term)
     if (live) {
         part_m[(int64_t)blockIdx.y * nobj + o] = m;
         part_s[(int64_t)blockIdx.y * nobj + o] = ssum;
     }
 }
 
-// Isochrone points from the plug-in's magnitudes (cluster.py:346-366): flux = 10^(-0.4 mag)
-// (a NaN band stays NaN), and a point none of whose bands is finite gets weight -inf,
-// as does one the host marked so.  Replaces fifteen host-side 10**x passes per call.
-// `src` (may be null = identity) lists the table rows the host kept, in order: the
-// output is the compact point list.
 // `neep` > 0: the weight of table row r is lnw_in[r % neep] + lnw_smf[r / neep] -- one
 // initial-mass grid for all slices (ln d mini per EEP, ln d smf per slice) --, else lnw_in[r].
 __global__ void k_cluster_points(int64_t npts, int nb, const int32_t *__restrict__ src,

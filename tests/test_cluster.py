@@ -247,6 +247,67 @@ def test_cluster_lnl_in_parts_equals_one_call():
             ws.data_ptr(), ws.numel(), 250, 10, None))
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim_prior", [1, 0])
+def test_cluster_lnl_edge_points_and_objects(dim_prior):
+    """C ABI, `brutus_cluster_lnl` against the reference's block (cluster.py:379-407) restated
+    in numpy / scipy, on what the online sum treats specially: points of weight -inf, points
+    without a finite band that the caller did NOT mark, points with some NaN bands, an object
+    that sits exactly on a point (chi2 = 0) with 1, 2, 3 and 4 measurements, objects 1e4
+    sigma from every point (every e^(-chi2/2) underflows on its own), 33 measurements
+    (the largest power), and a point list that is not a multiple of the kernel's step."""
+    import torch
+    from scipy.special import logsumexp
+    from scipy.stats import chi2 as chisquare
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(21)
+    nobj, nb, npts = 300, 32, 1003
+    flux = rng.uniform(0.5, 2., size=(npts, nb))
+    lnw = rng.normal(size=npts)
+    lnw[rng.choice(npts, 60, replace=False)] = -np.inf
+    flux[rng.choice(npts, 40, replace=False)] = np.nan                   # no finite band at all
+    flux[rng.uniform(size=flux.shape) < 0.02] = np.nan
+    phot = flux[rng.randint(0, npts, nobj)].copy()
+    phot[~np.isfinite(phot)] = 1.
+    phot *= 1. + 0.03 * rng.normal(size=phot.shape)
+    ivar = np.full((nobj, nb), 1. / 0.03 ** 2)
+    nuse = rng.randint(4, nb + 1, nobj)
+    nuse[:8] = (1, 2, 3, 4, 1, 2, 3, 4)
+    nuse[8:12] = nb
+    for o in range(nobj):
+        ivar[o, nuse[o]:] = 0.
+    good = np.flatnonzero(np.all(np.isfinite(flux), axis=1) & np.isfinite(lnw))
+    phot[:4] = flux[good[:4]]                                            # chi2 = 0 at one point
+    phot[4:8] = flux[good[4:8]]
+    phot[12:20] *= 300.                                                  # 1e4 sigma off everything
+    chi2_p = rng.uniform(0., 3., nobj) * (rng.uniform(size=nobj) < 0.6)
+    chi2_p[:4] = 0.
+    ndim = nuse + (chi2_p > 0.)
+    ndim[8] = 33
+    lnorm = rng.normal(size=nobj)
+    # the reference's block: nansum over bands, log-pdf, non-finite -> -inf, logsumexp
+    with np.errstate(all="ignore"):
+        chi2 = np.nansum((phot[None] - flux[:, None]) ** 2 * ivar[None], axis=2) + chi2_p
+        lnl_c = (chisquare.logpdf(chi2, ndim) if dim_prior else -0.5 * (chi2 + lnorm))
+        lnl_c[~np.isfinite(lnl_c)] = -np.inf
+        w = np.where(np.any(np.isfinite(flux), axis=1), lnw, -np.inf)
+        want = logsumexp(lnl_c + w[:, None], axis=0)
+    dev = torch.device("cuda:0")
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    t = [up(flux), up(lnw), up(phot), up(ivar), up(chi2_p), up(lnorm), up(ndim, np.int32)]
+    ws = torch.empty(L.brutus_cluster_workspace_bytes(nobj), dtype=torch.uint8, device=dev)
+    out = torch.empty(nobj, dtype=torch.float64, device=dev)
+    _lib.check(L.brutus_cluster_lnl(nobj, nb, npts, *[x.data_ptr() for x in t], dim_prior,
+                                    ws.data_ptr(), ws.numel(), out.data_ptr(), None))
+    got = out.cpu().numpy()
+    fin = np.isfinite(want)
+    assert np.array_equal(fin, np.isfinite(got)) and fin.sum() > nobj - 8
+    assert np.all(got[~fin] == want[~fin])
+    assert relerr(want[fin], got[fin]) < 1e-10, np.argmax(np.abs(want[fin] - got[fin]))
+    assert want[12:20].max() < -1e6                  # (those objects did exercise the underflow)
+
+
 def test_cache_keys_follow_content_not_identity():
     """The cluster caches are keyed by address, layout and a digest of the CONTENT of the
     catalogue arrays (CPU-only check of the helpers): an in-place edit, a copy, a view with
