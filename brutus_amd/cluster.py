@@ -114,8 +114,10 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     MODIFIED IN PLACE must change its `cache_token` (or the caller clears the caches / passes
     `cache=False`).  A plug-in that also offers
     `get_seds_grid(smf_grid=, ...same keywords...[, out=]) -> (seds (Nsmf, Neep, Nbands), mini)`
-    is asked once per call instead of once per mass fraction (with `out=`, it fills the
-    page-locked buffer the device copy starts from)."""
+    is asked for a GROUP of consecutive mass fractions at a time (`smf_grid` = that group, 2
+    groups per call by default, BRUTUS_CLUSTER_PIPELINE) instead of once per mass fraction; with
+    `out=` it fills the page-locked buffer the device copy starts from.  Either way the device
+    turns a group into fluxes and sums it while the plug-in works on the next one."""
     from .fitting import _torch, _stream_ptr
     from scipy.stats import chi2 as chisquare
     if phot is None:
