@@ -21,6 +21,8 @@ __all__ = ["isochrone_loglike"]
 
 _DEFAULT_SMF = (0., 0.2, 0.35, 0.45, 0.5, 0.55, 0.6, 0.65, 0.7, 0.75, 0.8,
                 0.85, 0.9, 0.95, 1.0)
+_DEFAULT_SMF_ARR = np.asarray(_DEFAULT_SMF, float)
+_DEFAULT_SMF_GRAD = np.gradient(_DEFAULT_SMF_ARR)
 
 
 # Per-dataset terms (masks, chi-square outlier level, device copies of the photometry)
@@ -32,6 +34,14 @@ _DATA_CACHE_MAX, _TABLE_CACHE_MAX = 4, 16
 # The cached entries own device / page-locked buffers that a call fills and reads: one
 # evaluation at a time (a sampler's chains on one GPU take turns anyway).
 _LOCK = threading.RLock()
+# development aid: a list here receives (label, perf_counter) marks of a call (tools/dev/cluster_marks.py)
+_TRACE = None
+
+
+def _mark(label):
+    if _TRACE is not None:
+        import time
+        _TRACE.append((label, time.perf_counter()))
 
 
 def clear_caches():
@@ -114,8 +124,8 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     MODIFIED IN PLACE must change its `cache_token` (or the caller clears the caches / passes
     `cache=False`).  A plug-in that also offers
     `get_seds_grid(smf_grid=, ...same keywords...[, out=]) -> (seds (Nsmf, Neep, Nbands), mini)`
-    is asked for a GROUP of consecutive mass fractions at a time (`smf_grid` = that group, 2
-    groups per call by default, BRUTUS_CLUSTER_PIPELINE) instead of once per mass fraction; with
+    is asked for a GROUP of consecutive mass fractions at a time (`smf_grid` = that group, 3
+    growing groups per call by default, BRUTUS_CLUSTER_PIPELINE) instead of once per mass fraction; with
     `out=` it fills the page-locked buffer the device copy starts from.  Either way the device
     turns a group into fluxes and sums it while the plug-in works on the next one."""
     from .fitting import _torch, _stream_ptr
@@ -129,8 +139,11 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     phot = np.asarray(phot, dtype=np.float64)
     err = np.asarray(err, dtype=np.float64)
     Nobjs, Nbands = phot.shape
-    smf_grid = np.asarray(_DEFAULT_SMF if smf_grid is None else smf_grid, float)
-    grad_smf = np.gradient(smf_grid) if len(smf_grid) > 1 else np.array([1.])
+    if smf_grid is None:            # (copies: the plug-in is handed slices of it)
+        smf_grid, grad_smf = _DEFAULT_SMF_ARR.copy(), _DEFAULT_SMF_GRAD.copy()
+    else:
+        smf_grid = np.asarray(smf_grid, float)
+        grad_smf = np.gradient(smf_grid) if len(smf_grid) > 1 else np.array([1.])
     if eep_grid is None:
         eep_grid = np.linspace(202., 808., 2000)
     eep_grid = np.asarray(eep_grid, dtype=np.float64)
@@ -156,6 +169,7 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
         raise ValueError("You forgot to provide the parallax errors to go "
                          "along with the parallaxes!")
 
+    _mark("checked")
     # ---- unpack theta (cluster.py:227-290) ------------------------------------
     pos = 0
     (feh, loga, av, rv, dist, fout), pos = _take(theta, pos, cluster_params, 6)
@@ -171,7 +185,9 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     else:
         corr_coef, pos = _take(theta, pos, corr_params, 4)
 
+    _mark("theta")
     ds = _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache)
+    _mark("dataset")
     torch, dev = _torch(), ds.dev
     L = _lib.lib()
 
@@ -186,36 +202,51 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
     with torch.cuda.device(dev):
         up = lambda a, dt=np.float64: torch.from_numpy(
             np.ascontiguousarray(a, dtype=dt)).to(dev)
-        # ---- the objects' side of the kernel, on its way before the plug-in is asked ----
-        t_ln = None
-        if np.all(Xb == 1.):
-            t_d, t_iv, t_ln = ds.t_d, ds.t_iv, ds.t_ln0
-        else:                                  # multiplicative offsets (cluster.py:327-333)
-            phot_t, err_t = phot * Xb, err * Xb
-            with np.errstate(all="ignore"):
-                ivar = np.where(ds.phot_mask, 1. / err_t ** 2, 0.)
-                lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + ds.lnorm_p
-            t_d, t_iv = up(np.where(ds.phot_mask, phot_t, 0.)), up(ivar)
-            t_ln = up(lnorm)
-        ds.h_cp.numpy()[...] = chi2_p
-        t_cp = ds.t_cp.copy_(ds.h_cp, non_blocking=True)
         stream = _stream_ptr(torch)
         ws, ws_n = ds.ws.data_ptr(), ds.ws.numel()
-        obj_args = (t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
-                    ds.t_n.data_ptr(), 1 if dim_prior else 0, ws, ws_n)
+        objs = []
+
+        def obj_args():
+            """The objects' side of the kernel (cluster.py:292-333).  Prepared when the first
+            group of isochrone points is already on its way to the device: the copy and the
+            flux kernel of that group run under this."""
+            if objs:
+                return objs[0]
+            t_ln = None
+            if np.all(Xb == 1.):
+                t_d, t_iv, t_ln = ds.t_d, ds.t_iv, ds.t_ln0
+            else:                                  # multiplicative offsets (cluster.py:327-333)
+                phot_t, err_t = phot * Xb, err * Xb
+                with np.errstate(all="ignore"):
+                    ivar = np.where(ds.phot_mask, 1. / err_t ** 2, 0.)
+                    lnorm = np.nansum(np.log(2. * np.pi * err_t ** 2), axis=1) + ds.lnorm_p
+                t_d, t_iv = up(np.where(ds.phot_mask, phot_t, 0.)), up(ivar)
+                t_ln = up(lnorm)
+            ds.h_cp.numpy()[...] = chi2_p
+            t_cp = ds.t_cp.copy_(ds.h_cp, non_blocking=True)
+            # (the tensors ride along: they must outlive the launches that read them)
+            objs.append(((t_d.data_ptr(), t_iv.data_ptr(), t_cp.data_ptr(), t_ln.data_ptr(),
+                          ds.t_n.data_ptr(), 1 if dim_prior else 0, ws, ws_n),
+                         (t_d, t_iv, t_cp, t_ln)))
+            _mark("objects up")
+            return objs[0]
 
         def part(t_flux, t_lnw, npts, chunk_lo, chunk_n):
             """The sum over `npts` points as partials in chunks [chunk_lo, chunk_lo + chunk_n)."""
             _lib.check(L.brutus_cluster_lnl_part(
                 Nobjs, Nbands, npts, t_flux.data_ptr() if npts else None,
-                t_lnw.data_ptr() if npts else None, *obj_args, chunk_lo, chunk_n, stream))
+                t_lnw.data_ptr() if npts else None, *obj_args()[0], chunk_lo, chunk_n, stream))
 
         # ---- isochrone points of every SMF slice (cluster.py:336-366) -------------
         tab, nchunk = _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid,
                                    grad_smf, eep_grid, mini_bound, eep_binary_max, Nbands, dev,
                                    torch, L, up, cache, part)
+        _mark("table")
         if tab is None:
             lnl = np.full(Nobjs, -np.inf)
+            with np.errstate(all="ignore"):     # outlier mixture (cluster.py:410-414)
+                lnl_mix = np.logaddexp(lnl + ln_fin, ds.lnl_outlier + ln_fout)
+            lnl_tot = np.sum(lnl_mix)
         else:
             if nchunk:      # the pieces were summed while the plug-in worked on the next one
                 _lib.check(L.brutus_cluster_lnl_merge(Nobjs, nchunk, ws, ws_n,
@@ -224,14 +255,22 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
                 t_flux, t_lnw = tab
                 _lib.check(L.brutus_cluster_lnl(
                     Nobjs, Nbands, t_lnw.numel(), t_flux.data_ptr(), t_lnw.data_ptr(),
-                    *obj_args, ds.out.data_ptr(), stream))
-            ds.h_out.copy_(ds.out, non_blocking=True)
+                    *obj_args()[0], ds.out.data_ptr(), stream))
+            # ---- outlier mixture and total (cluster.py:410-414), on the device -------------
+            _lib.check(L.brutus_cluster_mix(Nobjs, ds.out.data_ptr(), ds.t_lo.data_ptr(),
+                                            float(ln_fin), float(ln_fout), ds.t_mix.data_ptr(),
+                                            ds.t_mix[Nobjs:].data_ptr(), stream))
+            if return_lnls:
+                ds.h_mix.copy_(ds.t_mix, non_blocking=True)
+            else:
+                ds.h_mix[Nobjs:].copy_(ds.t_mix[Nobjs:], non_blocking=True)
+            _mark("enqueued")
             torch.cuda.current_stream().synchronize()
-            lnl = ds.h_out.numpy()
-    # ---- outlier mixture (cluster.py:410-414) ---------------------------------------
-    with np.errstate(all="ignore"):
-        lnl_mix = np.logaddexp(lnl + ln_fin, ds.lnl_outlier + ln_fout)
-    lnl_tot = np.sum(lnl_mix)
+            _mark("synced")
+            h = ds.h_mix.numpy()
+            lnl_tot = h[Nobjs]            # (a numpy scalar: a copy)
+            lnl_mix = h[:Nobjs].copy() if return_lnls else None
+    _mark("mixed")
     if return_lnls:
         return lnl_tot, lnl_mix
     return lnl_tot
@@ -312,6 +351,11 @@ def _dataset(phot, err, parallax, parallax_err, dim_prior, device, cache):
         ds.ws = torch.empty(L.brutus_cluster_workspace_bytes(Nobjs), dtype=torch.uint8, device=dev)
         ds.out = torch.empty(Nobjs, dtype=torch.float64, device=dev)
         ds.h_out = torch.empty(Nobjs, dtype=torch.float64).pin_memory()
+        # outlier mixture and total on the device (cluster.py:410-414): what comes back is one
+        # float64, and the per-object values only when they are asked for
+        ds.t_lo = up(ds.lnl_outlier)
+        ds.t_mix = torch.empty(Nobjs + 1, dtype=torch.float64, device=dev)      # [mix | total]
+        ds.h_mix = torch.empty(Nobjs + 1, dtype=torch.float64).pin_memory()
     if cache:
         _lru_put(_DATA_CACHE, key, ds, _DATA_CACHE_MAX)
     return ds
@@ -339,14 +383,29 @@ def _staging(nrow, nb, dev, torch):
 
 # The plug-in is asked for a few secondary-mass-fraction slices at a time; while it works on
 # the next group the device turns the previous one into fluxes and sums it (a group = one
-# host -> device copy from page-locked memory and two launches).  Measured with the synthetic
-# table plug-in of the benchmark (0.27 ms for all 15 slices; device 0.4 ms per call), whole
-# calls per second: 1 group 1 206, 2 groups 1 300, 3 groups 1 255, 5 groups 1 096 -- every
-# group costs the host ~0.03 ms (one more plug-in call, copy, two launches), and the device
-# chain, not the plug-in, is the longer one from 2 groups on.  A plug-in that takes
-# milliseconds per slice (the MIST / neural-net isochrones) hides the device entirely with
-# any number of groups > 1; BRUTUS_CLUSTER_PIPELINE sets it.
-_PIPELINE_GROUPS = 2
+# host -> device copy from page-locked memory and two launches, ~0.02 ms of host time, plus
+# the plug-in's own per-call overhead, ~0.02 ms for the benchmark's table plug-in).  With that
+# plug-in (0.27 ms for all 15 slices) the device chain (0.45 ms per call) is the longer one:
+# what counts is that it starts early and never waits, so the groups GROW -- 3, 5, 7 slices of
+# 15 -- and the objects' side of the kernel is prepared while the first group's copy runs.
+# Whole calls per second, same box: 1 group 1 235, 2 groups 1 380, 3 groups 1 400-1 420,
+# 4 groups 1 350 (equal halves before the growth: 1 300).  Marks of a call
+# (tools/dev/cluster_marks.py, 3 groups): plug-in 0.10 + 0.10 + 0.13 ms, host waiting for the
+# device at the end 0.19 ms.  A plug-in that takes milliseconds per slice (the MIST /
+# neural-net isochrones) hides the device entirely with any split; BRUTUS_CLUSTER_PIPELINE
+# sets the number of groups (1: one call to the plug-in and one sum, as before round 4).
+_PIPELINE_GROUPS = 3
+_PIPELINE_GROWTH = 1.5
+
+
+def _group_bounds(nsmf, ngroup, growth=_PIPELINE_GROWTH):
+    """Slice boundaries of `ngroup` consecutive groups whose sizes grow by `growth`."""
+    ngroup = max(1, min(nsmf, ngroup, 64))
+    w = np.cumsum(growth ** np.arange(ngroup))
+    b = np.rint(nsmf * w / w[-1]).astype(int)
+    b = np.maximum(b, np.arange(1, ngroup + 1))           # at least one slice per group
+    b = np.minimum(b, nsmf - (ngroup - 1 - np.arange(ngroup)))
+    return [0] + [int(x) for x in b]
 
 
 def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf, eep_grid,
@@ -367,12 +426,18 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
         tab = _lru_get(_TABLE_CACHE, key)
         if tab is not None:
             return tab[0], 0
+    _mark("table key")
     kw = dict(feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, dist=dist,
               mini_bound=mini_bound, eep_binary_max=eep_binary_max, corr_params=corr_coef)
     nsmf, neep = len(smf_grid), len(eep_grid)
     nrow = nsmf * neep
-    ngroup = max(1, min(nsmf, int(os.environ.get("BRUTUS_CLUSTER_PIPELINE", _PIPELINE_GROUPS))))
+    bounds = _group_bounds(nsmf, int(os.environ.get("BRUTUS_CLUSTER_PIPELINE", _PIPELINE_GROUPS)))
+    ngroup = len(bounds) - 1
     nchunk = L.brutus_cluster_chunks()
+    cbounds = [0]                                   # partial-sum chunks in proportion, >= 1 each
+    for g in range(ngroup):
+        cbounds.append(min(max(nchunk * bounds[g + 1] // nsmf, cbounds[-1] + 1),
+                           nchunk - (ngroup - 1 - g)))
     stage = _staging(nrow, Nbands, dev, torch)
     h_mags = stage.h_mags.numpy().reshape(nsmf, neep, Nbands)
     h_lnw = stage.h_lnw.numpy().reshape(nsmf, neep)
@@ -406,8 +471,8 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
         for g in range(ngroup):
-            a, b = nsmf * g // ngroup, nsmf * (g + 1) // ngroup
-            c0, c1 = nchunk * g // ngroup, nchunk * (g + 1) // ngroup
+            a, b = bounds[g], bounds[g + 1]
+            c0, c1 = cbounds[g], cbounds[g + 1]
             if grid_hook:
                 if stage.hook_out[type(isochrone)]:             # straight into pinned memory
                     mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid[a:b], out=h_mags[a:b],
@@ -424,6 +489,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                     seds, params, _ = isochrone.get_seds(smf=smf_grid[i], **kw)
                     h_mags[i] = seds
                     mini[i - a] = params['mini']
+            _mark("plug-in %d" % g)
             # the group's host -> device copy starts now, from page-locked memory, and runs
             # under the host arithmetic below
             stage.d_mags[a * neep:b * neep].copy_(stage.h_mags[a * neep:b * neep], non_blocking=True)
@@ -473,6 +539,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                         stage.d_lnw.data_ptr(), t_flux[off:].data_ptr(), t_lnw[off:].data_ptr(),
                         stream))
             part(t_flux[off:off + n], t_lnw[off:off + n], n, c0, c1 - c0)
+            _mark("group %d out" % g)
             off += n
     tab = (t_flux[:off], t_lnw[:off]) if off else None
     if cache:      # (the plug-in object is kept alive with its tables: `id` stays unique)

@@ -1366,6 +1366,16 @@ int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t wor
     return 0;
 }
 
+int brutus_cluster_mix(int nobj, const double *d_lnl, const double *d_lnl_outlier, double ln_fin,
+                       double ln_fout, double *d_lnl_mix, double *d_lnl_tot, void *stream) {
+    if (nobj <= 0 || !d_lnl || !d_lnl_outlier || !d_lnl_mix || !d_lnl_tot)
+        return fail(BRUTUS_EINVAL, "bad cluster mixture arguments (nobj=%d)", nobj);
+    hipLaunchKernelGGL(k_cluster_mix, dim3(1), dim3(CX_T), 0, (hipStream_t)stream, nobj, d_lnl,
+                       d_lnl_outlier, ln_fin, ln_fout, d_lnl_mix, d_lnl_tot);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 int brutus_cluster_lnl(int nobj, int nfilt, int npts, const double *d_pts_flux,
                        const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
                        const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,

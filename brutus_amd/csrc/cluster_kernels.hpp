@@ -230,4 +230,33 @@ k_cluster_merge(int nobj, int nchunk, const double *__restrict__ part_m,
     }
 }
 
+// Outlier mixture and total (cluster.py:410-414): lnl_mix = logaddexp(lnl + ln_fin,
+// lnl_outlier + ln_fout) per object and their sum, one workgroup, a fixed summation order
+// (thread t takes objects t, t + 1024, ...; a binary tree over the threads): the same bits
+// on every run.
+constexpr int CX_T = 1024;
+__global__ void __launch_bounds__(CX_T)
+k_cluster_mix(int nobj, const double *__restrict__ lnl, const double *__restrict__ lnl_out,
+              double ln_fin, double ln_fout, double *__restrict__ mix, double *__restrict__ tot) {
+    __shared__ double s_sum[CX_T];
+    double acc = 0.;
+    for (int o = threadIdx.x; o < nobj; o += CX_T) {
+        const double a = lnl[o] + ln_fin, b = lnl_out[o] + ln_fout;
+        const double d = a - b;
+        double v;
+        if (d > 0.) v = a + log1p(exp(-d));
+        else if (d <= 0.) v = b + log1p(exp(d));
+        else v = a + b;                     // NaN, or infinities of one sign (numpy: x1 + x2)
+        mix[o] = v;
+        acc += v;
+    }
+    s_sum[threadIdx.x] = acc;
+    __syncthreads();
+    for (int h = CX_T / 2; h > 0; h >>= 1) {
+        if ((int)threadIdx.x < h) s_sum[threadIdx.x] += s_sum[threadIdx.x + h];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) tot[0] = s_sum[0];
+}
+
 }  // namespace

@@ -321,6 +321,11 @@ int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_f
                             int chunk_n, void *stream);
 int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t workspace_bytes,
                              double *d_lnl, void *stream);
+/* Outlier mixture and total of cluster.py:410-414 on the device: d_lnl_mix (nobj) =
+ * logaddexp(d_lnl + ln_fin, d_lnl_outlier + ln_fout) (numpy's logaddexp, NaN and infinities
+ * included) and d_lnl_tot (1) = their sum in a fixed order (the same bits on every run). */
+int brutus_cluster_mix(int nobj, const double *d_lnl, const double *d_lnl_outlier, double ln_fin,
+                       double ln_fout, double *d_lnl_mix, double *d_lnl_tot, void *stream);
 
 /* ---- utils.photometric_offsets (reference utils.py:1218-1400) ------------------------
  * The per-band bootstrap of model / data flux ratios over the resampled fits of many

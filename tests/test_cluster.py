@@ -308,6 +308,64 @@ def test_cluster_lnl_edge_points_and_objects(dim_prior):
     assert want[12:20].max() < -1e6                  # (those objects did exercise the underflow)
 
 
+@pytest.mark.gpu
+def test_cluster_mix_is_numpy_logaddexp_and_a_fixed_order_sum():
+    """C ABI, `brutus_cluster_mix`: numpy's `logaddexp` per object -- equal arguments, -inf on
+    either or both sides, +inf, NaN -- and a total that has the same bits on every run."""
+    import torch
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(2)
+    n = 5003
+    a = rng.normal(size=n) * 30. - 40.
+    b = rng.normal(size=n) * 3. - 20.
+    a[:8] = (-np.inf, -np.inf, 0., np.inf, np.nan, -800., 5., -np.inf)
+    b[:8] = (-np.inf, -3., 0., 1., 2., -20., np.nan, np.inf)
+    b[8:16] = a[8:16]
+    ln_fin, ln_fout = np.log(0.9), np.log(0.1)
+    with np.errstate(all="ignore"):
+        want = np.logaddexp(a + ln_fin, b + ln_fout)
+    dev = torch.device("cuda:0")
+    ta, tb = torch.from_numpy(a).to(dev), torch.from_numpy(b).to(dev)
+    outs = []
+    for _ in range(3):
+        out = torch.zeros(n + 1, dtype=torch.float64, device=dev)
+        _lib.check(L.brutus_cluster_mix(n, ta.data_ptr(), tb.data_ptr(), float(ln_fin),
+                                        float(ln_fout), out.data_ptr(), out[n:].data_ptr(), None))
+        outs.append(out.cpu().numpy())
+    got = outs[0]
+    assert np.array_equal(np.isnan(want), np.isnan(got[:n]))
+    ok = np.isfinite(want)
+    assert np.array_equal(want[~ok & ~np.isnan(want)], got[:n][~ok & ~np.isnan(want)])
+    assert np.max(np.abs(want[ok] - got[:n][ok]) / np.maximum(1., np.abs(want[ok]))) < 4e-16
+    assert np.isnan(got[n])                                   # (a NaN term: numpy's sum too)
+    fin = np.isfinite(want)
+    out = torch.zeros(fin.sum() + 1, dtype=torch.float64, device=dev)
+    m = int(fin.sum())
+    fa, fb = torch.from_numpy(a[fin]).to(dev), torch.from_numpy(b[fin]).to(dev)
+    tots = []
+    for _ in range(3):
+        _lib.check(L.brutus_cluster_mix(m, fa.data_ptr(), fb.data_ptr(), float(ln_fin),
+                                        float(ln_fout), out.data_ptr(), out[m:].data_ptr(), None))
+        tots.append(float(out[m].item()))
+    assert tots[0] == tots[1] == tots[2]
+    assert abs(tots[0] - np.sum(want[fin])) < 1e-13 * abs(np.sum(want[fin]))
+    assert all(np.array_equal(outs[0], o, equal_nan=True) for o in outs[1:])
+
+
+def test_plugin_groups_grow_and_cover_every_slice():
+    """`_group_bounds`: consecutive, non-empty, growing groups for any slice / group count."""
+    from brutus_amd.cluster import _group_bounds
+    assert _group_bounds(15, 3) == [0, 3, 8, 15] and _group_bounds(15, 1) == [0, 15]
+    for nsmf in (1, 2, 3, 7, 15, 16, 100, 300):
+        for ng in (1, 2, 3, 4, 8, 15, 64, 1000):
+            b = _group_bounds(nsmf, ng)
+            sizes = np.diff(b)
+            assert b[0] == 0 and b[-1] == nsmf and np.all(sizes >= 1), (nsmf, ng, b)
+            assert len(sizes) == min(nsmf, ng, 64)
+            assert np.all(np.diff(sizes) >= -1)              # (growing, up to rounding)
+
+
 def test_cache_keys_follow_content_not_identity():
     """The cluster caches are keyed by address, layout and a digest of the CONTENT of the
     catalogue arrays (CPU-only check of the helpers): an in-place edit, a copy, a view with
