@@ -57,6 +57,10 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
     const int o = blockIdx.x * CL_T + threadIdx.x;
     const bool live = o < nobj;
     const int oo = live ? o : 0;
+    // (Tried: (D - u flux)^2 with u = 1 / err, D = u phot -- two operations per band instead of
+    // three, k_cluster -3 %.  Dropped: an object that sits EXACTLY on a point gets chi2 ~ 1e-30
+    // instead of 0, and with one or three measurements the density there is singular / zero:
+    // the edge-case test of tests/test_cluster.py differs from the reference's block.)
     double d[NB], iv[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
