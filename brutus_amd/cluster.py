@@ -483,7 +483,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                     mags, mini = isochrone.get_seds_grid(smf_grid=smf_grid[a:b], **kw)
                 mags = np.asarray(mags, dtype=np.float64)
                 mini = np.asarray(mini, dtype=np.float64)
-                if not np.shares_memory(mags, h_mags):
+                if not np.may_share_memory(mags, h_mags):
                     h_mags[a:b] = mags
             else:
                 mini = np.empty((b - a, neep))
