@@ -209,7 +209,7 @@ def _worker_balance(rank, world, port, tmp, ndata, fail_rank):
 def test_fit_sharded_eight_ranks_rank0_is_not_the_straggler(tmp_path):
     """World size 8 on CPU stand-ins: rank 0 fits an equal shard AND receives, unpacks and
     writes everybody's rows (in its hand-off thread); its fit must end with the others'
-    (within 10 %), and no rank's fit may be stretched by waiting for another rank's rounds
+    (within 25 %), and no rank's fit may be stretched by waiting for another rank's rounds
     (round 3's lock-step gather put rank 0's extra work into every rank's loop)."""
     import torch.multiprocessing as mp
     from brutus_amd import h5io
@@ -219,9 +219,12 @@ def test_fit_sharded_eight_ranks_rank0_is_not_the_straggler(tmp_path):
     assert all(x[0] == "ok" for x in res), res
     fit = np.array([float(x[1]) for x in res])
     others = np.median(fit[1:])
-    assert fit[0] <= 1.10 * others, fit
-    assert fit.max() <= 1.15 * fit.min(), fit               # nobody waits for anybody
-    assert fit.max() < 1500 * 4e-4 * 2.0, fit               # ~0.6 s of sleeping + overheads
+    # (sixteen threads on the eight cores of the CPU box: a sleep of 0.4 ms takes 0.6-0.7, and
+    # the ranks differ by 10-15 % on their own; lock-step rounds would cost every rank rank 0's
+    # unpacking and writing of ALL rows on top, i.e. a factor, not a fraction)
+    assert fit[0] <= 1.25 * others, fit
+    assert fit.max() <= 1.40 * fit.min(), fit               # nobody waits for anybody
+    assert fit.max() < 1500 * 4e-4 * 4.0, fit               # ~0.6 s of sleeping + overheads
     evid = h5io.read_dataset(os.path.join(str(tmp_path), "bal.h5"), "obj_log_evid")
     assert np.array_equal(evid.astype(np.int64), np.arange(ndata))
 
