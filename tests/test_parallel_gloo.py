@@ -191,12 +191,18 @@ def _worker_balance(rank, world, port, tmp, ndata, fail_rank):
 
     bf = Stub(models, labels, lmask)
     msg = "ok"
+    # what the same number of sleeps costs on this box right now, all ranks sleeping at once
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(300):
+        time.sleep(4e-4)
+    base = (time.perf_counter() - t0) * (ndata // world) / 300.
     try:
         parallel.fit_sharded(bf, flux, 0.05 * flux, np.ones((ndata, 6), dtype=bool), None,
                              os.path.join(tmp, "bal"), seed0=0, Ndraws=8, chunk=64,
                              lngalprior=lambda *a, **k: 0., data_coords=np.zeros((ndata, 2)))
         st = parallel.fit_sharded.last_stats
-        msg = "ok %.4f %.4f" % (st["fit_s"], st["total_s"])
+        msg = "ok %.4f %.4f %.4f" % (st["fit_s"], st["total_s"], base)
     except FloatingPointError as e:
         msg = "own %s" % e
     except RuntimeError as e:
@@ -218,15 +224,18 @@ def test_fit_sharded_eight_ranks_rank0_is_not_the_straggler(tmp_path):
     res = [open(os.path.join(str(tmp_path), "bal_%d.txt" % r)).read().split() for r in range(world)]
     assert all(x[0] == "ok" for x in res), res
     fit = np.array([float(x[1]) for x in res])
+    base = np.array([float(x[3]) for x in res])             # the shard's sleeps alone, same box, same moment
     others = np.median(fit[1:])
+    evid = h5io.read_dataset(os.path.join(str(tmp_path), "bal.h5"), "obj_log_evid")
+    assert np.array_equal(evid.astype(np.int64), np.arange(ndata))
+    if np.median(base) > 1500 * 4e-4 * 2.0:
+        pytest.skip("the box is too loaded for a timing statement (a 0.4 ms sleep takes %.2f ms)"
+                    % (np.median(base) / 1500 * 1e3))
+    assert fit.max() <= 1.6 * np.median(base) + 0.2, (fit, base)     # the fit = its own sleeps
     # (sixteen threads on the eight cores of the CPU box: a sleep of 0.4 ms takes 0.6-0.7, and
     # the ranks differ by 10-15 % on their own; lock-step rounds would cost every rank rank 0's
     # unpacking and writing of ALL rows on top, i.e. a factor, not a fraction)
-    assert fit[0] <= 1.25 * others, fit
-    assert fit.max() <= 1.40 * fit.min(), fit               # nobody waits for anybody
-    assert fit.max() < 1500 * 4e-4 * 4.0, fit               # ~0.6 s of sleeping + overheads
-    evid = h5io.read_dataset(os.path.join(str(tmp_path), "bal.h5"), "obj_log_evid")
-    assert np.array_equal(evid.astype(np.int64), np.arange(ndata))
+    assert fit[0] <= 1.35 * others + 0.1, fit               # rank 0 is not the straggler
 
 
 def test_fit_sharded_failure_on_one_rank_stops_all(tmp_path):
