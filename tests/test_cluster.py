@@ -169,6 +169,22 @@ def test_batched_plugin_hook_and_caches_change_nothing():
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("smf", [(0.,), (0., 1.), (0., 0.3, 0.6, 1.), None])
+def test_hip_short_mass_fraction_grids_vs_oracle(smf):
+    """One, two, four and the default fifteen secondary-mass-fraction slices (fewer slices
+    than plug-in groups; a single slice has the weight ln 1) and a short EEP grid against the
+    oracle, with the fake isochrone of the golden cases (per-slice `get_seds` only)."""
+    from brutus_amd import cluster
+    from oracle import brutus_oracle as O
+    iso, phot, err, par, perr = make_cluster_data(300, 8, 3)
+    kw = dict(parallax=par, parallax_err=perr, return_lnls=True, smf_grid=smf,
+              eep_grid=np.linspace(202., 808., 257))
+    a = cluster.isochrone_loglike(THETA, iso, phot, err, cache=False, **kw)
+    c = O.isochrone_loglike(THETA, iso, phot, err, **kw)
+    assert relerr(c[1], a[1]) < 1e-9 and abs(a[0] - c[0]) < 1e-9 * abs(c[0])
+
+
+@pytest.mark.gpu
 def test_pipelined_groups_change_nothing(monkeypatch):
     """The point table is built and summed a few mass-fraction slices at a time
     (`brutus_cluster_lnl_part` per group, `brutus_cluster_lnl_merge` at the end) while the
