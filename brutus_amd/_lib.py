@@ -119,6 +119,8 @@ SIGNATURES = {
     "brutus_cluster_chunks": (C.c_int, []),
     "brutus_cluster_lnl_part": (C.c_int, [_i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
                                           _vp, _i32, _vp, _sz, _i32, _i32, _vp]),
+    "brutus_cluster_lnl_part_mags": (C.c_int, [_i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp,
+                                               _vp, _vp, _vp, _i32, _vp, _sz, _i32, _i32, _vp]),
     "brutus_cluster_lnl_merge": (C.c_int, [_i32, _i32, _vp, _sz, _vp, _vp]),
     "brutus_cluster_mix": (C.c_int, [_i32, _vp, _vp, C.c_double, C.c_double, _vp, _vp, _vp]),
 }

@@ -237,10 +237,16 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
                 Nobjs, Nbands, npts, t_flux.data_ptr() if npts else None,
                 t_lnw.data_ptr() if npts else None, *obj_args()[0], chunk_lo, chunk_n, stream))
 
+        def part_mags(t_src, t_mags, t_lng, t_lnsmf, neep, npts, chunk_lo, chunk_n):
+            """The same straight from the plug-in's magnitudes (kept rows `t_src` of `t_mags`)."""
+            _lib.check(L.brutus_cluster_lnl_part_mags(
+                Nobjs, Nbands, npts, neep, t_src.data_ptr() if npts else None, t_mags.data_ptr(),
+                t_lng.data_ptr(), t_lnsmf.data_ptr(), *obj_args()[0], chunk_lo, chunk_n, stream))
+
         # ---- isochrone points of every SMF slice (cluster.py:336-366) -------------
         tab, nchunk = _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid,
                                    grad_smf, eep_grid, mini_bound, eep_binary_max, Nbands, dev,
-                                   torch, L, up, cache, part)
+                                   torch, L, up, cache, part, part_mags)
         _mark("table")
         if tab is None:
             lnl = np.full(Nobjs, -np.inf)
@@ -252,7 +258,7 @@ def _isochrone_loglike(theta, isochrone, phot, err, cluster_params, offsets, cor
                 _lib.check(L.brutus_cluster_lnl_merge(Nobjs, nchunk, ws, ws_n,
                                                       ds.out.data_ptr(), stream))
             else:           # a table met before
-                t_flux, t_lnw = tab
+                t_flux, t_lnw = tab[1:]
                 _lib.check(L.brutus_cluster_lnl(
                     Nobjs, Nbands, t_lnw.numel(), t_flux.data_ptr(), t_lnw.data_ptr(),
                     *obj_args()[0], ds.out.data_ptr(), stream))
@@ -411,7 +417,7 @@ def _group_bounds(nsmf, ngroup, growth=_PIPELINE_GROWTH):
 
 
 def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_smf, eep_grid,
-                 mini_bound, eep_binary_max, Nbands, dev, torch, L, up, cache, part):
+                 mini_bound, eep_binary_max, Nbands, dev, torch, L, up, cache, part, part_mags):
     """Device-resident isochrone points `(flux (Npts, Nbands), lnw (Npts))` of all
     secondary-mass-fraction slices, or None if no slice has a usable point
     (cluster.py:336-366), and the number of partial-sum chunks filled on the way: a table
@@ -427,7 +433,19 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     if cache:
         tab = _lru_get(_TABLE_CACHE, key)
         if tab is not None:
-            return tab[0], 0
+            tab = tab[0]
+            if tab is not None and tab[0] == "mags":
+                # first revisit of a table kept as magnitudes: make the flux table once (the sum
+                # over fluxes is 3 % faster than the one that forms them on the way)
+                _, t_src, t_mags, t_lng, t_lnsmf, neep_, npts = tab
+                t_flux = torch.empty((npts, Nbands), dtype=torch.float64, device=dev)
+                t_lnw = torch.empty(npts, dtype=torch.float64, device=dev)
+                _lib.check(L.brutus_cluster_points_grid(
+                    npts, Nbands, neep_, t_src.data_ptr(), t_mags.data_ptr(), t_lng.data_ptr(),
+                    t_lnsmf.data_ptr(), t_flux.data_ptr(), t_lnw.data_ptr(), _stream_ptr(torch)))
+                tab = ("flux", t_flux, t_lnw)
+                _lru_put(_TABLE_CACHE, key, (tab, isochrone), _TABLE_CACHE_MAX)
+            return tab, 0
     _mark("table key")
     kw = dict(feh=feh, loga=loga, av=av, rv=rv, eep=eep_grid, dist=dist,
               mini_bound=mini_bound, eep_binary_max=eep_binary_max, corr_params=corr_coef)
@@ -448,14 +466,16 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
         import inspect
         stage.hook_out[type(isochrone)] = \
             "out" in inspect.signature(isochrone.get_seds_grid).parameters
-    if cache:      # a cached table keeps its tensors; without the cache one pair is reused
-        t_flux = torch.empty((nrow, Nbands), dtype=torch.float64, device=dev)
-        t_lnw = torch.empty(nrow, dtype=torch.float64, device=dev)
-    else:
+    t_flux = t_lnw = None          # (flux table: only for per-slice mass grids, made on demand)
+
+    def flux_table():
+        if cache:      # a cached table keeps its tensors; without the cache one pair is reused
+            return (torch.empty((nrow, Nbands), dtype=torch.float64, device=dev),
+                    torch.empty(nrow, dtype=torch.float64, device=dev))
         if getattr(stage, "t_flux", None) is None:
             stage.t_flux = torch.empty((nrow, Nbands), dtype=torch.float64, device=dev)
             stage.t_lnw = torch.empty(nrow, dtype=torch.float64, device=dev)
-        t_flux, t_lnw = stage.t_flux, stage.t_lnw
+        return stage.t_flux, stage.t_lnw
     if stage.src is None or len(stage.src) != ngroup or tuple(stage.h_lng.shape) != (ngroup, neep):
         stage.src, stage.t_src, stage.srckey = [None] * ngroup, [None] * ngroup, [None] * ngroup
         stage.h_lng = torch.empty((ngroup, neep), dtype=torch.float64).pin_memory()
@@ -469,7 +489,7 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
     lateb = late.tobytes()
     ln_gsmf = np.log(grad_smf)
     stream = _stream_ptr(torch)
-    off = 0
+    off = shared = 0
     with warnings.catch_warnings(), np.errstate(all="ignore"):
         warnings.simplefilter("ignore")
         for g in range(ngroup):
@@ -515,6 +535,15 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                     src = (np.flatnonzero(keep) + a * neep).astype(np.int32)
                     stage.src[g], stage.t_src[g], stage.srckey[g] = src, up(src, np.int32), srckey
                 n = stage.src[g].size
+                if os.environ.get("BRUTUS_CLUSTER_MAGS", "1") != "0":
+                    # fluxes and weights are formed by the sum itself, from the staged magnitudes
+                    part_mags(stage.t_src[g], stage.d_mags, d_lng, d_lnsmf, neep, n, c0, c1 - c0)
+                    _mark("group %d out" % g)
+                    off += n
+                    shared += 1
+                    continue
+                if t_flux is None:
+                    t_flux, t_lnw = flux_table()
                 if n:
                     _lib.check(L.brutus_cluster_points_grid(
                         n, Nbands, neep, stage.t_src[g].data_ptr(), stage.d_mags.data_ptr(),
@@ -529,6 +558,8 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
                 lnw[first:, late] = -np.inf
                 src = (np.flatnonzero(keep) + a * neep).astype(np.int32)
                 n = src.size
+                if t_flux is None:
+                    t_flux, t_lnw = flux_table()
                 if n:
                     h_lnw[a:b] = lnw
                     stage.d_lnw[a * neep:b * neep].copy_(stage.h_lnw[a * neep:b * neep],
@@ -543,7 +574,24 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
             part(t_flux[off:off + n], t_lnw[off:off + n], n, c0, c1 - c0)
             _mark("group %d out" % g)
             off += n
-    tab = (t_flux[:off], t_lnw[:off]) if off else None
+    if not off:
+        tab = None
+    elif shared == ngroup:
+        # every group shared the one mass grid: the table IS the magnitudes + the kept rows.
+        # Kept for a revisit as copies of the staging buffers (they are reused by the next call).
+        tab = None
+        if cache:
+            srckey = tuple(stage.srckey)
+            if getattr(stage, "src_all_key", None) != srckey:
+                stage.src_all_key, stage.t_src_all = srckey, torch.cat(stage.t_src)
+            tab = ("mags", stage.t_src_all, stage.d_mags.clone(), d_lng.clone(), d_lnsmf, neep, off)
+        else:
+            tab = ("mags",)                                  # (summed already; not kept)
+    elif shared:
+        raise RuntimeError("isochrone plug-in returned a shared mass grid for some groups of "
+                           "mass fractions and per-slice grids for others")
+    else:
+        tab = ("flux", t_flux[:off], t_lnw[:off])
     if cache:      # (the plug-in object is kept alive with its tables: `id` stays unique)
         _lru_put(_TABLE_CACHE, key, (tab, isochrone), _TABLE_CACHE_MAX)
     return tab, nchunk

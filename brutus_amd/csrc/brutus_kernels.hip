@@ -1304,11 +1304,13 @@ size_t brutus_cluster_workspace_bytes(int nobj) {
 
 int brutus_cluster_chunks(void) { return CLUSTER_CHUNKS; }
 
-int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
-                            const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
-                            const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
-                            int dim_prior, void *d_workspace, size_t workspace_bytes, int chunk_lo,
-                            int chunk_n, void *stream) {
+extern "C++" {
+template <bool MAGS>
+static int cluster_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                        const double *d_pts_lnw, ClusterMags mg, const double *d_phot,
+                        const double *d_ivar, const double *d_chi2_p, const double *d_lnorm,
+                        const int32_t *d_ndim, int dim_prior, void *d_workspace,
+                        size_t workspace_bytes, int chunk_lo, int chunk_n, void *stream) {
     const int nb = padded_nb(nfilt);
     if (nobj <= 0 || npts < 0 || nb < 0)
         return fail(BRUTUS_EINVAL, "bad cluster dimensions (nobj=%d, npts=%d, nfilt=%d)", nobj,
@@ -1316,9 +1318,11 @@ int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_f
     if (chunk_lo < 0 || chunk_n < 1 || chunk_lo + chunk_n > CLUSTER_CHUNKS)
         return fail(BRUTUS_EINVAL, "bad chunk range [%d, %d) of %d", chunk_lo, chunk_lo + chunk_n,
                     CLUSTER_CHUNKS);
-    if ((npts > 0 && (!d_pts_flux || !d_pts_lnw)) || !d_phot || !d_ivar || !d_chi2_p ||
-        !d_lnorm || !d_ndim || !d_workspace)
+    if (!d_phot || !d_ivar || !d_chi2_p || !d_lnorm || !d_ndim || !d_workspace)
         return fail(BRUTUS_EINVAL, "NULL device pointer");
+    if (npts > 0 && (MAGS ? (!mg.src || !mg.mags || !mg.lnw_eep || !mg.lnw_smf || mg.neep <= 0)
+                          : (!d_pts_flux || !d_pts_lnw)))
+        return fail(BRUTUS_EINVAL, "NULL device pointer (isochrone points)");
     if (workspace_bytes < brutus_cluster_workspace_bytes(nobj))
         return fail(BRUTUS_ENOMEM, "cluster workspace too small");
     double *pm = (double *)d_workspace + (size_t)chunk_lo * nobj;
@@ -1332,9 +1336,9 @@ int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_f
     tm.begin("k_cluster");
 #define BRUTUS_CL(N)                                                                              \
     case N:                                                                                       \
-        hipLaunchKernelGGL(k_cluster<N>, g, dim3(CL_T), 0, st, nobj, nfilt, npts, d_pts_flux,     \
-                           d_pts_lnw, d_phot, d_ivar, d_chi2_p, d_lnorm, d_ndim, dim_prior, ppb,  \
-                           pm, ps);                                                               \
+        hipLaunchKernelGGL((k_cluster<N, MAGS>), g, dim3(CL_T), 0, st, nobj, nfilt, npts,         \
+                           d_pts_flux, d_pts_lnw, mg, d_phot, d_ivar, d_chi2_p, d_lnorm, d_ndim,  \
+                           dim_prior, ppb, pm, ps);                                               \
         break;
     switch (nb) {
         BRUTUS_CL(12)
@@ -1350,6 +1354,35 @@ int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_f
     HIP_TRY(hipGetLastError());
     tm.collect();
     return 0;
+}
+}  // extern "C++"
+
+int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
+                            const double *d_pts_lnw, const double *d_phot, const double *d_ivar,
+                            const double *d_chi2_p, const double *d_lnorm, const int32_t *d_ndim,
+                            int dim_prior, void *d_workspace, size_t workspace_bytes, int chunk_lo,
+                            int chunk_n, void *stream) {
+    return cluster_part<false>(nobj, nfilt, npts, d_pts_flux, d_pts_lnw, ClusterMags{}, d_phot,
+                               d_ivar, d_chi2_p, d_lnorm, d_ndim, dim_prior, d_workspace,
+                               workspace_bytes, chunk_lo, chunk_n, stream);
+}
+
+int brutus_cluster_lnl_part_mags(int nobj, int nfilt, int npts, int neep, const int32_t *d_src,
+                                 const double *d_mags, const double *d_lnw_eep,
+                                 const double *d_lnw_smf, const double *d_phot,
+                                 const double *d_ivar, const double *d_chi2_p,
+                                 const double *d_lnorm, const int32_t *d_ndim, int dim_prior,
+                                 void *d_workspace, size_t workspace_bytes, int chunk_lo,
+                                 int chunk_n, void *stream) {
+    ClusterMags mg;
+    mg.src = d_src;
+    mg.mags = d_mags;
+    mg.lnw_eep = d_lnw_eep;
+    mg.lnw_smf = d_lnw_smf;
+    mg.neep = neep;
+    return cluster_part<true>(nobj, nfilt, npts, nullptr, nullptr, mg, d_phot, d_ivar, d_chi2_p,
+                              d_lnorm, d_ndim, dim_prior, d_workspace, workspace_bytes, chunk_lo,
+                              chunk_n, stream);
 }
 
 int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t workspace_bytes,

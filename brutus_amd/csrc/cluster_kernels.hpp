@@ -35,10 +35,21 @@ constexpr int CL_U = BRUTUS_CL_U;   // points per step of the online sum
 // largest power the kernel takes (15.5: 33 measurements) stays finite.
 constexpr double CL_DEAD_FLUX = 1e150, CL_CHI2_MAX = 1e18;
 
-template <int NB>
+// MAGS: the points come as the plug-in's magnitude table + the list of kept rows + the two
+// factors of the ln-weight (what brutus_cluster_points_grid takes), and the staging does that
+// kernel's work -- 10^(-0.4 mag), the any-finite-band test, the weight -- for its own sub-slice:
+// no flux table in between, one launch less per group of slices.
+struct ClusterMags {
+    const int32_t *src;           // (npts) kept table rows
+    const double *mags;           // (nrow, nb)
+    const double *lnw_eep, *lnw_smf;
+    int neep;
+};
+
+template <int NB, bool MAGS>
 __global__ void __launch_bounds__(CL_T, NB <= 12 ? BRUTUS_CL_OCC : 1)
 k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
-          const double *__restrict__ pts_lnw, const double *__restrict__ phot,
+          const double *__restrict__ pts_lnw, ClusterMags mg, const double *__restrict__ phot,
           const double *__restrict__ ivar, const double *__restrict__ chi2_p,
           const double *__restrict__ lnorm, const int32_t *__restrict__ ndim, int dim_prior,
           int pts_per_block, double *__restrict__ part_m, double *__restrict__ part_s) {
@@ -86,10 +97,28 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
         const int np = min(SUB, p1_ - q0);
         const int npu = (np + CL_U - 1) / CL_U * CL_U;
         __syncthreads();                                   // previous sub-slice fully consumed
+        if constexpr (MAGS) {
+            // fluxes first, one (point, band) per thread and turn (an exponential each), ...
+            for (int idx = threadIdx.x; idx < npu * NB; idx += CL_T) {
+                const int c = idx / NB, b = idx - c * NB;
+                double v = 0.;
+                if (c < np && b < nb) v = exp10(-0.4 * mg.mags[(int64_t)mg.src[q0 + c] * nb + b]);
+                s_pts[c * STRIDE + b] = v;
+            }
+            __syncthreads();
+        }
         for (int c = threadIdx.x; c < npu; c += CL_T) {
             const bool real = c < np;
-            const double *src = pts_flux + (int64_t)(q0 + (real ? c : 0)) * nb;
-            const double w = real ? exp(pts_lnw[q0 + c]) : 0.;       // weight (0 for a dropped point)
+            double w = 0.;                                           // weight (0 for a dropped point)
+            if (real) {
+                if constexpr (MAGS) {
+                    const int r = mg.src[q0 + c];
+                    w = exp(mg.lnw_eep[r % mg.neep] + mg.lnw_smf[r / mg.neep]);
+                } else {
+                    w = exp(pts_lnw[q0 + c]);
+                }
+            }
+            const double *src = MAGS ? s_pts + c * STRIDE : pts_flux + (int64_t)(q0 + (real ? c : 0)) * nb;
             const bool dead = !(w > 0.) || !(w < INFINITY);
             bool hole = false, any = false;
             for (int b = 0; b < NB; ++b) {

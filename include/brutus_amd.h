@@ -319,6 +319,17 @@ int brutus_cluster_lnl_part(int nobj, int nfilt, int npts, const double *d_pts_f
                             const double *d_lnorm, const int32_t *d_ndim, int dim_prior,
                             void *d_workspace, size_t workspace_bytes, int chunk_lo,
                             int chunk_n, void *stream);
+/* `_part` straight from the plug-in's magnitude table: the inputs of
+ * brutus_cluster_points_grid (kept rows d_src (npts), d_mags (nrow, nfilt), the two factors of
+ * the ln-weight, neep) instead of a flux table -- the kernel forms fluxes and weights of its
+ * own sub-slices, one launch and one table less per piece. */
+int brutus_cluster_lnl_part_mags(int nobj, int nfilt, int npts, int neep, const int32_t *d_src,
+                                 const double *d_mags, const double *d_lnw_eep,
+                                 const double *d_lnw_smf, const double *d_phot,
+                                 const double *d_ivar, const double *d_chi2_p,
+                                 const double *d_lnorm, const int32_t *d_ndim, int dim_prior,
+                                 void *d_workspace, size_t workspace_bytes, int chunk_lo,
+                                 int chunk_n, void *stream);
 int brutus_cluster_lnl_merge(int nobj, int nchunk, void *d_workspace, size_t workspace_bytes,
                              double *d_lnl, void *stream);
 /* Outlier mixture and total of cluster.py:410-414 on the device: d_lnl_mix (nobj) =
