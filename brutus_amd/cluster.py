@@ -400,8 +400,10 @@ def _staging(nrow, nb, dev, torch):
 # device at the end 0.19 ms.  A plug-in that takes milliseconds per slice (the MIST /
 # neural-net isochrones) hides the device entirely with any split; BRUTUS_CLUSTER_PIPELINE
 # sets the number of groups (1: one call to the plug-in and one sum, as before round 4).
-# (Tried: the group's copy on a stream of its own, beside the previous group's sum: the
-# stream context and two events cost the host more than the 0.05 ms they free -- 1 370 -> 1 220.)
+# (Tried: the group's copy on a stream of its own, beside the previous group's sum.  Through
+# torch the stream context and two events cost the host more than the 0.05 ms they free
+# -- 1 370 -> 1 220; through a library call (hipMemcpyAsync on a side stream + event) no
+# difference either way, 1 384-1 402 against 1 399-1 442: the kernels are the chain.)
 _PIPELINE_GROUPS = 3
 _PIPELINE_GROWTH = 1.5
 
