@@ -89,7 +89,9 @@ struct Workspace {
     // brutus_fit_batch
     int32_t *ids;       // (S,) star list of a launch
     int32_t *ids2;      // (S,) second list (device-driven call: probe list beside the redo list)
-    int32_t *ctr;       // (8,) device-driven call: [0] stars to probe, [1] stars to redo, [3] "host path needed"
+    int32_t *ctr;       // (8,) device-driven call: [0] stars to probe, [1] stars to redo, [3] "host path needed";
+                        //      both drivers: [4], [5] lengths of the hot (block, star) lists of the two k_top1 launches
+    int32_t *hot;       // (nblk2 * S,) hot (block, star) pairs of a k_top1 launch
     int32_t *kfix;      // (S,)
     double *thr_cull, *maxsurv, *thr_sel;
     int32_t *surv_idx;  // (S * nmodel,) worst case: candidate lists, then band queues, then derived lists
@@ -180,6 +182,7 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool fit) {
         const size_t nblk2 = (size_t)(ntile + F2_T - 1) / F2_T;
         w.s32 = (Star32 *)take(sizeof(Star32) * nstar);
         w.part32 = (float *)take(sizeof(float) * nblk2 * nstar * NV32);
+        w.hot = (int32_t *)take(sizeof(int32_t) * nblk2 * nstar);
         w.st32 = (float *)take(sizeof(float) * nstar * NV32);
         w.status = (int32_t *)take(sizeof(int32_t) * nstar);
         w.ids_all = (int32_t *)take(sizeof(int32_t) * nstar);
@@ -493,12 +496,27 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     q.mtol_lo = (float)(p.mtol * 0.998 - 1e-4);
     q.dim_prior = p.dim_prior;
     q.nfilt = nfilt;
+    // Long star lists take the star-lane pass (pre32s_kernels.hpp: lane = star, the models' rows
+    // broadcast from LDS); short ones -- the re-run over a handful of stars, lists with other
+    // sweep counts than the opening pass's two -- the tile pass.
+    bool lanes_are_stars = brutus_i_pre32s_bands(NB) && mode != 2 && nrun >= 32 &&
+                           env_int("BRUTUS_PRE32_STAR_LANES", 1) != 0;
+    if (lanes_are_stars && !RVF)
+        for (int k = 0; k < nrun && lanes_are_stars; ++k) lanes_are_stars = kfix[ids[k]] == 2;
+    if (lanes_are_stars) {
+        tm.begin("k_pre32");
+        if (brutus_i_pre32s_launch(NB, RVF ? 1 : 0, grid, nmodel, nmodel_pad, nstar, nrun, list, w.s32, &q,
+                                   w.lnlp32, w.lnpr32, w.part32, st))
+            return fail(BRUTUS_EHIP, "star-lane float32 pass: launch failed");
+        tm.end();
+    } else {
     tm.begin("k_pre32");
     hipLaunchKernelGGL((k_pre32<NB, RVF, G>), dim3(8 * ((nblkx + 7) / 8) * ((nrun + G - 1) / G)),
                        dim3(TILE), 0, st, grid,
                        nmodel, nmodel_pad, nstar, nrun, list, w.s32, q, w.kfix, ntile, w.lnlp32,
                        w.lnpr32, w.part32, nrun_dev);
     tm.end();
+    }
     hipLaunchKernelGGL(k_pre_decide, dim3(nrun), dim3(256), 0, st, nblkx, nstar, list, w.part32,
                        w.s32, (float)p.ln_init, RVF ? 1 : 0, w.kfix, accept, w.st32, w.k1, w.status,
                        w.nomA, mode == 1 ? w.ctr : (int32_t *)nullptr, w.ids2, w.ids, nrun_dev);
@@ -528,7 +546,7 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     h_counts[0] = h_counts[1] = h_counts[2] = 0;
 
     // ---- float32 pass over the whole grid; K1 where float32 can decide it ----------
-    hipLaunchKernelGGL(k_prep32, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.stars,
+    hipLaunchKernelGGL(k_prep32, dim3(nstar), dim3(64), 0, st, nstar, w.stars,
                        (float)env_double("BRUTUS_EPS_SCALE", 1.0), p.dim_prior, w.s32);
     // Two drivers for the same kernels.  DEVICE-DRIVEN (default): which stars need the exact K1
     // probe, which need their float32 planes redone and which iterate on in the flux phase is
@@ -540,8 +558,8 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     // the HOST-DRIVEN driver below (round 3's: a host decision after the float32 pass and after
     // every flux launch; each one idles the stream for a round trip).
     const int FLUX_ROUNDS = env_int("BRUTUS_FLUX_ROUNDS", 4);       // (development switch)
+    HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(int32_t) * 8, st));
     if (device_driven) {
-        HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(int32_t) * 8, st));
         if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm, 1)) return rc;
         if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, nullptr, p, max_iter, w, st, tm)) return rc;
         if (!RVF)       // (pinned Rv: the planes never depend on the sweep count)
@@ -576,7 +594,17 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     }
 
     // ---- exact cull threshold ---------------------------------------------------------
+    // (k_hot_list + k_top1: the hot (block, star) pairs as a list; k_top itself -- every pair
+    // gets a workgroup, nearly all of which leave at once -- stays behind BRUTUS_TOP_LIST=0)
+    const bool top_list = env_int("BRUTUS_TOP_LIST", 1) != 0;
+    constexpr int TOP_BLOCKS = 1024;
     tm.begin("k_top");
+    if (top_list) {
+        hipLaunchKernelGGL(k_hot_list, dim3(nstar), dim3(256), 0, st, nblkx, nstar, 0, w.part32, w.nomA,
+                           (const double *)nullptr, w.s32, (double *)nullptr, w.part, w.hot, w.ctr + 4);
+        hipLaunchKernelGGL((k_top1<NB, RVF>), dim3(TOP_BLOCKS), blk, 0, st, grid, nmodel, nmodel_pad, nstar,
+                           w.stars, p, w.k1, ntile, 0, w.lnlp32, w.nomA, w.hot, w.ctr + 4, w.part, aud);
+    } else
     hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
                        nmodel_pad, nstar, nstar, w.ids_all, w.stars, p, w.k1, ntile, 0, w.lnlp32,
                        w.nomA, (const float *)nullptr, w.part32, w.part, aud);
@@ -649,11 +677,19 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     }
 
     // ---- exact first-cut threshold, selection masks ---------------------------------------
-    hipLaunchKernelGGL(k_nomB, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxsurv, w.s32, w.nomB);
     tm.begin("k_top");
+    if (top_list) {
+        hipLaunchKernelGGL(k_hot_list, dim3(nstar), dim3(256), 0, st, nblkx, nstar, 1, w.part32,
+                           (const double *)nullptr, w.maxsurv, w.s32, w.nomB, w.part, w.hot, w.ctr + 5);
+        hipLaunchKernelGGL((k_top1<NB, RVF>), dim3(TOP_BLOCKS), blk, 0, st, grid, nmodel, nmodel_pad, nstar,
+                           w.stars, p, w.k1, ntile, 1, w.lnpr32, w.nomB, w.hot, w.ctr + 5, w.part,
+                           aud ? aud + nstar : nullptr);
+    } else {
+    hipLaunchKernelGGL(k_nomB, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, w.maxsurv, w.s32, w.nomB);
     hipLaunchKernelGGL((k_top<NB, RVF, G>), dim3(nblkx, (nstar + G - 1) / G), blk, 0, st, grid, nmodel,
                        nmodel_pad, nstar, nstar, w.ids_all, w.stars, p, w.k1, ntile, 1, w.lnpr32,
                        w.nomB, w.lnpr32, w.part32, w.part, aud ? aud + nstar : nullptr);
+    }
     tm.end();
     hipLaunchKernelGGL(k_top_decide, dim3(nstar), dim3(256), 0, st, nblkx, nstar, w.ids_all, 1, w.part,
                        w.s32, p.ln_wt, w.maxsurv, w.thr_sel, (double *)nullptr);
@@ -1175,7 +1211,7 @@ int check_common(int64_t nmodel, int nfilt, int nstar) {
 int launch_prep(int nstar, int nfilt, const double *d_flux, const double *d_err,
                 const uint8_t *d_mask, const double *d_par, const double *d_perr, int has_par,
                 Workspace &w, int32_t *d_ndim, hipStream_t st) {
-    hipLaunchKernelGGL(k_prep, dim3((nstar + 63) / 64), dim3(64), 0, st, nstar, nfilt, d_flux,
+    hipLaunchKernelGGL(k_prep, dim3(nstar), dim3(64), 0, st, nstar, nfilt, d_flux,
                        d_err, d_mask, d_par, d_perr, (d_par && d_perr) ? has_par : 0, w.stars,
                        d_ndim);
     HIP_TRY(hipGetLastError());

@@ -44,62 +44,66 @@
 // and in tests/test_gpu_fit2.py).
 #pragma once
 
+#include "pre32_types.hpp"
+
 namespace {
-
-constexpr int F2_T = 8;        // tiles per workgroup (2048 models)
-constexpr int NV32 = 10;       // float32 partial maxima per (block, star)
-
-struct Star32 {
-    float gc[NBMAX];    // magnitude - weighted mean magnitude
-    float w[NBMAX];     // 1 / mags_var
-    float dd[NBMAX];    // flux / D,  D = 10^(-0.4 gbar)
-    float iv[NBMAX];    // D^2 / flux variance
-    float S, DD2, gbar;
-    float par, par_ivar, sp_mean, sp_var;
-    float c0, c1;
-    float eps, epsw;    // bounds on |f32 - f64| of lnl_p / lnprob and of logwt
-    float chi2_lo;      // below this chi2 float32 is not trusted (re-evaluated in float64)
-    int has_par, sp_on, ok;
-};
-
-struct P32 {
-    float avmin, avmax, rvmin, rvmax, av_mean, av_ivar, rv_mean, rv_ivar;
-    float mtol_hi, mtol_lo;     // mtol +- slack for the step test
-    int dim_prior, nfilt;
-};
 
 // ---------------------------------------------------------------------------
 // per-star float32 companion of StarPrep
 // ---------------------------------------------------------------------------
-__global__ void k_prep32(int nstar, const StarPrep *__restrict__ stars, float eps_scale,
-                         int dim_prior, Star32 *__restrict__ out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64)
+k_prep32(int nstar, const StarPrep *__restrict__ stars, float eps_scale, int dim_prior,
+         Star32 *__restrict__ out) {
+    // one wave per star, lane = band (like k_prep); the band sums are added up in band order
+    static_assert(NBMAX <= 64, "one lane per band");
+    __shared__ double s_a[NBMAX], s_b[NBMAX], s_c[NBMAX];
+    __shared__ double s_gbar, s_D;
+    __shared__ int s_bad;
+    const int s = blockIdx.x, j = threadIdx.x;
     if (s >= nstar) return;
     const StarPrep &sp = stars[s];
-    Star32 o;
-    double sw = 0., swg = 0.;
-    for (int j = 0; j < NBMAX; ++j) {
-        // bands with a non-positive flux carry mags_var = 1e50: no weight
-        const double w = sp.iW[j] > 1e-40 ? sp.iW[j] : 0.;
-        sw += w;
-        swg += w * sp.g[j];
+    Star32 &o = out[s];
+    // bands with a non-positive flux carry mags_var = 1e50: no weight
+    double w = 0.;
+    if (j < NBMAX) {
+        w = sp.iW[j] > 1e-40 ? sp.iW[j] : 0.;
+        s_a[j] = w;
+        s_b[j] = w * sp.g[j];
     }
-    const double gbar = sw > 0. ? swg / sw : 0.;
-    const double D = exp10(-0.4 * gbar);
-    double DD2 = 0., wy = 0., snmax = 0.;
-    bool ok = sw > 0. && isfinite(gbar) && isfinite(D) && D > 1e-30 && D < 1e30;
-    for (int j = 0; j < NBMAX; ++j) {
-        const double w = sp.iW[j] > 1e-40 ? sp.iW[j] : 0.;
+    if (j == 0) s_bad = 0;
+    __syncthreads();
+    if (j == 0) {
+        double sw = 0., swg = 0.;
+        for (int k = 0; k < NBMAX; ++k) {
+            sw += s_a[k];
+            swg += s_b[k];
+        }
+        const double gbar = sw > 0. ? swg / sw : 0.;
+        const double D = exp10(-0.4 * gbar);
+        s_gbar = gbar;
+        s_D = D;
+        if (!(sw > 0. && isfinite(gbar) && isfinite(D) && D > 1e-30 && D < 1e30)) s_bad = 1;
+    }
+    __syncthreads();
+    const double gbar = s_gbar, D = s_D;
+    if (j < NBMAX) {
         const double dd = sp.d[j] / D, iv = sp.iV[j] * D * D;
         o.gc[j] = (float)(w > 0. ? sp.g[j] - gbar : 0.);
         o.w[j] = (float)w;
         o.dd[j] = (float)dd;
         o.iv[j] = (float)iv;
-        DD2 += dd * dd * iv;
-        wy += w;
-        const double sn = fabs(dd) * sqrt(iv);
-        snmax = sn > snmax ? sn : snmax;
-        if (!(fabs(dd) < 1e15) || !(iv < 1e30) || !(w < 1e30)) ok = false;
+        s_a[j] = dd * dd * iv;
+        s_b[j] = w;
+        s_c[j] = fabs(dd) * sqrt(iv);
+        if (!(fabs(dd) < 1e15) || !(iv < 1e30) || !(w < 1e30)) atomicOr(&s_bad, 1);
+    }
+    __syncthreads();
+    if (j != 0) return;
+    double DD2 = 0., wy = 0., snmax = 0.;
+    for (int k = 0; k < NBMAX; ++k) {
+        DD2 += s_a[k];
+        wy += s_b[k];
+        snmax = s_c[k] > snmax ? s_c[k] : snmax;
     }
     o.S = (float)sp.S;
     o.DD2 = (float)DD2;
@@ -122,8 +126,7 @@ __global__ void k_prep32(int nstar, const StarPrep *__restrict__ stars, float ep
     o.epsw = (float)(eps_scale * (0.02 + 64. * u * wy));
     // ln(chi2) of the dimensionality prior amplifies the chi2 error by c1 / chi2
     o.chi2_lo = fmaxf(4.f * o.eps, dim_prior ? 0.5f * fabsf(o.c1) + 0.5f : 0.f);
-    o.ok = ok ? 1 : 0;
-    out[s] = o;
+    o.ok = s_bad ? 0 : 1;
 }
 
 // ---------------------------------------------------------------------------
@@ -673,6 +676,89 @@ k_top(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int ns
         x = slot[2][g] > x ? slot[2][g] : x;
         x = slot[3][g] > x ? slot[3][g] : x;
         part[(int64_t)blockIdx.x * nstar + star_ids[g0 + g]] = x;
+    }
+}
+
+// ---------------------------------------------------------------------------
+// k_hot_list + k_top1: the same exact maxima from a LIST of the hot (block, star) pairs
+// ---------------------------------------------------------------------------
+// k_top is launched over every (block, star group) and all but a few per cent of its ~12 000
+// workgroups find nothing to do: 0.08 ms per launch, twice per call, for some hundred hot
+// pairs.  k_hot_list (one workgroup per star) lists the pairs whose float32 block maximum
+// reaches the nominee level (or that hold a NaN lane) and marks the others' partials -inf;
+// k_top1 walks the list with a fixed launch, one (block, star) per workgroup and turn.
+//   mode 0: nom = nomA (k_pre_decide);   mode 1: nomB[s] = maxsurv[s] - eps is formed here.
+// An entry is  block * BRUTUS_MAX_BATCH + star.
+__global__ void __launch_bounds__(256)
+k_hot_list(int nblkx, int nstar, int mode, const float *__restrict__ part32,
+           const double *__restrict__ nomA, const double *__restrict__ maxsurv,
+           const Star32 *__restrict__ s32, double *__restrict__ nomB, double *__restrict__ part,
+           int32_t *__restrict__ hot, int32_t *__restrict__ nhot) {
+    const int s = blockIdx.x;
+    double nm;
+    if (mode == 0) {
+        nm = nomA[s];
+    } else {
+        nm = maxsurv[s] - (double)s32[s].eps;
+        if (threadIdx.x == 0) nomB[s] = nm;
+    }
+    for (int b = threadIdx.x; b < nblkx; b += blockDim.x) {
+        const float *pp = part32 + ((int64_t)b * nstar + s) * NV32;
+        const bool is_hot = !((double)pp[6 + mode] < nm) || pp[9] > 0.f;
+        if (is_hot) hot[atomicAdd(nhot, 1)] = b * BRUTUS_MAX_BATCH + s;
+        else part[(int64_t)b * nstar + s] = -INFINITY;
+    }
+}
+
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(TILE, top_waves(NB))
+k_top1(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
+       const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1, int ntile,
+       int mode, const float *__restrict__ plane32, const double *__restrict__ nom,
+       const int32_t *__restrict__ hot, const int32_t *__restrict__ nhot,
+       double *__restrict__ part, float *__restrict__ aud) {
+    __shared__ double slot[4];
+    __shared__ double s_tbl[64];
+    const int n = *nhot;
+    if ((int)blockIdx.x >= n) return;
+    stage_exp_table(s_tbl);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int e = blockIdx.x; e < n; e += gridDim.x) {
+        const int entry = hot[e];
+        const int b = entry / BRUTUS_MAX_BATCH, s = entry - b * BRUTUS_MAX_BATCH;
+        const int t0 = b * F2_T, t1 = min(ntile, t0 + F2_T);
+        const StarPrep &sp = stars[s];
+        const double nm_s = nom[s];
+        const int K = k1[s];
+        // the block's float32 values first, all in flight at once (clamped addresses)
+        float v[F2_T];
+#pragma unroll
+        for (int u = 0; u < F2_T; ++u) {
+            const int64_t i = (int64_t)(t0 + u) * TILE + threadIdx.x;
+            v[u] = plane32[(int64_t)s * nmodel + (i < nmodel ? i : nmodel - 1)];
+        }
+        double mx = -INFINITY;
+#pragma unroll
+        for (int u = 0; u < F2_T; ++u) {
+            const int64_t i = (int64_t)(t0 + u) * TILE + threadIdx.x;
+            // nominee: not below the level (NaN counts); mode 1: and not a survivor (tagged)
+            bool mine = t0 + u < t1 && i < nmodel && !((double)v[u] < nm_s);
+            if (mode == 1 && mine) mine = !surv_is(v[u]);
+            if (__ballot(mine) == 0ull) continue;          // (wave-uniform)
+            Tile64<NB, RVF> tl;
+            tile_load<NB, RVF>(grid, nmodel_pad, i, p.rv_mean, tl);
+            double av, rv;
+            mag_phase<NB, RVF>(tl, sp, p, K, av, rv);
+            Mle m;
+            mle_at<NB, RVF, false>(tl, sp, p, av, rv, s_tbl, m);
+            double val;
+            if (mode == 0) val = cull_stat(sp, m);
+            else val = first_cut_lnprob(sp, final_lnl<false>(sp, p, m.chi2, false), m.scale, m.i00);
+            if (mine) audit(aud, s, v[u], val, nm_s);
+            if (mine && val == val) mx = val > mx ? val : mx;
+        }
+        block_max_store(mx, slot, part + (int64_t)b * nstar + s);
     }
 }
 

@@ -185,29 +185,34 @@ __device__ __forceinline__ void store_mle(const Planes &pl, int64_t o, const Mle
 // ---------------------------------------------------------------------------
 
 // Per-star preparation (fitting.py:706-725).  One thread per star.
-__global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
-                       const double *__restrict__ err, const uint8_t *__restrict__ mask,
-                       const double *__restrict__ par, const double *__restrict__ perr,
-                       int has_parallax, StarPrep *__restrict__ out,
-                       int32_t *__restrict__ ndim_out) {
-    const int s = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ void __launch_bounds__(64)
+k_prep(int nstar, int nfilt, const double *__restrict__ flux,
+       const double *__restrict__ err, const uint8_t *__restrict__ mask,
+       const double *__restrict__ par, const double *__restrict__ perr,
+       int has_parallax, StarPrep *__restrict__ out, int32_t *__restrict__ ndim_out) {
+    // One wave per star, lane = band: the logarithms and divisions of the bands run side by
+    // side (one thread per star looping over its bands was 23 us of dependent float64 latency
+    // per call); the three band sums are then added up by every lane in the reference's order,
+    // j = 0, 1, ..., so the result does not depend on how the work was spread.
+    static_assert(NBMAX <= 64, "one lane per band");
+    __shared__ double s_w[NBMAX], s_lnv[NBMAX], s_d2[NBMAX];
+    __shared__ int s_ok[NBMAX];
+    const int s = blockIdx.x, j = threadIdx.x;
     if (s >= nstar) return;
-    StarPrep sp;
-    int ndim = 0;
-    double S = 0., sumlnv = 0., D2 = 0.;
+    StarPrep &sp = out[s];
     const double kmag = 2.5 / log(10.);
-    for (int j = 0; j < NBMAX; ++j) {
-        double d = 0., iv = 0., g = 0., iw = 0.;
+    if (j < NBMAX) {
+        double d = 0., iv = 0., g = 0., iw = 0., lnv = 0., d2 = 0.;
+        bool ok = false;
         if (j < nfilt) {
             const double f = flux[(int64_t)s * nfilt + j];
             const double e = err[(int64_t)s * nfilt + j];
-            const bool ok = mask[(int64_t)s * nfilt + j] && isfinite(f) && isfinite(e) && e > 0.;
+            ok = mask[(int64_t)s * nfilt + j] && isfinite(f) && isfinite(e) && e > 0.;
             if (ok) {
-                ++ndim;
                 const double v = e * e;
                 d = f;
                 iv = 1. / v;
-                sumlnv += log(v);
+                lnv = log(v);
                 g = -2.5 * log10(f);
                 double W = kmag * kmag * v / (f * f);
                 if (!isfinite(g)) {                           // fitting.py:724-725
@@ -215,14 +220,28 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
                     W = 1e50;
                 }
                 iw = 1. / W;
-                S += 1. / W;
-                D2 += f * f * iv;
+                d2 = f * f * iv;
             }
         }
         sp.d[j] = d;
         sp.iV[j] = iv;
         sp.g[j] = g;
         sp.iW[j] = iw;
+        s_w[j] = iw;
+        s_lnv[j] = lnv;
+        s_d2[j] = d2;
+        s_ok[j] = ok ? 1 : 0;
+    }
+    __syncthreads();
+    if (j != 0) return;
+    int ndim = 0;
+    double S = 0., sumlnv = 0., D2 = 0.;
+    for (int k = 0; k < NBMAX; ++k) {
+        if (!s_ok[k]) continue;
+        ++ndim;
+        sumlnv += s_lnv[k];
+        S += s_w[k];
+        D2 += s_d2[k];
     }
     sp.S = S;
     sp.D2 = D2;
@@ -245,17 +264,8 @@ __global__ void k_prep(int nstar, int nfilt, const double *__restrict__ flux,
     sp.sp_mean = sp.sp_on ? pm * pm + pe * pe : 0.;
     sp.sp_var = sp.sp_on ? 2. * pe * pe * pe * pe + 4. * pm * pm * pe * pe : 0.;
     sp.pad_ = 0;
-    out[s] = sp;
     ndim_out[s] = ndim;
 }
-
-// AoS (nmodel, nfilt, 3) -> device grid blob; padded entries zero.  With
-// Np = nmodel_pad and offsets in 4-byte units:
-//   [0, 3*NB*Np)          f32 band-major SoA [NB][3][Np]   full-grid scans
-//   [3*NB*Np, 6*NB*Np)    f32 model-major   [Np][NB][3]    single-model gathers
-//   [6*NB*Np, 8*NB*Np)    f64 band-major    [NB][Np]       F0 = 10^(-0.4 mag)
-// F0 (the unreddened model flux, fitting.py:529) is star-independent, so it
-// is tabulated once here instead of 12 exponentials per tile of the full scan.
 
 __global__ void k_relayout(const float *__restrict__ aos, int64_t nmodel, int nfilt, int nb,
                            int64_t nmodel_pad, float *__restrict__ blob) {

@@ -1,0 +1,373 @@
+// pre32s_kernels.hpp -- the float32 proof pass with the roles of the lanes swapped: lane = STAR,
+// the models pass by as rows broadcast from LDS.  Compiled in the library's second translation unit,
+// pre32s_unit.hip (same statistics, same outputs as k_pre32 of fit2_kernels.hpp, which stays for
+// short star lists and for more than 12 bands).
+//
+// Why (round 5; profiles/r05_pre32_bound.txt).  k_pre32 (lane = model, four stars per
+// workgroup) holds the tile's coefficients in vector registers and takes the stars' ~60
+// constants as scalar operands -- 4 x 60 scalars do not fit the scalar file, so every (tile,
+// star) step reloads them through the scalar cache in ~8 dependent s_load / s_waitcnt
+// lgkmcnt(0) round trips; with its branches (`live`, `lw == lw`, has_par, sp_on) and the
+// 40-value cross-lane reduction at the end of a workgroup it issues ~295 vector instructions
+// per (star, model) pair, 19 of them transcendental (3 issue slots each, tools/ubench/
+// dpp_rate.hip): 0.57 ms of pure issue per 128 stars at the measured 1.16 ns per float32
+// wave-instruction and SIMD, 0.69 ms observed.  Here a wave owns 64 STARS for a run of models:
+// the stars' constants stay in ~60 vector registers for the whole run; everything that depends
+// on the model alone (the centred magnitudes times -0.4 log2(10), R = r0 + Rv dr) is computed
+// once per model, not once per (star, model), and reaches the lanes as a row of broadcast LDS
+// reads; every per-star condition is a select, the running maxima live in the lanes (no
+// cross-lane reduction at all), and the two float32 planes leave through a 16-model LDS
+// transposition as 64-byte row segments.  ~230 vector instructions per pair.
+// Forms tried on the way (same-box A/B, profiles/r05_pre32_forms.txt):
+//  * the rows as a table in global memory read with scalar loads, one batch per step: every row
+//    a scalar-cache miss, ~1.3 us of exposed latency per step -- 0.80-0.90 ms; a streaming read
+//    does not belong on the scalar path;
+//  * 49 broadcast values per step (mc AND -0.4 log2(10) mc, R, R^2, mbar) against 25 (scaled
+//    magnitudes, below; R^2 formed in the lanes): 0.605 against 0.64 ms -- neither the LDS pipe
+//    nor the global stores (left out: 0.613) set the pace, the vector instructions do (measured
+//    1.16 ns per float32 wave-instruction and SIMD from two waves per SIMD up, 3 slots per
+//    transcendental: 234 + 34 slots x 1536 steps per SIMD = 0.48 ms at full issue rate);
+//  * the row in the LANES of four registers, read through the DPP row broadcast of the
+//    consuming instructions (v_fmac_f32_dpp row_newbcast:j): no LDS traffic to speak of, but a
+//    DPP operation issues at 0.6 of the plain rate (ubench) and hipcc cannot see a VALU-write ->
+//    DPP-read hazard inside asm statements (a software-pipelined form produced wrong maxima):
+//    0.74 ms.
+// Scaled magnitudes.  With c = -0.4 log2(10), the stars' centred magnitudes pre-multiplied
+// (gcC = c gc, gbarC = c gbar) and the models' too (mcC = c mc, mbarC = c mbar), every sum
+// that carries y picks up a factor c per y, and the Av solve of fitting.py:176-204 holds
+// verbatim for av' = c av with limits and prior mean scaled (c < 0 swaps the two clamps);
+// av' is what the flux phase's exponent wants (2^(av' R + mcC)), so the models' plain centred
+// magnitudes are never needed.
+// Semantics to hold: /root/reference/brutus/fitting.py:173-264 (sweep statistics), :743-759
+// (cull statistic), :976-985 + pdf.py:209-218 (first-cut statistic); float32 only ever
+// classifies (see fit2_kernels.hpp).
+#pragma once
+
+#include "pre32_types.hpp"
+
+namespace {
+
+constexpr int PS_M = 16;                      // models per tile (staging and transposition)
+constexpr int PS_STRIDE = 66;                 // floats per transposition row: (2 m + star) mod 32 is conflict-free
+constexpr int PS_WM = F2_T * PS_TILE / 4;        // models per wave: a block of F2_T tiles over four waves
+constexpr int ps_row(int nb) { return 3 * nb + 4; }
+// (16 bands: 168 registers + 72-160 bytes of scratch at three waves per SIMD -- k_pre32 keeps them)
+constexpr bool ps_bands(int nb) { return nb <= 12; }
+
+// v_max_f32 as the hardware defines it: a NaN operand yields the other one (fmaxf compiles to
+// two canonicalising v_max per call on top)
+__device__ __forceinline__ float vmaxf(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+// ln x for a normal-range positive argument: v_log_f32 (log2, 1 ulp) times ln 2 -- __logf's
+// denormal rescue and its extended-precision multiplication are ten more instructions, and the
+// arguments here (chi2 above chi2_lo >= 0.5, variances) never need them
+__device__ __forceinline__ float ln_pos(float x) { return 0.69314718055994531f * __builtin_amdgcn_logf(x); }
+// LDS hand-over between the lanes of ONE wave (its instructions reach the LDS in order: no
+// hardware wait is needed, but the compiler must not move the reads of other lanes' words
+// across the writes, in either direction)
+__device__ __forceinline__ void ps_wave_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("" ::: "memory");
+}
+
+// One workgroup = one block of F2_T tiles (the unit of part32) x one group of 64 stars; wave w
+// takes a quarter of the block's models, in tiles of 16.  Per tile: the wave's lanes (model m =
+// lane & 15, band group lane >> 4) turn the 16 models' raw coefficients -- requested a whole
+// tile ahead -- into rows of everything that depends on the model alone ([0, NB) mcC_j =
+// c (m_j - mbar), [NB, 2NB) R_j = r0_j + rv_mean dr_j (RVF) or r0_j, [2NB, 3NB) R_j^2 (RVF)
+// or dr_j, then mbarC = c mbar) in LDS; then lane = star, and each of the 16 steps reads its row with
+// uniform-address ds_read_b128 (a broadcast: four values per instruction into every lane).
+// The star group is the FAST block index: the workgroups that run together read the same
+// coefficients.  General kernels: every star of the launch has kfix = 2 (the opening pass; a
+// re-run with other sweep counts goes through k_pre32).
+template <int NB, bool RVF>
+__global__ void __launch_bounds__(PS_TILE, 3)
+k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+         const int32_t *__restrict__ star_ids, const Star32 *__restrict__ stars, P32 p,
+         float *__restrict__ lnlp32, float *__restrict__ lnpr32, float *__restrict__ part) {
+    constexpr int ROW = ps_row(NB);
+    constexpr int NBG = NB / 4;                   // bands per staging lane
+    constexpr int NF = 3;                         // per-band fields of a row
+    __shared__ float s_t[4][2][PS_M][PS_STRIDE];
+    __shared__ __attribute__((aligned(16))) float s_row[4][PS_M][ROW];
+    __shared__ int64_t s_base[64];
+    const float C10 = -1.32877123795494494f;      // c = -0.4 log2(10)
+    const float NINF = -INFINITY;
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int ngroup = (nrun + 63) >> 6;
+    const int bx = blockIdx.x / ngroup, sg = blockIdx.x - bx * ngroup;
+    const int sl = sg * 64 + lane;
+    const bool slive = sl < nrun;
+    const int s = star_ids[slive ? sl : nrun - 1];
+    if (wv == 0) s_base[lane] = slive ? (int64_t)s * nmodel : (int64_t)-1;
+    // the star's constants, resident for the whole run of models
+    const Star32 &sp = stars[s];
+    float gcC[NB], w[NB], dd[NB], iv[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+        gcC[j] = C10 * sp.gc[j];
+        w[j] = sp.w[j];
+        dd[j] = sp.dd[j];
+        iv[j] = sp.iv[j];
+    }
+    const float S = sp.S, rS = __builtin_amdgcn_rcpf(sp.S), gbarC = C10 * sp.gbar, DD2 = sp.DD2;
+    const bool has_par = sp.has_par != 0, sp_on = sp.sp_on != 0;
+    // (a star float32 cannot represent: both limits at +inf turn every value into NaN)
+    const float eps4 = sp.ok ? 4.f * sp.eps : INFINITY, chi2_lo = sp.ok ? sp.chi2_lo : INFINITY;
+    const float par = has_par ? sp.par : 0.f, par_hiv = has_par ? 0.5f * sp.par_ivar : 0.f;
+    const float sp_mean = sp.sp_mean, sp_var = sp.sp_var, c0 = sp.c0, c1 = sp.c1;
+    const bool any_par = __ballot(has_par) != 0ull, any_sp = __ballot(sp_on) != 0ull;     // wave-uniform
+    // the Av solve in av' = c av (c < 0: the clamps trade places)
+    const float avm = C10 * p.av_mean, av_lo = C10 * p.avmax, av_hi = C10 * p.avmin;
+    const float tol_hi = -C10 * p.mtol_hi, tol_lo = -C10 * p.mtol_lo;
+    const float lw_scale = -0.5f / (C10 * C10);
+    float mx0 = NINF, mx1 = NINF, mx2 = NINF, mx3 = NINF, mx4 = NINF, mx5 = NINF, mx6 = NINF, mx7 = NINF,
+          mx8 = NINF, mx9 = NINF;
+    const int64_t i0 = (int64_t)bx * (F2_T * PS_TILE) + (int64_t)wv * PS_WM;
+    const int64_t i1 = i0 + PS_WM < nmodel ? i0 + PS_WM : nmodel;
+    // staging role of this lane
+    const int sm = lane & 15, bg = lane >> 4;
+    const float inv_nf = 1.f / (float)p.nfilt;
+    float cm[NBG], cr0[NBG], cdr[NBG];
+    auto fetch = [&](int64_t ib) {
+        int64_t i = ib + sm;
+        i = i < nmodel_pad ? i : nmodel_pad - 1;
+#pragma unroll
+        for (int k = 0; k < NBG; ++k) {
+            const float *q = grid + (int64_t)(3 * (bg * NBG + k)) * nmodel_pad + i;
+            cm[k] = q[0];
+            cr0[k] = q[nmodel_pad];
+            cdr[k] = q[2 * nmodel_pad];
+        }
+    };
+    if (i0 < i1) fetch(i0);
+    __syncthreads();
+    for (int64_t ib = i0; ib < i1; ib += PS_M) {
+        const int nm = (int)(i1 - ib < PS_M ? i1 - ib : PS_M);
+        {   // the tile's rows
+            float ps = 0.f;
+#pragma unroll
+            for (int k = 0; k < NBG; ++k)
+                if (bg * NBG + k < p.nfilt) ps += cm[k];
+            ps += __shfl_xor(ps, 16, 64);
+            ps += __shfl_xor(ps, 32, 64);
+            const float mbar = ps * inv_nf;
+            float *rw = &s_row[wv][sm][0];
+#pragma unroll
+            for (int k = 0; k < NBG; ++k) {
+                const int j = bg * NBG + k;
+                rw[j] = C10 * (cm[k] - mbar);
+                if constexpr (RVF) {
+                    const float R = fmaf(p.rv_mean, cdr[k], cr0[k]);
+                    rw[NB + j] = R;
+                    rw[2 * NB + j] = R * R;
+                } else {
+                    rw[NB + j] = cr0[k];
+                    rw[2 * NB + j] = cdr[k];
+                }
+            }
+            if (bg == 0) rw[NF * NB] = C10 * mbar;
+        }
+        if (ib + PS_M < i1) fetch(ib + PS_M);        // the next tile's coefficients: a whole tile of latency cover
+        ps_wave_sync();
+        for (int u = 0; u < nm; ++u) {
+            // (wave-uniform address: every ds_read_b128 is a broadcast into all lanes)
+            const float4 *__restrict__ r4 = reinterpret_cast<const float4 *>(&s_row[wv][u][0]);
+            float mcC[NB], A[NB], B[NB];
+#pragma unroll
+            for (int k = 0; k < NB / 4; ++k) {
+                const float4 a = r4[k], c = r4[NB / 4 + k], d = r4[2 * (NB / 4) + k];
+                mcC[4 * k] = a.x; mcC[4 * k + 1] = a.y; mcC[4 * k + 2] = a.z; mcC[4 * k + 3] = a.w;
+                A[4 * k] = c.x; A[4 * k + 1] = c.y; A[4 * k + 2] = c.z; A[4 * k + 3] = c.w;
+                B[4 * k] = d.x; B[4 * k + 1] = d.y; B[4 * k + 2] = d.z; B[4 * k + 3] = d.w;
+            }
+            const float dbar = gbarC - s_row[wv][u][NF * NB];      // c (gbar - mbar)
+            float av = avm, rv = p.rv_mean;                       // av: c Av throughout
+            if constexpr (RVF) {
+                float uR = 0.f, RR = 0.f, yR = 0.f, uy = 0.f, yy = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float y = gcC[j] - mcC[j];
+                    const float yw = y * w[j];
+                    uR = fmaf(A[j], w[j], uR);
+                    RR = fmaf(B[j], w[j], RR);
+                    yR = fmaf(A[j], yw, yR);
+                    uy += yw;
+                    yy = fmaf(y, yw, yy);
+                }
+                const float rs = uy - av * uR;
+                const float ra = (yR - av * RR) + (avm - av) * p.av_ivar;
+                const float a_den = RR + p.av_ivar;
+                float dav = (S * ra - uR * rs) * __builtin_amdgcn_rcpf(S * a_den - uR * uR);
+                dav = fminf(dav, av_hi - av);
+                dav = fmaxf(dav, av_lo - av);
+                av += dav;
+                const float oc = (uy - av * uR) * rS;
+                const float tt0 = dbar + oc;
+                const float lw = lw_scale * ((yy - av * (2.f * yR - av * RR)) + S * (tt0 * tt0 - oc * oc));
+                const float st = fabsf(dav);
+                mx0 = vmaxf(mx0, lw);
+                mx1 = vmaxf(mx1, st >= tol_hi ? lw : NINF);
+                mx2 = vmaxf(mx2, st >= tol_lo ? lw : NINF);
+                mx8 = lw != lw ? 1.f : mx8;
+            } else {
+                float ua = 0.f, ub = 0.f, uy = 0.f, aa = 0.f, ab = 0.f, bb = 0.f, ay = 0.f, by = 0.f, yy = 0.f;
+#pragma unroll
+                for (int j = 0; j < NB; ++j) {
+                    const float y = gcC[j] - mcC[j];
+                    const float aw = A[j] * w[j], bw = B[j] * w[j], yw = y * w[j];
+                    ua += aw;
+                    ub += bw;
+                    uy += yw;
+                    aa = fmaf(A[j], aw, aa);
+                    ab = fmaf(A[j], bw, ab);
+                    bb = fmaf(B[j], bw, bb);
+                    ay = fmaf(A[j], yw, ay);
+                    by = fmaf(B[j], yw, by);
+                    yy = fmaf(y, yw, yy);
+                }
+                // one sweep of fitting.py:176-243 with av -> c av: the Av half as above; in the
+                // Rv half every product av x (a y-free sum) carries one c and every product
+                // av x (a y sum) two, so its numerator and denominator are both c^2 times the
+                // reference's once the prior terms are scaled likewise: drv comes out unscaled
+                const float c2 = C10 * C10;
+                auto sweep = [&](float &dav_o, float &drv_o) -> float {
+                    const float uR = ua + rv * ub;
+                    const float RR = aa + rv * (2.f * ab + rv * bb);
+                    const float yR = ay + rv * by;
+                    float rs = uy - av * uR;
+                    const float ra = (yR - av * RR) + (avm - av) * p.av_ivar;
+                    const float a_den = RR + p.av_ivar;
+                    float dav = (S * ra - uR * rs) * __builtin_amdgcn_rcpf(S * a_den - uR * uR);
+                    dav = fminf(dav, av_hi - av);
+                    dav = fmaxf(dav, av_lo - av);
+                    av += dav;
+                    const float r_den = bb * av * av + c2 * p.rv_ivar;
+                    const float sr = ub * av;
+                    rs = uy - av * uR;
+                    const float bres = by - av * (ab + rv * bb);
+                    const float rr = av * bres + c2 * ((p.rv_mean - rv) * p.rv_ivar);
+                    float drv = (S * rr - sr * rs) * __builtin_amdgcn_rcpf(S * r_den - sr * sr);
+                    drv = fmaxf(drv, p.rvmin - rv);
+                    drv = fminf(drv, p.rvmax - rv);
+                    rv += drv;
+                    const float RR2 = aa + rv * (2.f * ab + rv * bb);
+                    const float yR2 = ay + rv * by;
+                    dav_o = dav;
+                    drv_o = drv;
+                    const float uR2 = ua + rv * ub;
+                    const float oc = (uy - av * uR2) * rS;
+                    const float tt0 = dbar + oc;
+                    return lw_scale * ((yy - av * (2.f * yR2 - av * RR2)) + S * (tt0 * tt0 - oc * oc));
+                };
+                float d1, d2;
+                {
+                    const float lw = sweep(d1, d2);
+                    const float st = fmaxf(fabsf(d1) * (-1.f / C10), fabsf(d2));
+                    mx0 = vmaxf(mx0, lw);
+                    mx1 = vmaxf(mx1, st >= p.mtol_hi ? lw : NINF);
+                    mx2 = vmaxf(mx2, st >= p.mtol_lo ? lw : NINF);
+                    mx8 = lw != lw ? 1.f : mx8;
+                }
+                {
+                    const float lw = sweep(d1, d2);
+                    const float st = fmaxf(fabsf(d1) * (-1.f / C10), fabsf(d2));
+                    mx3 = vmaxf(mx3, lw);
+                    mx4 = vmaxf(mx4, st >= p.mtol_hi ? lw : NINF);
+                    mx5 = vmaxf(mx5, st >= p.mtol_lo ? lw : NINF);
+                    mx8 = lw != lw ? 1.f : mx8;
+                }
+            }
+            // MLE in scaled units: F = A f, A = 10^(-0.4 mbar), d = D dd
+            float num = 0.f, den = 0.f;
+#pragma unroll
+            for (int j = 0; j < NB; ++j) {
+                float Rj;
+                if constexpr (RVF) Rj = A[j];
+                else Rj = fmaf(rv, B[j], A[j]);
+                const float e = __builtin_amdgcn_exp2f(fmaf(av, Rj, mcC[j]));
+                const float fw = e * iv[j];
+                num = fmaf(dd[j], fw, num);
+                den = fmaf(e, fw, den);
+            }
+            const float q = __builtin_amdgcn_exp2f(dbar);       // D / A
+            const float rden = __builtin_amdgcn_rcpf(den);
+            float tt = num * rden;
+            float sc = tt * q;
+            {
+                const bool tiny = sc <= 1e-20f;
+                const float tt_lo = 1e-20f * __builtin_amdgcn_rcpf(q);
+                tt = tiny ? tt_lo : tt;
+                sc = tiny ? 1e-20f : sc;
+            }
+            const float chi2 = fmaf(tt, fmaf(tt, den, -2.f * num), DD2);
+            const float lnl = -0.5f * chi2;
+            float lnlp = lnl;
+            if (any_par) {
+                const float dp = __builtin_amdgcn_sqrtf(sc) - par;
+                lnlp = has_par ? lnl - dp * dp * par_hiv : lnl;
+            }
+            float lnpr = lnl;
+            if (p.dim_prior) lnpr = c0 + c1 * ln_pos(chi2) - 0.5f * chi2;
+            if (any_sp) {
+                const float vt = sp_var + q * q * rden;
+                const float ds = sc - sp_mean;
+                const float t = -0.5f * (ds * ds * __builtin_amdgcn_rcpf(vt) + ln_pos(6.2831853071795865f * vt));
+                lnpr = sp_on ? lnpr + t : lnpr;
+            }
+            // a chi2 the cancellation cannot resolve, or a star float32 cannot represent:
+            // NaN = "re-evaluate in float64"
+            lnlp = chi2 > eps4 ? lnlp : NAN;
+            lnpr = chi2 > chi2_lo ? lnpr : NAN;
+            s_t[wv][0][u][lane] = lnlp;
+            s_t[wv][1][u][lane] = lnpr;
+            mx9 = (lnlp != lnlp || lnpr != lnpr) ? 1.f : mx9;
+            mx6 = vmaxf(mx6, lnlp);
+            mx7 = vmaxf(mx7, lnpr);
+        }
+        // the tile leaves transposed: a store covers four stars x sixteen models (64-byte row
+        // segments; the next tile of this wave completes the lines)
+        ps_wave_sync();
+#pragma unroll
+        for (int qq = 0; qq < 16; ++qq) {
+            const int ss = 4 * qq + bg;
+            const float a = s_t[wv][0][sm][ss], b = s_t[wv][1][sm][ss];
+            const int64_t base = s_base[ss];
+#ifndef PS_DIAG_NOSTORE
+            if (sm < nm && base >= 0) {
+                lnlp32[base + ib + sm] = a;
+                lnpr32[base + ib + sm] = b;
+            }
+#else
+            if (a == 12345.f && b == 54321.f) lnlp32[0] = a;
+#endif
+        }
+        ps_wave_sync();
+    }
+    // the four waves' maxima meet in LDS (the transposition tiles are free now)
+    __syncthreads();
+    float *s_mx = &s_t[0][0][0][0];                      // [4][NV32][64]
+    {
+        const float v[NV32] = {mx0, mx1, mx2, mx3, mx4, mx5, mx6, mx7, mx8, mx9};
+#pragma unroll
+        for (int k = 0; k < NV32; ++k) s_mx[(wv * NV32 + k) * 64 + lane] = v[k];
+    }
+    __syncthreads();
+    if (wv == 0 && slive) {
+#pragma unroll
+        for (int k = 0; k < NV32; ++k) {
+            float x = s_mx[k * 64 + lane];
+            x = vmaxf(x, s_mx[(NV32 + k) * 64 + lane]);
+            x = vmaxf(x, s_mx[(2 * NV32 + k) * 64 + lane]);
+            x = vmaxf(x, s_mx[(3 * NV32 + k) * 64 + lane]);
+            part[((int64_t)bx * nstar + s) * NV32 + k] = x;
+        }
+    }
+}
+
+}  // namespace

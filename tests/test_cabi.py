@@ -65,9 +65,12 @@ def test_hot_kernels_do_not_spill():
     import kernel_resources
     from brutus_amd import _lib
     ks = kernel_resources.kernels(_lib.LIB_PATH)
-    hot = [n for n in ks if re.match(r"k_(fflux|derive|pre32|top|sel_band)<(8|12),", n)]
-    assert len(hot) >= 20, sorted(ks)[:10]
-    bad = {n: ks[n] for n in hot if ks[n]["scratch"] != 0 or ks[n]["vgpr"] > 256}
+    hot = [n for n in ks if re.match(r"k_(fflux|derive|pre32|pre32s|top|top1|sel_band)<(8|12),", n)]
+    assert len(hot) >= 28, sorted(ks)[:10]
+    # (the general-Rv star-lane pass reloads one register per 16-model tile -- outside its step
+    # loop -- to stay at three waves per SIMD: 32 bytes, measured harmless)
+    allowed = {"k_pre32s<12, false>": 32}
+    bad = {n: ks[n] for n in hot if ks[n]["scratch"] > allowed.get(n, 0) or ks[n]["vgpr"] > 256}
     assert not bad, bad
     # 24 / 32 bands: built for one workgroup per CU (512 registers); what is left in scratch
     # stays small -- at two workgroups these kernels carried 500-1700 bytes and ran 3-4x slower
@@ -78,6 +81,7 @@ def test_hot_kernels_do_not_spill():
     # occupancy steps the measurements in DESIGN.md rest on: four waves per SIMD for the
     # float32 pass, two for the float64 list kernels
     assert ks["k_pre32<12, true, 4>"]["vgpr"] <= 128 and ks["k_pre32<12, false, 4>"]["vgpr"] <= 128
+    assert ks["k_pre32s<12, true>"]["vgpr"] <= 168 and ks["k_pre32s<12, false>"]["vgpr"] <= 168
 
 
 def test_abi_version_and_queries():

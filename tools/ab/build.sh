@@ -4,5 +4,8 @@
 # Run the variants with tools/ab/multi.sh on the GPU box.
 name=${1:?variant name}; shift
 R=$(cd $(dirname $0)/../.. && pwd)
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -Wno-unused-value \
-    -DBRUTUS_DEV_NB12_ONLY "$@" $R/brutus_amd/csrc/brutus_kernels.hip -o $R/tools/ab/$name.so
+cd $R && python - "$name" "$@" <<'PY'
+import sys
+import __graft_entry__ as g
+g.build_hip(force=True, out="tools/ab/%s.so" % sys.argv[1], extra=["-DBRUTUS_DEV_NB12_ONLY"] + sys.argv[2:])
+PY

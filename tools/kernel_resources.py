@@ -18,31 +18,41 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 READELF = "/opt/rocm/lib/llvm/bin/llvm-readelf"
 
 
-def code_object(so):
+def code_objects(so):
+    """The gfx950 code objects of the library: one offload bundle per translation unit, laid
+    end to end (page-aligned) in .hip_fatbin."""
     out = subprocess.check_output([READELF, "-S", "-W", so], text=True)
     m = re.search(r"\.hip_fatbin\s+\S+\s+([0-9a-f]+)\s+([0-9a-f]+)\s+([0-9a-f]+)", out)
     off, size = int(m.group(2), 16), int(m.group(3), 16)
     with open(so, "rb") as f:
         f.seek(off)
         data = f.read(size)
-    assert data[:24] == b"__CLANG_OFFLOAD_BUNDLE__", "compressed / unknown offload bundle"
-    n = struct.unpack_from("<Q", data, 24)[0]
-    p = 32
-    for _ in range(n):
-        o, s, t = struct.unpack_from("<QQQ", data, p)
-        triple = data[p + 24:p + 24 + t].decode()
-        p += 24 + t
-        if "gfx950" in triple:
-            return data[o:o + s]
-    raise RuntimeError("no gfx950 code object in %s" % so)
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    assert data[:24] == magic, "compressed / unknown offload bundle"
+    found, at = [], data.find(magic)
+    while at >= 0:
+        n = struct.unpack_from("<Q", data, at + 24)[0]
+        p = at + 32
+        for _ in range(n):
+            o, s, t = struct.unpack_from("<QQQ", data, p)
+            triple = data[p + 24:p + 24 + t].decode()
+            p += 24 + t
+            if "gfx950" in triple:
+                found.append(data[at + o:at + o + s])
+        at = data.find(magic, at + 24)
+    if not found:
+        raise RuntimeError("no gfx950 code object in %s" % so)
+    return found
 
 
 def kernels(so):
     """{demangled kernel name: dict(vgpr, sgpr, scratch, lds)}"""
-    with tempfile.NamedTemporaryFile(suffix=".co") as f:
-        f.write(code_object(so))
-        f.flush()
-        notes = subprocess.check_output([READELF, "--notes", f.name], text=True)
+    notes = ""
+    for co in code_objects(so):
+        with tempfile.NamedTemporaryFile(suffix=".co") as f:
+            f.write(co)
+            f.flush()
+            notes += subprocess.check_output([READELF, "--notes", f.name], text=True)
     res, cur = {}, {}
     keys = {".vgpr_count": "vgpr", ".sgpr_count": "sgpr", ".private_segment_fixed_size": "scratch",
             ".group_segment_fixed_size": "lds", ".name": "name", ".vgpr_spill_count": "vgpr_spills"}
