@@ -14,7 +14,7 @@ __all__ = ["lib", "Params", "PostParams", "check", "LIB_PATH", "BrutusError", "N
 LIB_PATH = os.environ.get("BRUTUS_AMD_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libbrutus_amd.so")
 NVALS = 11
-ABI_VERSION = 2
+ABI_VERSION = 3
 MAX_BATCH = 256
 MAX_FILT = 32
 

@@ -520,7 +520,14 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
             if mini.ndim == 1:
                 # one mass grid for all slices: 2 000 logarithms per call, the (slice, EEP) table
                 # of weights is formed on the device and the kept rows are looked up, not rebuilt
-                if mini0 is None or not (mini is mini0 or np.array_equal(mini, mini0)):
+                if mini0 is not None and not (mini is mini0 or np.array_equal(mini, mini0)):
+                    # (a "shared" grid is one grid: the table kept for a revisit holds ONE vector of
+                    # ln(d mini) for all groups, and so does the reference, whose `mini` comes from
+                    # the EEP / [Fe/H] / age of the isochrone alone, cluster.py:342-349)
+                    raise RuntimeError("isochrone plug-in returned different 1-D mass grids for "
+                                       "different groups of mass fractions; return a (slices, EEP) "
+                                       "array if the grid depends on the slice")
+                if mini0 is None:
                     mini0 = mini
                     gmini = np.gradient(mini)
                     pos = gmini > 0.
@@ -586,6 +593,8 @@ def _point_table(isochrone, feh, loga, av, rv, dist, corr_coef, smf_grid, grad_s
             srckey = tuple(stage.srckey)
             if getattr(stage, "src_all_key", None) != srckey:
                 stage.src_all_key, stage.t_src_all = srckey, torch.cat(stage.t_src)
+            # (d_lnsmf and t_src_all are replaced, never rewritten in place, when their keys
+            # change -- stage.smfkey / stage.src_all_key above --, so the table may share them)
             tab = ("mags", stage.t_src_all, stage.d_mags.clone(), d_lng.clone(), d_lnsmf, neep, off)
         else:
             tab = ("mags",)                                  # (summed already; not kept)

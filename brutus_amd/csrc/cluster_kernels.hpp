@@ -102,7 +102,13 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
             for (int idx = threadIdx.x; idx < npu * NB; idx += CL_T) {
                 const int c = idx / NB, b = idx - c * NB;
                 double v = 0.;
-                if (c < np && b < nb) v = exp10(-0.4 * mg.mags[(int64_t)mg.src[q0 + c] * nb + b]);
+                if (c < np && b < nb) {
+                    // (a band "exists" where its MAGNITUDE is finite, cluster.py:358 -- the
+                    // flux of mag = +inf is a perfectly finite 0; it is staged as -0.0, which
+                    // the band sums cannot tell from 0 and the any-band test below can)
+                    const double mag = mg.mags[(int64_t)mg.src[q0 + c] * nb + b];
+                    v = mag == INFINITY ? -0. : exp10(-0.4 * mag);
+                }
                 s_pts[c * STRIDE + b] = v;
             }
             __syncthreads();
@@ -124,7 +130,10 @@ k_cluster(int nobj, int nb, int npts, const double *__restrict__ pts_flux,
             for (int b = 0; b < NB; ++b) {
                 const double v = b < nb ? src[b] : 0.;
                 hole = hole || (v != v);
-                any = any || (b < nb && v == v);
+                // (fluxes from the caller's table: any non-NaN band; staged from magnitudes:
+                // any band whose magnitude was finite -- not the -0.0 of +inf, not the inf of -inf)
+                if constexpr (MAGS) any = any || (b < nb && fabs(v) < INFINITY && !(v == 0. && signbit(v)));
+                else any = any || (b < nb && v == v);
                 s_pts[c * STRIDE + b] = dead ? CL_DEAD_FLUX : v;
             }
             // (a point all of whose bands are NaN would have chi2 = chi2_p; the caller gives it

@@ -183,6 +183,26 @@ __device__ __forceinline__ T block_exclusive_sum(T v, T *slot, T &total) {
     total = tot;
     return pre + (inc - v);
 }
+// The INCLUSIVE sum of the same scan (for floating point `exclusive + v` is not it:
+// (inc - v) + v need not round back to inc).
+template <class T, int NT>
+__device__ __forceinline__ T block_inclusive_sum(T v, T *slot, T &total) {
+    constexpr int NW = NT / 64;
+    const T inc = wave_inclusive_sum(v);
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 63) slot[w] = inc;
+    __syncthreads();
+    T pre = T(0), tot = T(0);
+#pragma unroll
+    for (int q = 0; q < NW; ++q) {
+        const T x = slot[q];
+        if (q < w) pre += x;
+        tot += x;
+    }
+    total = tot;
+    return pre + inc;
+}
 
 template <int NB>
 struct Coef {

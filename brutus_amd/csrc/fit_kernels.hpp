@@ -304,6 +304,14 @@ constexpr bool wide_bands(int nb) { return nb >= BRUTUS_WIDE_FROM; }
 #define BRUTUS_LIST_OCC1_FROM 17
 #endif
 constexpr int list_waves(int nb) { return nb >= BRUTUS_LIST_OCC1_FROM ? 1 : 2; }
+// (the opening flux kernel on its own: at 16 bands it is the one list kernel that does not fit
+// 256 registers -- 52 / 148 bytes of scratch at two workgroups per CU)
+#ifndef BRUTUS_FFLUX_OCC1_FROM
+#define BRUTUS_FFLUX_OCC1_FROM BRUTUS_LIST_OCC1_FROM
+#endif
+constexpr int fflux_waves(int nb, bool first) {
+    return nb >= (first ? BRUTUS_FFLUX_OCC1_FROM : BRUTUS_LIST_OCC1_FROM) ? 1 : 2;
+}
 // (the tile kernels of fit2_kernels.hpp likewise: k_sel_band from 24 bands -- 0.16 -> 0.10,
 // 0.27 -> 0.13 ms --, k_top at 32 -- 2.19 -> 1.27 ms; k_top<24> is faster with two: 0.68
 // against 0.87 ms)
@@ -920,7 +928,7 @@ struct RecPlanes {
 // M = max final lnprob.  Entries at or beyond the record capacity are skipped (the host
 // sees ncand > capacity and reports BRUTUS_ENOMEM).
 template <int NB, bool RVF, bool FIRST>
-__global__ void __launch_bounds__(TILE, list_waves(NB))
+__global__ void __launch_bounds__(TILE, fflux_waves(NB, FIRST))
 k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar,
         const StarPrep *__restrict__ stars, DevParams p, const int32_t *__restrict__ k1,
         const int32_t *__restrict__ k2state, const int32_t *__restrict__ cand_idx,

@@ -115,7 +115,7 @@ k_po_cdf(int nobj, int nsamps, const double *__restrict__ weights,
         double v = 0.;
         if (k < nsamps) v = fit ? exp(row[k] - mx) * w[k] : w[k];
         double tot;
-        const double inc = block_exclusive_sum<double, PO_T>(v, s_slot, tot) + v;
+        const double inc = block_inclusive_sum<double, PO_T>(v, s_slot, tot);
         if (k < nsamps) row[k] = carry + inc;
         carry += tot;
     }

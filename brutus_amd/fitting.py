@@ -907,7 +907,10 @@ class BruteForce(object):
         was adopted in kernel layout (`use_device_grid`) is used as it is."""
         if self._grid_adopted:
             return None
-        return _bands_in_use(data_mask, self.NDIM)
+        # (`fit_sharded` decides from the WHOLE catalogue, so that every rank -- and every run of
+        # a resumed fit -- uses the same band set, i.e. the same kernel instantiations)
+        whole = getattr(self, "_catalogue_mask", None)
+        return _bands_in_use(data_mask if whole is None else whole, self.NDIM)
 
     def use_device_grid(self, grid):
         """Adopt a `DeviceGrid` that is already resident (e.g. broadcast)."""

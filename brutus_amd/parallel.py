@@ -112,13 +112,18 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
 
     A failure anywhere -- a fit, the writer (its errors are sticky), a hand-off -- is
     announced in the next round's headers; every rank then stops its generator and raises,
-    none is left waiting in a collective.  The side group is destroyed on the way out.
+    none is left waiting in a collective.  That includes the writer's LAST blocks: when every
+    rank has reported "done", rank 0 flushes and closes the file inside the protocol and a
+    closing round of headers carries the outcome.  The side group is destroyed on the way out.
 
     With `running_io=True` (default) the file on disk is current up to the last flush and
     `model_idx` is the last dataset of a block to be written, so a crash leaves the rows in
     flight unfitted (-99), never half-written.
 
-    Object `i` draws from its own stream keyed `seed0 + i`, so the file is
+    The bands that enter a fit are chosen once, from the whole catalogue's mask (a rank whose
+    shard happens to lack a band must not run other kernel instantiations than its peers; up
+    to three engines -- band sets -- stay resident per process).  Object `i` draws from its
+    own stream keyed `seed0 + i`, so the file is
     identical for any number of ranks (the reference's single sequential
     stream, fitting.py:2039-2053, would make results depend on the sharding):
     `rng="philox"` (default) uses `rng.PhiloxRandomState(seed0 + i)`, which
@@ -127,8 +132,11 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     optionally spread over `bf.host_workers` processes, for user prior hooks).
 
     `fit_kwargs` are `BruteForce.fit` keyword arguments (`lnprior_ext` arrays
-    are sliced to each rank's shard; `resume` is not supported here).  Returns
-    the number of objects this rank fitted; `fit_sharded.last_stats` holds this rank's
+    are sliced to each rank's rows).  `resume=True` completes an interrupted
+    `running_io=True` file instead of creating one: rank 0 reads which rows still hold the
+    sentinel, every rank fits the unfinished rows of its shard (same per-object streams, so
+    the completed file equals an uninterrupted run's, for any number of ranks before and
+    after).  Returns the number of objects this rank fitted; `fit_sharded.last_stats` holds this rank's
     timings (`fit_s`: until its last row was packed, `total_s`).
     """
     import queue
@@ -139,9 +147,7 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     from . import h5io
     rank, world = dist.get_rank(), dist.get_world_size()
     kw = dict(fit_kwargs)
-    if kw.pop("resume", False):
-        raise ValueError("fit_sharded: `resume` is not supported (rows are written by "
-                         "rank 0 in catalogue order; re-run the missing range instead)")
+    resume = bool(kw.pop("resume", False))
     Ndraws = kw.pop("Ndraws", 250)
     save_dar_draws = kw.pop("save_dar_draws", True)
     running_io = kw.pop("running_io", True)
@@ -168,29 +174,74 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                         "wt_thresh")}
     if "logl_dim_prior" not in fkw:
         fkw["logl_dim_prior"] = True
-    if lnprior_ext is not None:
-        # per-object constraints: this rank sees objects lo..hi as 0..hi-lo
-        fkw["lnprior_ext"] = {k: np.asarray(v)[lo:hi] for k, v in lnprior_ext.items()}
     par = kw.get("parallax")
     perr = kw.get("parallax_err")
     t_start = time.time()
-    gen = iter(()) if hi == lo else bf._fit(
-        data[lo:hi], data_err[lo:hi], data_mask[lo:hi],
-        parallax=None if par is None else np.asarray(par)[lo:hi],
-        parallax_err=None if perr is None else np.asarray(perr)[lo:hi],
-        lnprior=lnprior, lngalprior=lngalprior, lndustprior=lndustprior,
-        av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[lo:hi],
-        Ndraws=Ndraws, return_distreds=save_dar_draws,
-        seed0=seed0 + lo,
-        rstate_per_object="philox" if rng == "philox" else None, **fkw)
+    side = dist.new_group(backend="gloo") if world > 1 else None     # host-to-host hand-off
     out = None
-    if rank == 0:
+    todo = None
+    if resume:
+        # Rank 0 re-opens the interrupted file and reads the sentinel column (`model_idx[:, 0]
+        # == -99`: never fitted, reference fitting.py:1635); every rank then fits only the
+        # unfinished rows of ITS shard, each contiguous run of them as one `_fit` call seeded
+        # `seed0 + first row` -- object i draws from stream `seed0 + i` as in the interrupted
+        # run, so the completed file equals an uninterrupted one.
+        state = torch.zeros(Ndata + 1, dtype=torch.uint8)
+        open_error = None
+        if rank == 0:
+            try:
+                out = h5io.ResultsFile.resume("{0}.h5".format(save_file), Ndata, Ndraws,
+                                              save_dar_draws)
+                state[0] = 1
+                state[1:][torch.from_numpy(np.asarray(out.todo, dtype=np.int64))] = 1
+            except BaseException as e:
+                open_error = e
+        if world > 1:
+            dist.broadcast(state, src=0, group=side)
+        if not int(state[0]):
+            if side is not None:
+                dist.destroy_process_group(side)
+            raise open_error or RuntimeError("fit_sharded: rank 0 could not re-open %s.h5" % save_file)
+        todo = state[1:].numpy().astype(bool)
+    elif rank == 0:
         out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
                                data_labels, save_dar_draws,
                                running_io=running_io)
+    # the contiguous runs [a, b) of rows this rank fits
+    if todo is None:
+        runs = [(lo, hi)] if hi > lo else []
+    else:
+        mine = np.flatnonzero(todo[lo:hi]) + lo
+        cuts = np.flatnonzero(np.diff(mine) != 1) + 1
+        runs = [(int(r[0]), int(r[-1]) + 1) for r in np.split(mine, cuts) if r.size]
+    nmine = sum(b - a for a, b in runs)
+    current = [None]
+
+    def fitted_rows():
+        """(catalogue row, 13-tuple) of every row of this rank's runs, in row order."""
+        for a, b in runs:
+            rkw = dict(fkw)
+            if lnprior_ext is not None:
+                # per-object constraints: `_fit` sees objects a..b as 0..b-a
+                rkw["lnprior_ext"] = {k: np.asarray(v)[a:b] for k, v in lnprior_ext.items()}
+            g = bf._fit(
+                data[a:b], data_err[a:b], data_mask[a:b],
+                parallax=None if par is None else np.asarray(par)[a:b],
+                parallax_err=None if perr is None else np.asarray(perr)[a:b],
+                lnprior=lnprior, lngalprior=lngalprior, lndustprior=lndustprior,
+                av_gauss=av_gauss, wt_thresh=wt_thresh, data_coords=data_coords[a:b],
+                Ndraws=Ndraws, return_distreds=save_dar_draws,
+                seed0=seed0 + a,
+                rstate_per_object="philox" if rng == "philox" else None, **rkw)
+            current[0] = g
+            for k, res in enumerate(g):
+                yield a + k, res
+            current[0] = None
+
+    gen = fitted_rows()
+    bf._catalogue_mask = data_mask       # one band set for all ranks and runs (BruteForce._bands_for)
     rowdt, positions = h5io.ResultsFile.row_dtype(Ndraws, save_dar_draws)
     rowbytes = rowdt.itemsize
-    side = dist.new_group(backend="gloo") if world > 1 else None     # host-to-host hand-off
     q = queue.Queue(maxsize=max(1, int(queue_depth)))
     abort = threading.Event()
     failure = {"local": None, "remote": None}
@@ -252,6 +303,25 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                     failure["local"] = e
                     continue
                 if np.all(hdrs[:, 2] == 1) and not np.any(hdrs[:, 0]):
+                    # Everything has been handed over -- but the writer is asynchronous: a
+                    # failure in its last blocks (a full disk) only shows when the file is
+                    # flushed and closed.  Rank 0 does that HERE, and one more round of headers
+                    # tells everybody how it went; otherwise rank 0 alone would raise after the
+                    # threads have ended and the others would wait in the closing barrier.
+                    if rank == 0:
+                        try:
+                            out.close()
+                        except BaseException as e:
+                            failure["local"] = e
+                    if world > 1:
+                        last = torch.tensor([0, 0, 1, 0 if failure["local"] is None else 1],
+                                            dtype=torch.int64)
+                        lasts = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
+                        dist.all_gather(lasts, last, group=side)
+                        if int(lasts[0][3]) and rank != 0:
+                            failure["remote"] = RuntimeError(
+                                "fit_sharded: rank 0 could not finish the results file; "
+                                "this rank stops too")
                     return
         except BaseException as e:                   # the collective itself failed
             failure["local"] = failure["local"] or e
@@ -275,24 +345,32 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     t_fit = None
     try:
         try:
-            start = lo
             exhausted = False
+            pending = None                           # a row of the next run, already fitted
             while not exhausted:
                 block = np.zeros(chunk, dtype=rowdt)
-                n = 0
+                n, start = 0, None
                 with np.errstate(over="ignore"):
                     while n < chunk:
-                        try:
-                            res = next(gen)
-                        except StopIteration:
-                            exhausted = True
+                        if pending is not None:
+                            row, res = pending
+                            pending = None
+                        else:
+                            try:
+                                row, res = next(gen)
+                            except StopIteration:
+                                exhausted = True
+                                break
+                        if start is None:
+                            start = row
+                        elif row != start + n:       # a new run: blocks hold consecutive rows
+                            pending = (row, res)
                             break
                         for name, pos in positions:
                             block[name][n] = res[pos]
                         n += 1
                 if n:
                     put(("rows", start, n, block))
-                    start += n
             t_fit = time.time() - t_start
             put(("done",))
         except BaseException as e:
@@ -301,8 +379,10 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                 failure["local"] = failure["local"] or e
         th.join()
     finally:
-        if hasattr(gen, "close"):
-            gen.close()                     # shuts the scan-ahead helper thread down
+        bf._catalogue_mask = None
+        if current[0] is not None and hasattr(current[0], "close"):
+            current[0].close()              # shuts the scan-ahead helper thread down
+        gen.close()
         close_error = None
         if out is not None:
             try:
@@ -315,6 +395,6 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     if err is not None:
         raise err
     fit_sharded.last_stats = {"fit_s": t_fit, "total_s": time.time() - t_start,
-                              "objects": hi - lo}
+                              "objects": nmine}
     dist.barrier()
-    return hi - lo
+    return nmine

@@ -35,7 +35,7 @@
 extern "C" {
 #endif
 
-#define BRUTUS_ABI_VERSION 2
+#define BRUTUS_ABI_VERSION 3
 #define BRUTUS_MAX_FILT 32   /* bands per fit (device register budget)            */
 #define BRUTUS_MAX_BATCH 256 /* stars per brutus_*_batch call                     */
 #define BRUTUS_NVALS 11      /* lnlike, chi2, scale, av, rv, icov[00,01,02,11,12,22] */

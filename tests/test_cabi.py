@@ -78,6 +78,16 @@ def test_hot_kernels_do_not_spill():
     assert len(wide) >= 16
     bad = {n: ks[n] for n in wide if ks[n]["scratch"] > 128}
     assert not bad, bad
+    # 16 bands: the opening flux kernel does not fit 256 registers (52 / 148 bytes of scratch);
+    # one workgroup per CU instead was measured 15-25 % slower (profiles/r05_fflux16_occupancy_ab.txt),
+    # so it stays -- bounded, and its siblings stay clean
+    mid = [n for n in ks if re.match(r"k_(fflux|derive|top1|sel_band)<16,", n)]
+    assert len(mid) >= 10
+    # (k_sel_band<16, false>: 28 bytes, a 0.05 ms kernel over 0.4 % of the pairs)
+    limit = lambda n: (160 if re.match(r"k_fflux<16, (true|false), true>", n)
+                       else 32 if n == "k_sel_band<16, false>" else 0)
+    bad = {n: ks[n] for n in mid if ks[n]["scratch"] > limit(n)}
+    assert not bad, bad
     # occupancy steps the measurements in DESIGN.md rest on: four waves per SIMD for the
     # float32 pass, two for the float64 list kernels
     assert ks["k_pre32<12, true, 4>"]["vgpr"] <= 128 and ks["k_pre32<12, false, 4>"]["vgpr"] <= 128
@@ -87,7 +97,7 @@ def test_hot_kernels_do_not_spill():
 def test_abi_version_and_queries():
     from brutus_amd import _lib
     L = _lib.lib()
-    assert L.brutus_abi_version() == _lib.ABI_VERSION == 2
+    assert L.brutus_abi_version() == _lib.ABI_VERSION == 3
     assert L.brutus_padded_filters(6) == 8
     assert L.brutus_padded_filters(12) == 12
     assert L.brutus_padded_filters(33) < 0

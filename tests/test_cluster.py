@@ -403,3 +403,80 @@ def test_cache_keys_follow_content_not_identity():
     assert list(lru) == [1, 2, 3] and cluster._lru_get(lru, 1) == "1" and list(lru) == [2, 3, 1]
     cluster._lru_put(lru, 9, "9", 3)
     assert list(lru) == [3, 1, 9] and cluster._lru_get(lru, 2) is None
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dim_prior", [1, 0])
+def test_cluster_magnitude_path_counts_a_band_by_its_magnitude(dim_prior):
+    """C ABI: the sum that takes the plug-in's MAGNITUDES (`brutus_cluster_lnl_part_mags`) and
+    the flux table (`brutus_cluster_points_grid` + `brutus_cluster_lnl_part`) must agree on
+    which points exist -- a point counts if any band's magnitude is finite (reference
+    cluster.py:358-364, `np.any(np.isfinite(cmd_sed), axis=1)`), so a point whose bands are
+    all +inf (flux exactly 0, a finite number) is dropped, one with a -inf band gives -inf,
+    NaN bands fall out of the band sum -- and on the value, which is the reference block's."""
+    import torch
+    from scipy.special import logsumexp
+    from scipy.stats import chi2 as chisquare
+    from brutus_amd import _lib
+    L = _lib.lib()
+    rng = np.random.RandomState(3)
+    nobj, nb, neep, nsmf = 64, 8, 160, 3
+    nrow = neep * nsmf
+    mags = rng.uniform(14., 16., size=(nrow, nb))
+    mags[rng.choice(nrow, 25, replace=False)] = np.inf               # every band +inf: no such point
+    mags[rng.choice(nrow, 10, replace=False)] = np.nan
+    some = rng.uniform(size=mags.shape)
+    mags[some < 0.02] = np.inf                                       # a band at +inf: flux 0, counted in chi2
+    mags[(some > 0.02) & (some < 0.03)] = np.nan
+    mags[7, 2] = -np.inf                                             # infinite flux: chi2 = inf
+    lnw_eep = rng.normal(size=neep)
+    lnw_eep[rng.choice(neep, 9, replace=False)] = -np.inf
+    lnw_smf = rng.normal(size=nsmf)
+    src = np.sort(rng.choice(nrow, 400, replace=False)).astype(np.int32)
+    src = np.union1d(src, [7]).astype(np.int32)
+    npts = src.size
+    with np.errstate(all="ignore"):
+        flux = 10. ** (-0.4 * mags[src])
+    phot = 10. ** (-0.4 * rng.uniform(14., 16., size=(nobj, nb)))
+    ivar = 1. / (0.05 * phot) ** 2
+    chi2_p = rng.uniform(0., 2., nobj)
+    lnorm = rng.normal(size=nobj)
+    ndim = np.full(nobj, nb + 1, dtype=np.int32)
+    with np.errstate(all="ignore"):
+        chi2 = np.nansum((phot[None] - flux[:, None]) ** 2 * ivar[None], axis=2) + chi2_p
+        lnl_c = (chisquare.logpdf(chi2, ndim) if dim_prior else -0.5 * (chi2 + lnorm))
+        lnl_c[~np.isfinite(lnl_c)] = -np.inf
+        w = lnw_eep[src % neep] + lnw_smf[src // neep]
+        w = np.where(np.any(np.isfinite(mags[src]), axis=1), w, -np.inf)
+        want = logsumexp(lnl_c + w[:, None], axis=0)
+    dev = torch.device("cuda:0")
+    up = lambda a, dt=np.float64: torch.from_numpy(np.ascontiguousarray(a, dtype=dt)).to(dev)
+    t_src, t_mags, t_eep, t_smf = up(src, np.int32), up(mags), up(lnw_eep), up(lnw_smf)
+    obj = [up(phot), up(ivar), up(chi2_p), up(lnorm), up(ndim, np.int32)]
+    ws = torch.empty(L.brutus_cluster_workspace_bytes(nobj), dtype=torch.uint8, device=dev)
+    nchunk = L.brutus_cluster_chunks()
+    out = {}
+    for path in ("mags", "flux"):
+        res = torch.empty(nobj, dtype=torch.float64, device=dev)
+        if path == "mags":
+            _lib.check(L.brutus_cluster_lnl_part_mags(
+                nobj, nb, npts, neep, t_src.data_ptr(), t_mags.data_ptr(), t_eep.data_ptr(),
+                t_smf.data_ptr(), *[x.data_ptr() for x in obj], dim_prior, ws.data_ptr(), ws.numel(),
+                0, nchunk, None))
+        else:
+            t_flux = torch.empty(npts * nb, dtype=torch.float64, device=dev)
+            t_lnw = torch.empty(npts, dtype=torch.float64, device=dev)
+            _lib.check(L.brutus_cluster_points_grid(npts, nb, neep, t_src.data_ptr(), t_mags.data_ptr(),
+                                                    t_eep.data_ptr(), t_smf.data_ptr(),
+                                                    t_flux.data_ptr(), t_lnw.data_ptr(), None))
+            _lib.check(L.brutus_cluster_lnl_part(
+                nobj, nb, npts, t_flux.data_ptr(), t_lnw.data_ptr(), *[x.data_ptr() for x in obj],
+                dim_prior, ws.data_ptr(), ws.numel(), 0, nchunk, None))
+        _lib.check(L.brutus_cluster_lnl_merge(nobj, nchunk, ws.data_ptr(), ws.numel(),
+                                              res.data_ptr(), None))
+        torch.cuda.synchronize()
+        out[path] = res.cpu().numpy()
+    assert np.all(np.isfinite(want))
+    assert relerr(want, out["flux"]) < 1e-10
+    assert relerr(want, out["mags"]) < 1e-10
+    assert relerr(out["flux"], out["mags"]) < 1e-13

@@ -259,3 +259,120 @@ def test_shard_bounds_with_a_lighter_rank0():
         assert b[0][0] == 0 and b[-1][1] == 1000 and all(x[1] == y[0] for x, y in zip(b[:-1], b[1:]))
         sizes = [y - x for x, y in b]
         assert abs(sizes[0] - share * sizes[1]) <= 1 and max(sizes[1:]) - min(sizes[1:]) <= 1
+
+
+def _stub_class(fail_at=None):
+    """A deterministic stand-in for the GPU fit: row i depends on `seed0 + i` and the data only."""
+    sys.path.insert(0, ROOT)
+    from brutus_amd import fitting
+
+    class Stub(fitting.BruteForce):
+        def _fit(self, data, data_err, data_mask, Ndraws=250, seed0=None, **kw):
+            for i in range(data.shape[0]):
+                if fail_at is not None and seed0 + i == fail_at:
+                    raise FloatingPointError("object %d" % (seed0 + i))
+                rs = np.random.RandomState(seed0 + i)
+                val = rs.uniform(size=Ndraws) + float(np.sum(data[i])) * 1e8
+                yield (rs.randint(0, 64, size=Ndraws), val, val + 1., val + 2.,
+                       rs.uniform(size=(Ndraws, 3, 3)), 6, val + 3., float(rs.uniform()), 1.5,
+                       val + 4., val + 5., val + 6., val + 7.)
+    return Stub
+
+
+def _worker_resume(rank, world, port, tmp, name, fail_at, resume):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from brutus_amd import parallel, synth
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    models, labels, lmask = synth.make_grid(64, 6, seed=1)
+    ndata = 301
+    rng = np.random.RandomState(5)
+    flux = rng.uniform(1e-9, 1e-8, size=(ndata, 6))
+    bf = _stub_class(fail_at)(models, labels, lmask)
+    msg = "ok"
+    try:
+        n = parallel.fit_sharded(bf, flux, 0.05 * flux, np.ones((ndata, 6), dtype=bool), None,
+                                 os.path.join(tmp, name), seed0=1000, Ndraws=7, chunk=16,
+                                 lngalprior=lambda *a, **k: 0., data_coords=np.zeros((ndata, 2)),
+                                 resume=resume)
+        msg = "ok %d" % n
+    except FloatingPointError as e:
+        msg = "own %s" % e
+    except RuntimeError as e:
+        msg = "remote %s" % e
+    with open(os.path.join(tmp, "%s_%d.txt" % (name, rank)), "w") as f:
+        f.write(msg)
+    dist.destroy_process_group()
+
+
+def test_fit_sharded_resume_completes_an_interrupted_file(tmp_path):
+    """World size 2: the fit of object 1230 (rank 1's shard) raises, every rank stops, the
+    file keeps the sentinel in the rows that never arrived.  `resume=True` -- with THREE ranks
+    this time -- fits exactly those rows and the file equals an uninterrupted single-rank
+    run's, dataset by dataset (reference fitting.py:1635: `model_idx == -99` marks a row as
+    not yet fitted)."""
+    import torch.multiprocessing as mp
+    from brutus_amd import h5io
+    tmp = str(tmp_path)
+    mp.spawn(_worker_resume, args=(1, _free_port(), tmp, "full", None, False), nprocs=1, join=True)
+    mp.spawn(_worker_resume, args=(2, _free_port(), tmp, "part", 1230, False), nprocs=2, join=True)
+    res = [open(os.path.join(tmp, "part_%d.txt" % r)).read() for r in range(2)]
+    assert res[1].startswith("own object 1230") and res[0].startswith("remote"), res
+    idx = h5io.read_dataset(os.path.join(tmp, "part.h5"), "model_idx")
+    missing = np.flatnonzero(idx[:, 0] == -99)
+    assert 0 < missing.size < 301 and 230 in missing
+    mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "part", None, True), nprocs=3, join=True)
+    res = [open(os.path.join(tmp, "part_%d.txt" % r)).read().split() for r in range(3)]
+    assert all(x[0] == "ok" for x in res), res
+    assert sum(int(x[1]) for x in res) == missing.size          # only the unfinished rows were fitted
+    names = h5io.list_datasets(os.path.join(tmp, "full.h5"))
+    assert "model_idx" in names and len(names) >= 12
+    for k in names:
+        a = h5io.read_dataset(os.path.join(tmp, "full.h5"), k)
+        b = h5io.read_dataset(os.path.join(tmp, "part.h5"), k)
+        assert a.dtype == b.dtype and np.array_equal(a, b), k
+
+
+def _worker_close_fails(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from brutus_amd import h5io, parallel, synth
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    models, labels, lmask = synth.make_grid(64, 6, seed=1)
+    ndata = 120
+    flux = np.random.RandomState(5).uniform(1e-9, 1e-8, size=(ndata, 6))
+    bf = _stub_class()(models, labels, lmask)
+    real_close = h5io.ResultsFile.close
+
+    def close(self):                      # the writer's last blocks hit a full disk
+        real_close(self)
+        if not getattr(self, "_failed_once", False):
+            self._failed_once = True
+            raise OSError("No space left on device")
+    h5io.ResultsFile.close = close
+    try:
+        parallel.fit_sharded(bf, flux, 0.05 * flux, np.ones((ndata, 6), dtype=bool), None,
+                             os.path.join(tmp, "cf"), seed0=0, Ndraws=5, chunk=16,
+                             lngalprior=lambda *a, **k: 0., data_coords=np.zeros((ndata, 2)))
+        msg = "ok"
+    except OSError as e:
+        msg = "own %s" % e
+    except RuntimeError as e:
+        msg = "remote %s" % e
+    with open(os.path.join(tmp, "cf_%d.txt" % rank), "w") as f:
+        f.write(msg)
+    dist.destroy_process_group()
+
+
+def test_fit_sharded_writer_failure_at_the_very_end_reaches_every_rank(tmp_path):
+    """The writer is asynchronous: an error in its last blocks only shows when rank 0 flushes
+    and closes the file -- after every rank has reported "done".  The closing round of the
+    hand-off protocol carries it: rank 0 raises the OSError, the others a RuntimeError, and
+    nobody waits in the final barrier (the spawn would hang)."""
+    import torch.multiprocessing as mp
+    mp.spawn(_worker_close_fails, args=(3, _free_port(), str(tmp_path)), nprocs=3, join=True)
+    res = [open(os.path.join(str(tmp_path), "cf_%d.txt" % r)).read() for r in range(3)]
+    assert res[0].startswith("own No space left"), res
+    assert all(r.startswith("remote") and "rank 0" in r for r in res[1:]), res
