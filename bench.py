@@ -82,6 +82,9 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true")
     ap.add_argument("--no-cluster", action="store_true",
                     help="skip the cluster-mode block (BASELINE configs[4]) of the default line")
+    ap.add_argument("--no-sharp", action="store_true",
+                    help="skip the sharp-posterior block (S/N 50 photometry + parallax at S/N 10 on "
+                         "synth.make_sharp_grid: a few per cent of the grid selected per star)")
     ap.add_argument("--no-survey-grid", action="store_true",
                     help="skip the third block: the main configuration on SURVEY 8(d)'s own "
                          "grid generator (synth.make_grid, random model order)")
@@ -209,6 +212,35 @@ def end_to_end(models, grid, stars, n, kw, with_par, check=True):
     return res
 
 
+SHARP_STARS = dict(frac_err=0.02, parallax_snr=10., frac_no_parallax=0.)
+
+
+def end_to_end_sharp(models, grid, n):
+    """`BruteForce.fit()` to the HDF5 file on the sharp-posterior workload (counter-based
+    stream, device `lnpost`): what a user of the demo notebooks' regime sees end to end."""
+    import tempfile
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    _, labels, lmask = synth.make_sharp_grid(models.shape[0], models.shape[1])
+    bf = fitting.BruteForce(models, labels, lmask)
+    bf.use_device_grid(grid)
+    bf.batch_size = 128
+    st = synth.make_stars(models, n, seed=4243, with_parallax=True, **SHARP_STARS)
+    times = []
+    for rep in range(3):
+        with tempfile.TemporaryDirectory() as tmp:
+            t0 = time.perf_counter()
+            bf.fit(st["flux"], st["err"], st["mask"], np.arange(n), os.path.join(tmp, "e2e"),
+                   parallax=st["parallax"], parallax_err=st["parallax_err"],
+                   data_coords=st["coords"], lngalprior=gal_lnprior, verbose=False,
+                   rstate=PhiloxRandomState(862))
+            times.append(time.perf_counter() - t0)
+    return {"value": n / float(np.median(times)), "unit": "stars/s", "stars": n,
+            "statistic": "median of 3 whole fit() calls",
+            "note": "BruteForce.fit, rstate=PhiloxRandomState, Nmc_prior=50, Ndraws=250, HDF5"}
+
+
 def csrc_sha16():
     """Fingerprint of the kernel sources (brutus_amd/csrc + include): the PMC table under
     profiles/ carries the fingerprint it was measured on, so a kernel edited after the PMC
@@ -251,6 +283,71 @@ def measured_traffic(kernel, batch, config):
     except (IOError, ValueError, KeyError):
         pass
     return None
+
+
+def measure_issue(L, torch, dev):
+    """Time one SIMD needs per vector wave-instruction on THIS box, at the clock the device
+    holds under that load (brutus_calibrate_issue: every SIMD busy with one kind of
+    instruction and nothing else): plain float32, float64, float32 transcendental.  The
+    spec-sheet figures (2 / 4 cycles at 2.4 GHz = 0.83 / 1.67 ns) ride along."""
+    from brutus_amd import _lib
+    out = {}
+    ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+    for name, kind, waves in (("f32", 0, 4), ("f64", 1, 2), ("trans32", 2, 4)):
+        scratch = torch.empty(ncu * waves * 256, dtype=torch.float32, device=dev)
+        iters = 2000
+        _lib.check(L.brutus_calibrate_issue(kind, 50, waves, scratch.data_ptr(), scratch.numel(), None))
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        _lib.check(L.brutus_calibrate_issue(kind, iters, waves, scratch.data_ptr(), scratch.numel(), None))
+        e1.record()
+        torch.cuda.synchronize()
+        out[name + "_ns"] = e0.elapsed_time(e1) * 1e6 / (iters * 128. * waves)
+    out["spec_ns"] = {"f32": 2 / 2.4, "f64": 4 / 2.4}
+    out["simds"] = 4 * ncu
+    out["how"] = ("brutus_calibrate_issue: 4 (f32, transcendental) / 2 (f64) waves per SIMD of "
+                  "back-to-back instructions of one kind, HIP events")
+    return out
+
+
+def valu_table(batch, config):
+    """Rows of profiles/sq_valu.json (tools/sq_to_json.py: SQ_INSTS_VALU per kernel and call,
+    static float64 / transcendental shares) for this batch / config, and whether the kernel
+    sources changed since."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "sq_valu.json")) as f:
+            t = json.load(f)
+        rows = [r for r in t["rows"] if r["batch"] == batch and r["config"] == config]
+        return rows, t.get("csrc_sha16") != csrc_sha16(), t.get("commit")
+    except (IOError, ValueError, KeyError):
+        return [], None, None
+
+
+def valu_block(rows, stale, commit, issue, call_ms):
+    """`roofline.valu`: the ceiling that binds.  Issue time = sum over the call's kernels of
+    (vector wave-instructions x the issue time of their kind) / number of SIMDs -- what the
+    call would take if every SIMD issued vector instructions back to back, nothing else in
+    the way -- against the wall time of a call."""
+    if not rows or not issue:
+        return None
+    per_kernel, tot_n, tot_t = {}, 0., 0.
+    for r in rows:
+        if r["kernel"] == "__total__":
+            continue
+        n = r["valu_wave_insts_per_call"]
+        f64, tr = r.get("f64_share", 0.), r.get("trans32_share", 0.)
+        ns = n * (f64 * issue["f64_ns"] + tr * issue["trans32_ns"] + (1. - f64 - tr) * issue["f32_ns"])
+        ms = ns / issue["simds"] * 1e-6
+        per_kernel[r["kernel"]] = {"valu_wave_insts_per_call": n, "f64_share": f64,
+                                   "trans32_share": tr, "issue_ms_per_call": ms}
+        tot_n += n
+        tot_t += ms
+    return {"bound": "vector instruction issue", "unit": "ms of issue time per call / ms per call",
+            "valu_wave_insts_per_call": tot_n, "issue_ms_per_call": tot_t, "call_ms": call_ms,
+            "frac": tot_t / call_ms if call_ms else None, "issue_ns_per_wave_inst": issue,
+            "kernels": per_kernel, "stale": stale, "from_commit": commit,
+            "source": "profiles/sq_valu.json (rocprofv3 --pmc SQ_INSTS_VALU of tools/pmc_workload.py; "
+                      "static ISA mix per kernel), issue times measured in this run"}
 
 
 def _local_device(local_rank):
@@ -365,11 +462,12 @@ def bench_cluster(args, emit=True):
         # it is bound by f64 VALU issue, the HBM figure is shown for completeness
         alg = 8. * (npts * (args.nfilt + 1) + nobj * (2 * args.nfilt + 3))
         flops = pairs * (3. * args.nfilt + 40.)
-        line["roofline"] = {"bound": "hbm", "kernel": "k_cluster", "achieved": alg / (k_ms * 1e-3) / 1e9,
-                            "peak": 8000.0, "unit": "GB/s", "frac": alg / (k_ms * 1e-3) / 8e12,
-                            "traffic": None, "avg_launch_ms": k_ms,
-                            "valu_f64_tflops": flops / (k_ms * 1e-3) / 1e12,
-                            "valu_f64_peak_tflops": 78.6,
+        tf = flops / (k_ms * 1e-3) / 1e12
+        line["roofline"] = {"bound": "vector f64 (the block re-reads a 2.9 MB point table per 64-object "
+                                     "workgroup: HBM sees next to nothing)",
+                            "kernel": "k_cluster", "achieved": tf, "peak": 78.6, "unit": "TFLOP/s",
+                            "frac": tf / 78.6, "traffic": None, "avg_launch_ms": k_ms,
+                            "hbm_algorithmic_gbs": alg / (k_ms * 1e-3) / 1e9,
                             "device_star_points_per_s": pairs / (k_ms * 1e-3)}
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         from oracle import brutus_oracle as O
@@ -487,7 +585,21 @@ KERNEL_ALG_BYTES = {
 }
 
 
-def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
+def TIMER_OF(kernel):
+    """The library's timer name (`kernels_ms`) a kernel runs under (brutus_kernels.hip, run_fit)."""
+    k = kernel.split("<")[0]
+    if k in ("k_pre32", "k_pre32s"):
+        return "k_pre32"
+    if k in ("k_top", "k_top1", "k_hot_list"):
+        return "k_top"
+    if k in ("k_cmp_count32", "k_cmp_scatter"):     # (k_offsets / k_items run under two names: left out)
+        return "k_surv_compact"
+    if k == "k_rec_index":
+        return "k_select"
+    return k
+
+
+def run_config(config, args, L, grid, models, dev, world, rank, dist, torch, star_kw=None):
     """Time `args.steps` steps of configs[config - 1] on this rank; returns a dict with
     the whole-job rate and the per-kernel durations.  A step = `args.batch` DISTINCT
     stars, pushed through brutus_fit_batch in sub-batches of `args.sub_batch`."""
@@ -505,12 +617,12 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
     if strong:
         from brutus_amd import parallel
         lo, hi = parallel.shard_range(nstars_job, rank, world)
-        stars = synth.make_stars(models, nstars_job, seed=seed, with_parallax=with_par)
+        stars = synth.make_stars(models, nstars_job, seed=seed, with_parallax=with_par, **(star_kw or {}))
         stars = {k: v[lo:hi] for k, v in stars.items()}
         mine = hi - lo
     else:
         stars = synth.make_stars(models, nstars_job, seed=seed + 1000 * rank,
-                                 with_parallax=with_par)
+                                 with_parallax=with_par, **(star_kw or {}))
         mine = nstars_job
     params = fitting._make_params(
         (0., 20.), (0., 1e6), kw.get("rvlim", (1., 8.)), (3.32, 0.18),
@@ -646,7 +758,7 @@ def run_config(config, args, L, grid, models, dev, world, rank, dist, torch):
     return res
 
 
-def roofline_of(res, args, config, world, with_traffic=True):
+def roofline_of(res, args, config, world, with_traffic=True, issue=None):
     """SURVEY 8(d) / BASELINE.md section 4: achieved = stars/s x B_star (one float32
     read of the grid per star = 108.0 MB at 750k x 12) against the 8 TB/s HBM peak,
     for the WHOLE step.  The per-kernel entries carry each kernel's own algorithmic
@@ -662,14 +774,38 @@ def roofline_of(res, args, config, world, with_traffic=True):
         SB = res["kernel_sub_batch"]
         pairs = float(SB) * args.nmodel
         kern = {}
+        vrows, vstale, vcommit = valu_table(SB, config) if with_traffic else ([], None, None)
+        vb = valu_block(vrows, vstale, vcommit, issue, res["ms_per_step"] / max(1., float(args.batch) / SB))
+        valu_k = vb["kernels"] if vb else {}
+        if vb:
+            rl["valu"] = vb
         for name, ms in sorted(res["kernels_ms"].items(), key=lambda kv: -kv[1]):
             alg = KERNEL_ALG_BYTES.get(name.replace("_cont", ""), None)
             e = {"avg_launch_ms": ms}
+            tr = measured_traffic(name, SB, config) if with_traffic else None
+            e["traffic"] = tr
+            # vector issue time of the kernels timed under this name (roofline.valu's table)
+            vi = sum(v["issue_ms_per_call"] for k, v in valu_k.items()
+                     if TIMER_OF(k) == name.replace("_cont", "")) if valu_k else None
+            if vi:
+                e["valu_issue_ms"] = vi
+                e["valu_issue_frac"] = vi / ms
             if alg is not None:
                 ab = alg(SB, g, pairs, res["kernel_counts"])
-                e.update(bound="f64 VALU issue" if name.startswith("k_fflux") else "hbm",
-                         algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
-            e["traffic"] = measured_traffic(name, SB, config) if with_traffic else None
+                e.update(algorithmic_bytes=ab, achieved_gbs=ab / (ms * 1e-3) / 1e9)
+                if e["achieved_gbs"] > HBM_PEAK_GBS and tr:
+                    # more algorithmic bytes per second than the memory delivers: the kernel
+                    # serves several units from one read (the grid tile for a group of stars)
+                    e["reuse"] = ab / tr
+                    e["hbm_gbs"] = tr / (ms * 1e-3) / 1e9
+            # what bounds it: the vector unit where issue time is most of the duration, else
+            # the memory system (by PMC bytes where measured)
+            if vi and vi / ms >= 0.5:
+                e["bound"] = "vector issue (%.2f of the duration is issue time)" % (vi / ms)
+            elif tr:
+                e["bound"] = "memory (%.0f GB/s of PMC traffic)" % (tr / (ms * 1e-3) / 1e9)
+            elif alg is not None:
+                e["bound"] = "memory / latency"
             kern[name] = e
         rl["kernels"] = kern
         dom = max(res["kernels_ms"], key=res["kernels_ms"].get)
@@ -697,7 +833,7 @@ def main():
         # BASELINE configs[3]: ONE catalogue of 1M stars (configs[2]'s generator) split over the
         # ranks by parallel.shard_range; one timed pass of it is 30 s at 8 ranks, so one repeat
         args.config, args.scaling, args.steps, args.batch = 3, "strong", 250, 4000
-        args.single_config = args.no_survey_grid = args.no_cluster = True
+        args.single_config = args.no_survey_grid = args.no_cluster = args.no_sharp = True
         args.e2e_stars, args.cpu_seconds = 0, 0.
         args.repeats = min(args.repeats, 2)
     import torch
@@ -755,6 +891,23 @@ def main():
         del g8, m8
         torch.cuda.empty_cache()
 
+    # the regime of the demo notebooks: sharp posteriors (a few per cent of the grid selected)
+    res_sharp = e2e_sharp = None
+    if not args.no_sharp and not cfg4:
+        msh, _, _ = synth.make_sharp_grid(nmodel, nfilt)
+        gsh = fitting.DeviceGrid(msh, device=dev) if rank == 0 or world == 1 else None
+        if world > 1:
+            from brutus_amd import parallel
+            gsh = parallel.broadcast_grid(gsh if rank == 0 else None, nmodel, nfilt, dev, src=0)
+        res_sharp = run_config(3, args, L, gsh, msh, dev, world, rank, dist, torch, star_kw=SHARP_STARS)
+        if world == 1 and args.e2e_stars > 0:
+            try:
+                e2e_sharp = end_to_end_sharp(msh, gsh, min(4096, args.e2e_stars))
+            except Exception as e:
+                e2e_sharp = {"value": None, "error": repr(e)}
+        del gsh, msh
+        torch.cuda.empty_cache()
+
     # measured on this box beside the 8 TB/s spec figure: the guide's reference stream
     # (device copy, 16 B per lane; MI355X_MICROARCH.md quotes 6.29 TB/s for it)
     stream_gbs = None
@@ -772,6 +925,12 @@ def main():
         stream_gbs = 5 * 2.0 * nbytes / (e0.elapsed_time(e1) * 1e-3) / 1e9
         del src, dst
 
+    issue = None
+    if rank == 0 and not args.no_kernel_timing:
+        try:
+            issue = measure_issue(L, torch, dev)
+        except Exception as e:              # (an older library: the line goes without the block)
+            issue = None
     if world > 1:
         dist.barrier()
     if rank != 0:
@@ -809,7 +968,7 @@ def main():
                                       + line["config"]["workload"])
     if "parity" in res:
         line["parity"] = res["parity"]
-    rl = roofline_of(res, args, main_cfg, world)
+    rl = roofline_of(res, args, main_cfg, world, issue=issue)
     if stream_gbs is not None:
         rl["measured_stream_gbs"] = stream_gbs
     line["roofline"] = rl
@@ -819,7 +978,7 @@ def main():
             "repeats": res_other["repeats"], "value_min": res_other["value_min"], "value_max": res_other["value_max"],
             "parity": res_other.get("parity"),
             "config": cfg_block(other_cfg, res_other),
-            "roofline": roofline_of(res_other, args, other_cfg, world)}
+            "roofline": roofline_of(res_other, args, other_cfg, world, issue=issue)}
     if res_8d is not None:
         line["survey8d_grid"] = {
             "value": res_8d["value"], "unit": "stars/s", "ms_per_step": res_8d["ms_per_step"],
@@ -827,6 +986,19 @@ def main():
             "parity": res_8d.get("parity"),
             "config": cfg_block(main_cfg, res_8d, "survey8d"),
             "roofline": roofline_of(res_8d, args, main_cfg, world, with_traffic=False)}
+    if res_sharp is not None:
+        line["sharp_posterior"] = {
+            "value": res_sharp["value"], "unit": "stars/s", "ms_per_step": res_sharp["ms_per_step"],
+            "repeats": res_sharp["repeats"], "value_min": res_sharp["value_min"],
+            "value_max": res_sharp["value_max"], "parity": res_sharp.get("parity"),
+            "selected_fraction": res_sharp["selected_fraction"],
+            "config": {"workload": "750k-model x 12-band grid, Av+Rv free, S/N 50 photometry in every "
+                                   "band, parallax at S/N 10 for every star; grid = synth.make_sharp_grid "
+                                   "(colours quadratic in the band index: not degenerate with reddening)",
+                       "stars_per_step": args.batch, "sub_batch": args.sub_batch,
+                       "selected_fraction": res_sharp["selected_fraction"]},
+            "roofline": roofline_of(res_sharp, args, 3, world, with_traffic=False),
+            "fit_end_to_end": e2e_sharp}
     if world == 1 and args.e2e_stars > 0:
         kw = dict(rvlim=(3.32, 3.32)) if main_cfg == 2 else dict()
         line["fit_end_to_end"] = end_to_end(models, grid, None, args.e2e_stars, kw, main_cfg == 3,
@@ -837,7 +1009,8 @@ def main():
         # BASELINE configs[4] (cluster mode) rides along: < 1 s, so that the driver's own
         # run times it too (`python bench.py --config 5` prints the same block as a line)
         ca = argparse.Namespace(**vars(args))
-        ca.steps, ca.warmup, ca.cpu_seconds = 200, 20, 0.
+        ca.steps, ca.warmup = 200, 20
+        ca.cpu_seconds = min(args.cpu_seconds, 10.)     # (its CPU leg: ~1 s of numpy on 100 objects)
         try:
             line["cluster_mode"] = bench_cluster(ca, emit=False)
         except Exception as e:          # never at the expense of the headline line

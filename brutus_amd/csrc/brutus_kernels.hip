@@ -231,7 +231,13 @@ struct Timer {
     hipStream_t st;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> ev;
     explicit Timer(hipStream_t s) : st(s) {}
+    // (development aid: BRUTUS_TRACE_KERNELS=1 waits for every timed section and names it on
+    // stderr -- a memory fault then says which kernel it was)
+    const bool trace = getenv("BRUTUS_TRACE_KERNELS") != nullptr;
+    const char *cur = "";
     void begin(const char *name) {
+        cur = name;
+        if (trace) fprintf(stderr, "[brutus] %s ...\n", name);
         if (!g_timing) return;
         hipEvent_t a, b;
         (void)hipEventCreate(&a);
@@ -240,6 +246,10 @@ struct Timer {
         ev.push_back({name, {a, b}});
     }
     void end() {
+        if (trace) {
+            const hipError_t e = hipStreamSynchronize(st);
+            fprintf(stderr, "[brutus] %s done (%s)\n", cur, hipGetErrorString(e));
+        }
         if (!g_timing) return;
         (void)hipEventRecord(ev.back().second.second, st);
     }
@@ -1311,6 +1321,8 @@ int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt, int nst
     if (!d_grid_soa || !d_flux || !d_err || !d_mask || !d_workspace || !d_rec_idx || !d_rec_slot ||
         !d_rec_vals || !d_rec_off || !d_ndim || !h_counts || capacity < 0 || capacity > INT32_MAX)
         return fail(BRUTUS_EINVAL, "NULL pointer or capacity outside [0, 2^31)");
+    if (nmodel >= SURV_TAG_END)       // (candidate-list positions are kept as float32 bit patterns below 2^-100)
+        return fail(BRUTUS_EINVAL, "brutus_fit_batch takes grids of fewer than %d models", SURV_TAG_END);
     Workspace w = carve((char *)d_workspace, nmodel, nstar, true);
     if (w.bytes > workspace_bytes)
         return fail(BRUTUS_ENOMEM, "workspace too small: need %zu bytes, got %zu", w.bytes,
@@ -2258,6 +2270,23 @@ int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes, void 
     if ((n + TILE - 1) / TILE > 0x7fffffff) return fail(BRUTUS_EINVAL, "calibration buffer too large");
     hipLaunchKernelGGL(k_calib_copy16, dim3((unsigned)((n + TILE - 1) / TILE)), dim3(TILE), 0,
                        (hipStream_t)stream, (const calib_f4 *)d_in, (calib_f4 *)d_out, n);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+int brutus_calibrate_issue(int kind, int iters, int waves_per_simd, float *d_scratch,
+                           int64_t scratch_floats, void *stream) {
+    if (kind < 0 || kind > 2 || iters <= 0 || waves_per_simd < 1 || waves_per_simd > 8 || !d_scratch)
+        return fail(BRUTUS_EINVAL, "bad calibration arguments");
+    int dev = 0, ncu = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    HIP_TRY(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    const int blocks = ncu * waves_per_simd;       // 256 threads = one wave on each of a CU's four SIMDs
+    if (scratch_floats < (int64_t)blocks * 256) return fail(BRUTUS_EINVAL, "calibration scratch too small");
+    hipStream_t st = (hipStream_t)stream;
+    if (kind == 0) hipLaunchKernelGGL(k_calib_issue<0>, dim3(blocks), dim3(256), 0, st, d_scratch, iters);
+    else if (kind == 1) hipLaunchKernelGGL(k_calib_issue<1>, dim3(blocks), dim3(256), 0, st, d_scratch, iters);
+    else hipLaunchKernelGGL(k_calib_issue<2>, dim3(blocks), dim3(256), 0, st, d_scratch, iters);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -386,6 +386,7 @@ k_pre32(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             // a chi2 the cancellation cannot resolve, or a star float32 cannot
             // represent: NaN = "re-evaluate in float64"
             if (!(chi2 > 4.f * sp.eps) || !sp.ok) lnlp = NAN;
+            lnpr = surv_clean(lnpr);                  // (the plane's tag range stays free)
             if (!(chi2 > sp.chi2_lo) || !sp.ok) lnpr = NAN;
             if (live) {
                 const int64_t o = (int64_t)s * nmodel + i;

@@ -732,17 +732,23 @@ k_cmp_scatter(int64_t nmodel, int ntile, const unsigned long long *__restrict__ 
     }
 }
 
-// The float32 lnprob~ plane doubles as the survivor map.  Its genuine entries are negative,
-// -inf or NaN (the value of a survivor is not needed again: survivors are judged by their
-// final float64 lnprob); k_fflux overwrites a survivor's entry with the bit pattern
-// 1 + (position in the star's candidate list), a positive finite word, and leaves a
-// candidate that failed the exact cull test alone.  Every later pass (exact first-cut
-// threshold, classification) then reads ONE plane.
+// The float32 lnprob~ plane doubles as the survivor map.  k_fflux overwrites a survivor's entry
+// (its value is not needed again: survivors are judged by their final float64 lnprob) with
+// the bit pattern 1 + (position in the star's candidate list) -- as a float a positive number
+// below 2^-100 --, and leaves a candidate that failed the exact cull test alone.  Every later
+// pass (exact first-cut threshold, classification) then reads ONE plane.  A genuine entry is
+// never such a number: the float32 passes store +0 for any |lnprob~| < 2^-100 (surv_clean).
+// (Until round 5 a tag was "any positive finite word", on the assumption that a log-density is
+// negative -- but the scale-space parallax term contributes -ln(2 pi var)/2, which is +3 for a
+// parallax at S/N 10: positive entries were read as tags, and k_sel_classify gathered from
+// wherever they pointed.  Found by the sharp-posterior block of the bench.)
+constexpr int SURV_TAG_END = 27 << 23;            // bit pattern of 2^-100: list positions < 2.2e8
 __device__ __forceinline__ float surv_tag(int64_t slot) { return __int_as_float((int)slot + 1); }
 __device__ __forceinline__ bool surv_is(float x) {
     const int b = __float_as_int(x);
-    return b > 0 && b < 0x7F800000;
+    return b > 0 && b < SURV_TAG_END;
 }
+__device__ __forceinline__ float surv_clean(float x) { return fabsf(x) < 0x1p-100f ? 0.f : x; }
 __device__ __forceinline__ int surv_slot(float x) { return __float_as_int(x) - 1; }
 
 // A work item -> its star and the list positions [q0, q0 + n) it covers (k_offsets: items

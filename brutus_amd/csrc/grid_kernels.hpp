@@ -534,6 +534,45 @@ k_calib_copy16(const calib_f4 *__restrict__ in, calib_f4 *__restrict__ out, int6
     if (i < n) __builtin_nontemporal_store(__builtin_nontemporal_load(in + i), out + i);
 }
 
+// Measurement aid: the vector unit's issue rate, by kind of instruction.  Every lane runs
+// `iters` rounds of 128 independent-enough operations of one kind (8 accumulators), so a launch
+// of w x 256 workgroups of 256 threads puts w waves on every SIMD that issue nothing else:
+//   kind 0  v_fmac_f32      1  v_fmac_f64      2  v_exp_f32 (transcendental)
+// (the same loops as tools/ubench/dpp_rate.hip, which also has the DPP and packed forms).
+#define CALIB_REP16(x) x x x x x x x x x x x x x x x x
+template <int KIND>
+__global__ void __launch_bounds__(256)
+k_calib_issue(float *__restrict__ out, int iters) {
+    float a0 = threadIdx.x, a1 = 1.f, a2 = 2.f, a3 = 3.f, a4 = 4.f, a5 = 5.f, a6 = 6.f, a7 = 7.f;
+    const float r = threadIdx.x * 0.5f, x = 1.0001f;
+    double d0 = a0, d1 = a1, d2 = a2, d3 = a3;
+    const double dr = r, dx = x;
+    for (int i = 0; i < iters; ++i) {
+        if constexpr (KIND == 0) {
+            CALIB_REP16(asm volatile(
+                "v_fmac_f32_e32 %0, %8, %9\n v_fmac_f32_e32 %1, %8, %9\n v_fmac_f32_e32 %2, %8, %9\n"
+                "v_fmac_f32_e32 %3, %8, %9\n v_fmac_f32_e32 %4, %8, %9\n v_fmac_f32_e32 %5, %8, %9\n"
+                "v_fmac_f32_e32 %6, %8, %9\n v_fmac_f32_e32 %7, %8, %9\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7)
+                : "v"(r), "v"(x));)
+        } else if constexpr (KIND == 1) {
+            CALIB_REP16(asm volatile(
+                "v_fmac_f64_e32 %0, %4, %5\n v_fmac_f64_e32 %1, %4, %5\n v_fmac_f64_e32 %2, %4, %5\n"
+                "v_fmac_f64_e32 %3, %4, %5\n v_fmac_f64_e32 %0, %4, %5\n v_fmac_f64_e32 %1, %4, %5\n"
+                "v_fmac_f64_e32 %2, %4, %5\n v_fmac_f64_e32 %3, %4, %5\n"
+                : "+v"(d0), "+v"(d1), "+v"(d2), "+v"(d3) : "v"(dr), "v"(dx));)
+        } else {
+            CALIB_REP16(asm volatile(
+                "v_exp_f32_e32 %0, %0\n v_exp_f32_e32 %1, %1\n v_exp_f32_e32 %2, %2\n v_exp_f32_e32 %3, %3\n"
+                "v_exp_f32_e32 %4, %4\n v_exp_f32_e32 %5, %5\n v_exp_f32_e32 %6, %6\n v_exp_f32_e32 %7, %7\n"
+                : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7));)
+        }
+    }
+    out[(int64_t)blockIdx.x * blockDim.x + threadIdx.x] =
+        a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7 + (float)(d0 + d1 + d2 + d3);
+}
+#undef CALIB_REP16
+
 __global__ void k_debug_exp10(const double *__restrict__ x, double *__restrict__ y, int64_t n) {
     const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) y[i] = fast_exp10(x[i]);

@@ -323,6 +323,9 @@ k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int
             // a chi2 the cancellation cannot resolve, or a star float32 cannot represent:
             // NaN = "re-evaluate in float64"
             lnlp = chi2 > eps4 ? lnlp : NAN;
+            // (|lnprob~| < 2^-100 is stored as +0: that range of bit patterns marks survivors in
+            // this plane, fit_kernels.hpp surv_tag)
+            lnpr = fabsf(lnpr) < 0x1p-100f ? 0.f : lnpr;
             lnpr = chi2 > chi2_lo ? lnpr : NAN;
             s_t[wv][0][u][lane] = lnlp;
             s_t[wv][1][u][lane] = lnpr;

@@ -8,7 +8,7 @@ shape, dtype and value ranges as `utils.load_models` returns
 """
 import numpy as np
 
-__all__ = ["make_grid", "make_stars", "GRID_SEED"]
+__all__ = ["make_grid", "make_stars", "make_sharp_grid", "GRID_SEED"]
 
 GRID_SEED = 20250523
 
@@ -52,13 +52,16 @@ def make_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
 
 
 def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
-               min_frac_err=0.02):
+               min_frac_err=0.02, frac_err=None, parallax_snr=None):
     """Draw `nstar` synthetic stars from the grid.
 
     Returns dict with flux, err (nstar, nfilt) f64 in maggies, mask (bool, all
     True), parallax / parallax_err (mas; NaN where absent), coords (l, b) deg
     and the truth columns.  Fractional flux errors follow the spread seen in
     the reference's Orion demo fixture (median 0.025-0.06 mag, tail to 0.14).
+    `frac_err`: one fractional error for every band instead (0.02 = S/N 50);
+    `parallax_snr`: parallax errors as that fraction of the true parallax instead of the
+    log-uniform 0.05-1.5 mas.
     """
     rng = np.random.RandomState(seed)
     nmodel, nfilt, _ = models.shape
@@ -72,11 +75,15 @@ def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
     frac = np.maximum(min_frac_err,
                       10. ** rng.normal(np.log10(0.04), 0.25,
                                         size=(nstar, nfilt)))
+    if frac_err is not None:
+        frac = np.full((nstar, nfilt), float(frac_err))
     err = frac * flux_true
     flux = flux_true + rng.normal(size=(nstar, nfilt)) * err
     mask = np.ones((nstar, nfilt), dtype=bool)
     if with_parallax:
         perr = 10. ** rng.uniform(np.log10(0.05), np.log10(1.5), size=nstar)
+        if parallax_snr is not None:
+            perr = (1. / dist) / float(parallax_snr)
         par = 1. / dist + rng.normal(size=nstar) * perr
         drop = rng.uniform(size=nstar) < frac_no_parallax
         par[drop] = np.nan
@@ -89,6 +96,30 @@ def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
     return dict(flux=flux, err=err, mask=mask, parallax=par, parallax_err=perr,
                 coords=coords, true_idx=idx, true_av=av, true_rv=rv,
                 true_dist=dist)
+
+
+def make_sharp_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
+    """`make_mist_like_grid` with colours that reddening cannot imitate: the temperature term of
+    the SED is QUADRATIC in the band index (peaked mid-spectrum) where the reddening vector
+    falls monotonically, so a (temperature, Av) trade-off that keeps all bands within their
+    errors does not exist.  With S/N 50 photometry and a parallax at S/N 10
+    (`make_stars(..., frac_err=0.02, parallax_snr=10., frac_no_parallax=0.)`) a few per cent
+    of the grid pass the first cut per object -- the regime of BASELINE.md section 2 and of
+    the demo notebooks, where the float32 proof pass and the bookkeeping are the call."""
+    models, labels, labels_mask = make_mist_like_grid(nmodel, nfilt, seed)
+    rng = np.random.RandomState(seed + 1)
+    lam = np.linspace(0., 1., nfilt)
+    x = (labels['eep'] - 202.) / 606.
+    t = 0.25 + 0.45 * (labels['mini'] - 0.5) / 1.5 - 0.3 * x - 0.04 * (labels['feh'] + 1.)
+    mag0 = models[:, :, 0].astype(np.float64)
+    M = mag0.mean(axis=1)
+    bump = 1. - (2. * lam - 1.) ** 2                     # 0 at both ends, 1 in the middle
+    colour = (1. - t)[:, None] * (2.4 * bump - 1.6)[None, :]
+    colour += 0.35 * (labels['feh'] + 1.)[:, None] * np.cos(3. * np.pi * lam)[None, :]
+    mag = M[:, None] + colour + rng.normal(0., 0.004, size=(nmodel, nfilt))
+    models = models.copy()
+    models[:, :, 0] = mag.astype(np.float32)
+    return models, labels, labels_mask
 
 
 def make_mist_like_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):

@@ -56,6 +56,15 @@ int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n,
 int brutus_calibrate_copy16(const void *d_in, void *d_out, int64_t nbytes,
                             void *stream);
 
+/* Measurement aid: the vector unit's issue rate.  Launches waves_per_simd x (number of CUs)
+ * workgroups of 256 threads, every lane running `iters` x 128 back-to-back operations of one
+ * kind (0 v_fmac_f32, 1 v_fmac_f64, 2 v_exp_f32) and nothing else; timed by the caller with
+ * events on `stream`, (elapsed) / (iters x 128 x waves_per_simd) is the time one SIMD needs
+ * per wave-instruction at the clock the device holds under that load -- the unit of
+ * bench.py's `roofline.valu`.  d_scratch: waves_per_simd x CUs x 256 floats. */
+int brutus_calibrate_issue(int kind, int iters, int waves_per_simd, float *d_scratch,
+                           int64_t scratch_floats, void *stream);
+
 /* Test hooks: y[i] = the kernels' own elementary functions for n inputs.  `which` in
  * brutus_debug_math: 0 10^x, 1 e^x, 2 ln x (the general forms); 3 sqrt x, 4 1/sqrt x, 5 1/x
  * (hardware seed + Newton); 6 e^x for finite x, 7 ln x for normal positive x (the

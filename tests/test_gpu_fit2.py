@@ -150,6 +150,30 @@ def test_high_signal_to_noise_and_sharp_posteriors():
         _vs_full_grid(grid, st, dict(rvlim=rvlim), tol=1e-8, audit_frac=0.5)
 
 
+def test_positive_log_densities_are_not_survivor_tags():
+    """S/N 50 photometry with a parallax at S/N 10 on the sharp grid: the scale-space parallax
+    term of the first-cut statistic (pdf.py:252-258) contributes -ln(2 pi var) / 2 = +3, so
+    lnprob is POSITIVE for the best models.  The float32 lnprob~ plane marks survivors with
+    bit patterns of its own (fit_kernels.hpp surv_tag); until round 5 those were "any positive
+    finite word", a positive statistic was read as a tag and k_sel_classify gathered from
+    wherever it pointed (a memory fault on the sharp-posterior block of the bench)."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.pdf import scale_parallax_lnprior
+    models, _, _ = synth.make_sharp_grid(60000, 12)
+    st = synth.make_stars(models, 32, seed=4243, frac_err=0.02, parallax_snr=10., frac_no_parallax=0.)
+    grid = fitting.DeviceGrid(models)
+    full = fitting.loglike_batch(st["flux"][:4], st["err"][:4], st["mask"][:4], grid,
+                                 parallax=st["parallax"][:4], parallax_err=st["parallax_err"][:4])
+    with np.errstate(all="ignore"):
+        top = [np.nanmax(full["lnl"][i] + scale_parallax_lnprior(
+            full["scale"][i], 1. / np.sqrt(np.abs(full["icov6"][0, i])), st["parallax"][i],
+            st["parallax_err"][i])) for i in range(4)]
+    assert max(top) > 0.5, top                      # the case is exercised
+    for kw in (dict(), dict(rvlim=(3.32, 3.32))):
+        recs = _vs_full_grid(grid, st, kw)
+        assert np.median([r["sel"].size for r in recs]) < 0.05 * 60000
+
+
 ADVERSARIAL = [
     ("sn1e3", 12, dict(frac=1e-3)),
     ("sn1e4", 12, dict(frac=1e-4)),

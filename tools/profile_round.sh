@@ -16,7 +16,7 @@ cd /tmp && export TMPDIR=/tmp
 # that bench.py's own HIP-event pass (also sequential) must agree with
 for cfg in 2 3; do
   rocprofv3 --kernel-trace --stats -d $O/${tag}_trace_cfg${cfg} -o t -- python $R/bench.py --config $cfg \
-      --steps 4 --warmup 1 --batch 512 --sub-batch $B --streams 1 --cpu-seconds 0 --e2e-stars 0 --single-config --no-survey-grid --no-cluster \
+      --steps 4 --warmup 1 --batch 512 --sub-batch $B --streams 1 --cpu-seconds 0 --e2e-stars 0 --single-config --no-survey-grid --no-sharp --no-cluster \
       > $O/${tag}_bench_under_rocprof_cfg${cfg}_b${B}.json 2> $O/${tag}_trace_cfg${cfg}.log
 done
 for cfg in 2 3; do
