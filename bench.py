@@ -276,10 +276,13 @@ def measured_traffic(kernel, batch, config):
     try:
         with open(path) as f:
             table = json.load(f)
-        for row in table["rows"]:
-            if (row["kernel"] == kernel and row["batch"] == batch
-                    and row["config"] == config):
-                return row["hbm_bytes_per_launch"]
+        # (rows are per kernel; a timer name of the library can cover several kernels)
+        tot = [row["hbm_bytes_per_launch"] for row in table["rows"]
+               if row["batch"] == batch and row["config"] == config
+               and (row["kernel"] == kernel
+                    or (kernel != "__total__" and TIMER_OF(row["kernel"]) == kernel))]
+        if tot:
+            return float(sum(tot))
     except (IOError, ValueError, KeyError):
         pass
     return None
