@@ -15,7 +15,10 @@ constexpr int PS_TILE = 256;                 // = TILE of common.hpp
 constexpr int PS_NBMAX = BRUTUS_MAX_FILT;    // = NBMAX
 #endif
 
-constexpr int F2_T = 8;        // tiles per workgroup (2048 models)
+#ifndef BRUTUS_F2_T
+#define BRUTUS_F2_T 8
+#endif
+constexpr int F2_T = BRUTUS_F2_T;   // tiles per block of the float32 pass and its partial maxima (2048 models)
 constexpr int NV32 = 10;       // float32 partial maxima per (block, star)
 
 struct Star32 {
