@@ -591,6 +591,8 @@ KERNEL_ALG_BYTES = {
 def TIMER_OF(kernel):
     """The library's timer name (`kernels_ms`) a kernel runs under (brutus_kernels.hip, run_fit)."""
     k = kernel.split("<")[0]
+    if k == "k_fflux":                              # k_fflux<NB, RVF, FIRST>: the continuation launches
+        return "k_fflux" if kernel.rstrip(">").endswith("true") else "k_fflux_cont"
     if k in ("k_pre32", "k_pre32s"):
         return "k_pre32"
     if k in ("k_top", "k_top1", "k_hot_list"):
@@ -789,7 +791,7 @@ def roofline_of(res, args, config, world, with_traffic=True, issue=None):
             e["traffic"] = tr
             # vector issue time of the kernels timed under this name (roofline.valu's table)
             vi = sum(v["issue_ms_per_call"] for k, v in valu_k.items()
-                     if TIMER_OF(k) == name.replace("_cont", "")) if valu_k else None
+                     if TIMER_OF(k) == name) if valu_k else None
             if vi:
                 e["valu_issue_ms"] = vi
                 e["valu_issue_frac"] = vi / ms

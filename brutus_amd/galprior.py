@@ -17,7 +17,7 @@ parameter set -- Galactic -> FK5(J2000) -> ICRS rotation, `galcen_coord` ICRS
 as in the reference, the frame's Sun (8.122 kpc, 20.8 pc) is NOT the `R_solar`/`Z_solar`
 = (8.2 kpc, 25 pc) at which the density model is normalised.  `frame="simple"` is the
 self-consistent geometry of earlier versions of this package (Sun at `R_solar`,
-`Z_solar`, l = 0 towards the centre); DESIGN.md quantifies the difference.
+`Z_solar`, l = 0 towards the centre); HISTORY.md section 2.3c quantifies the difference.
 """
 from math import erf, log, sqrt
 

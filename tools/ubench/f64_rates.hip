@@ -2,7 +2,7 @@
 // kernels lean on (gfx950).  Each kernel runs ITER x 8 independent copies of one
 // instruction per lane, 4 waves per SIMD on every CU; the printed figure is
 // "cycles per wave-instruction per SIMD" (v_fma_f64 = 4 means full rate... the
-// table in DESIGN.md quotes these).  Build + run:
+// table in HISTORY.md section 4 quotes these; round 5: tools/ubench/dpp_rate.hip).  Build + run:
 //   hipcc --offload-arch=gfx950 -O2 tools/ubench/f64_rates.hip -o /tmp/f64_rates && /tmp/f64_rates
 #include <hip/hip_runtime.h>
 #include <cstdio>
