@@ -92,6 +92,9 @@ struct Workspace {
     int32_t *ctr;       // (8,) device-driven call: [0] stars to probe, [1] stars to redo, [3] "host path needed";
                         //      both drivers: [4], [5] lengths of the hot (block, star) lists of the two k_top1 launches
     int32_t *hot;       // (nblk2 * S,) hot (block, star) pairs of a k_top1 launch
+    int64_t *res;       // brutus_fit_batch: what the host reads at the end of a call, in ONE copy --
+                        // totals[4] = selected, derived, candidates, -; then k1 (S), k2 (S),
+                        // n_unconv (4), ctr (8) as int32 (w.k1 / w.k2 / w.n_unconv / w.ctr point here)
     int32_t *kfix;      // (S,)
     double *thr_cull, *maxsurv, *thr_sel;
     int32_t *surv_idx;  // (S * nmodel,) worst case: candidate lists, then band queues, then derived lists
@@ -157,7 +160,16 @@ Workspace carve(char *base, int64_t nmodel, int nstar, bool fit) {
     } else {
         w.ids = (int32_t *)take(sizeof(int32_t) * nstar);
         w.ids2 = (int32_t *)take(sizeof(int32_t) * nstar);
-        w.ctr = (int32_t *)take(sizeof(int32_t) * 8);
+        w.res = (int64_t *)take(sizeof(int64_t) * 4 + sizeof(int32_t) * (2 * (size_t)nstar + 12));
+        if (base) {
+            int32_t *r32 = (int32_t *)(w.res + 4);
+            w.k1 = r32;
+            w.k2 = r32 + nstar;
+            w.n_unconv = r32 + 2 * nstar;
+            w.ctr = r32 + 2 * nstar + 4;
+        } else {
+            w.ctr = nullptr;
+        }
         w.kfix = (int32_t *)take(sizeof(int32_t) * nstar);
         w.thr_cull = (double *)take(sizeof(double) * nstar);
         w.maxsurv = (double *)take(sizeof(double) * nstar);
@@ -408,8 +420,8 @@ void launch_fflux(hipStream_t st, int nact, const float *grid, int64_t nmodel, i
                            grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx,
                            w.surv_off, w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part,
                            w.lnpr32, w.thr_cull, w.ids, nact, (const int32_t *)nullptr);
-    else
-        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(CONT_BLOCKS), dim3(TILE), 0, st,
+    else       // (nact = -r, the r-th continuation: a per cent of the stars reach the first, fewer every round)
+        hipLaunchKernelGGL((k_fflux<NB, RVF, false>), dim3(nact == -1 ? CONT_BLOCKS : CONT_BLOCKS / 8), dim3(TILE), 0, st,
                            grid, nmodel, nmodel_pad, nstar, w.stars, p, w.k1, w.k2, w.surv_idx,
                            w.surv_off, w.wbase_surv, w.items_surv, rec, w.step_st, w.lnprob_st, w.part,
                            w.lnpr32, w.thr_cull, w.ids, 0, nact_dev);
@@ -491,7 +503,8 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     const int nrun = mode == 2 ? nstar : (int)ids.size();
     const int32_t *list = mode == 1 ? w.ids_all : w.ids;
     if (mode == 0) HIP_TRY(hipMemcpyAsync(w.ids, ids.data(), sizeof(int32_t) * nrun, hipMemcpyHostToDevice, st));
-    if (mode != 2) HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
+    // (mode 1: kfix = 2 for every star, set on the device by k_prep32)
+    if (mode == 0) HIP_TRY(hipMemcpyAsync(w.kfix, kfix.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
     const int32_t *nrun_dev = mode == 2 ? w.ctr + 1 : nullptr;
     P32 q;
     q.avmin = (float)p.avmin;
@@ -549,15 +562,17 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     const RecPlanes rec{d_rec_vals, capacity};
     std::vector<int32_t> ids(nstar), kfix(nstar, 2), k1(nstar, 0), status(nstar, 0);
     for (int s = 0; s < nstar; ++s) ids[s] = s;
-    HIP_TRY(hipMemcpyAsync(w.ids_all, ids.data(), sizeof(int32_t) * nstar, hipMemcpyHostToDevice, st));
     const int audit_on = env_int("BRUTUS_AUDIT", 0);
     float *aud = audit_on ? w.aud : nullptr;
     if (aud) HIP_TRY(hipMemsetAsync(w.aud, 0, sizeof(float) * nstar * 4, st));
     h_counts[0] = h_counts[1] = h_counts[2] = 0;
 
     // ---- float32 pass over the whole grid; K1 where float32 can decide it ----------
+    // (k_prep32 also starts the call's small device state: w.ids_all = 0, 1, ..., kfix = k2 = 2,
+    // n_unconv and ctr zero -- they lie side by side in the result block)
     hipLaunchKernelGGL(k_prep32, dim3(nstar), dim3(64), 0, st, nstar, w.stars,
-                       (float)env_double("BRUTUS_EPS_SCALE", 1.0), p.dim_prior, w.s32);
+                       (float)env_double("BRUTUS_EPS_SCALE", 1.0), p.dim_prior, w.s32,
+                       CallInit{w.ids_all, w.kfix, w.k2, w.n_unconv, 12});
     // Two drivers for the same kernels.  DEVICE-DRIVEN (default): which stars need the exact K1
     // probe, which need their float32 planes redone and which iterate on in the flux phase is
     // decided and listed ON THE DEVICE (k_pre_decide, k_k1_decide, k_fflux_decide), the
@@ -568,7 +583,6 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     // the HOST-DRIVEN driver below (round 3's: a host decision after the float32 pass and after
     // every flux launch; each one idles the stream for a round trip).
     const int FLUX_ROUNDS = env_int("BRUTUS_FLUX_ROUNDS", 4);       // (development switch)
-    HIP_TRY(hipMemsetAsync(w.ctr, 0, sizeof(int32_t) * 8, st));
     if (device_driven) {
         if (int rc = launch_pre32<NB, RVF>(grid, nmodel, nfilt, nstar, ids, kfix, p, w, 0, st, tm, 1)) return rc;
         if (int rc = launch_k1probe<NB, RVF>(grid, nmodel, nstar, nullptr, p, max_iter, w, st, tm)) return rc;
@@ -627,8 +641,8 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     hipLaunchKernelGGL(k_cmp_count32, dim3(NCHUNK, nstar), blk, 0, st, nmodel, ntile, w.lnlp32, w.candS,
                        w.counts, w.smask);
     {
-        const OffsetsJob job{w.counts, w.coffsets, w.surv_off, w.wbase_surv};
-        hipLaunchKernelGGL(k_offsets, dim3(1), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, job, job);
+        const OffsetsJob job{w.counts, w.coffsets, w.surv_off, w.wbase_surv, w.res + 2};
+        hipLaunchKernelGGL(k_offsets, dim3(2), dim3(OFF_T), 0, st, nstar, job, job);
     }
     hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_surv,
                        w.coffsets, w.surv_off, w.items_surv);
@@ -636,27 +650,27 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
                        w.coffsets, (int64_t)nstar * nmodel, w.surv_idx);
     tm.end();
     int64_t h_ncand = 0;
-    HIP_TRY(hipMemcpyAsync(&h_ncand, w.surv_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
+    if (!device_driven)
+        HIP_TRY(hipMemcpyAsync(&h_ncand, w.surv_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
 
     // ---- exact cull test + flux phase on the candidates; results into the record planes ------
-    hipLaunchKernelGGL(k_set_i32, dim3((nstar + 255) / 256), dim3(256), 0, st, w.k2, nstar, 2);
     int32_t h_unconv = 0;
     int iter = 2;
     std::vector<int32_t> k2s(nstar), act;
     if (device_driven) {
         // opening launch + FLUX_ROUNDS continuations; round r's decision counts and lists the
         // stars that iterate on in w.n_unconv[r & 1] / w.ids, the next launch reads them there
+        // (both counters start at zero, k_prep32; round r's decision zeroes the one round r + 1 adds to)
         for (int r = 0; r <= FLUX_ROUNDS; ++r) {
             tm.begin(r == 0 ? "k_fflux" : "k_fflux_cont");
-            launch_fflux<NB, RVF>(st, r == 0 ? 0 : -1, grid, nmodel, nmodel_pad, nstar, p, w, rec,
+            launch_fflux<NB, RVF>(st, r == 0 ? 0 : -r, grid, nmodel, nmodel_pad, nstar, p, w, rec,
                                   w.n_unconv + ((r - 1) & 1));
             tm.end();
-            HIP_TRY(hipMemsetAsync(w.n_unconv + (r & 1), 0, sizeof(int32_t), st));
             hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
-                               p.ln_sub, w.k2, w.maxsurv, w.n_unconv + (r & 1), w.ids);
+                               p.ln_sub, w.k2, w.maxsurv, w.n_unconv + (r & 1), w.ids,
+                               w.n_unconv + ((r + 1) & 1));
         }
-        HIP_TRY(hipMemcpyAsync(w.n_unconv + 2, w.n_unconv + (FLUX_ROUNDS & 1), sizeof(int32_t),
-                               hipMemcpyDeviceToDevice, st));      // stars still iterating at the end
+        // (stars still iterating at the end: w.n_unconv[FLUX_ROUNDS & 1], read with the result block)
     } else
     for (int first = 1;; first = 0) {
         HIP_TRY(hipMemsetAsync(w.n_unconv, 0, sizeof(int32_t), st));
@@ -664,7 +678,7 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
         launch_fflux<NB, RVF>(st, (int)act.size(), grid, nmodel, nmodel_pad, nstar, p, w, rec);
         tm.end();
         hipLaunchKernelGGL(k_fflux_decide, dim3(nstar), dim3(256), 0, st, nstar, w.wbase_surv, w.part,
-                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv, (int32_t *)nullptr);
+                           p.ln_sub, w.k2, w.maxsurv, w.n_unconv, (int32_t *)nullptr, (int32_t *)nullptr);
         HIP_TRY(hipMemcpyAsync(&h_unconv, w.n_unconv, sizeof(int32_t), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipMemcpyAsync(k2s.data(), w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
@@ -717,9 +731,9 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     // ---- record index (model, slot) in np.where order; values of the derived records -------
     tm.begin("k_select");
     {
-        const OffsetsJob sel{w.counts, w.offsets, d_rec_off, nullptr};
-        const OffsetsJob der{w.dcounts, w.doffsets, w.der_off, w.wbase_der};
-        hipLaunchKernelGGL(k_offsets, dim3(2), dim3(BRUTUS_MAX_BATCH), 0, st, nstar, sel, der);
+        const OffsetsJob sel{w.counts, w.offsets, d_rec_off, nullptr, w.res + 0};
+        const OffsetsJob der{w.dcounts, w.doffsets, w.der_off, w.wbase_der, w.res + 1};
+        hipLaunchKernelGGL(k_offsets, dim3(4), dim3(OFF_T), 0, st, nstar, sel, der);
     }
     hipLaunchKernelGGL(k_items, dim3((NCHUNK * nstar + 255) / 256), dim3(256), 0, st, nstar, w.wbase_der,
                        w.doffsets, w.der_off, w.items_der);
@@ -732,18 +746,26 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     hipLaunchKernelGGL((k_derive<NB, RVF>), dim3(PERSIST_BLOCKS), blk, 0, st, grid, nmodel_pad, nstar,
                        w.stars, p, w.k1, w.surv_idx, w.wbase_der, w.items_der, w.surv_off, rec);
     tm.end();
+    // everything the host wants to know, in one copy: totals, K1, K2, the counters
     int64_t h_nder = 0;
     int32_t h_ctr[8] = {0, 0, 0, 0, 0, 0, 0, 0}, h_left = 0;
-    HIP_TRY(hipMemcpyAsync(&h_counts[0], d_rec_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipMemcpyAsync(&h_nder, w.der_off + nstar, sizeof(int64_t), hipMemcpyDeviceToHost, st));
-    if (h_k1) HIP_TRY(hipMemcpyAsync(h_k1, w.k1, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-    if (h_k2) HIP_TRY(hipMemcpyAsync(h_k2, w.k2, sizeof(int32_t) * nstar, hipMemcpyDeviceToHost, st));
-    if (device_driven) {
-        HIP_TRY(hipMemcpyAsync(h_ctr, w.ctr, sizeof(h_ctr), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(&h_left, w.n_unconv + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    }
+    std::vector<int64_t> h_res(4 + (2 * (size_t)nstar + 12 + 1) / 2);
+    HIP_TRY(hipMemcpyAsync(h_res.data(), w.res, sizeof(int64_t) * 4 + sizeof(int32_t) * (2 * (size_t)nstar + 12),
+                           hipMemcpyDeviceToHost, st));
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    {
+        const int32_t *r32 = reinterpret_cast<const int32_t *>(h_res.data() + 4);
+        h_counts[0] = h_res[0];
+        h_nder = h_res[1];
+        if (device_driven) h_ncand = h_res[2];
+        if (h_k1) memcpy(h_k1, r32, sizeof(int32_t) * nstar);
+        if (h_k2) memcpy(h_k2, r32 + nstar, sizeof(int32_t) * nstar);
+        if (device_driven) {
+            memcpy(h_ctr, r32 + 2 * nstar + 4, sizeof(h_ctr));
+            h_left = r32[2 * nstar + (FLUX_ROUNDS & 1)];
+        }
+    }
     if (device_driven && h_ncand > capacity) {      // (every write was bounded by the capacity)
         h_counts[1] = h_ncand;
         h_counts[2] = h_ncand + (h_nder > 0 ? h_nder : h_ncand);

@@ -51,9 +51,16 @@ namespace {
 // ---------------------------------------------------------------------------
 // per-star float32 companion of StarPrep
 // ---------------------------------------------------------------------------
+// `init` (brutus_fit_batch): the call's small device state starts here too -- the identity star
+// list, two sweeps / two flux iterations per star, every counter zero -- instead of as two
+// uploads, a fill kernel and a memset in front of it.
+struct CallInit {
+    int32_t *ids_all, *kfix, *k2, *counters;
+    int ncounters;
+};
 __global__ void __launch_bounds__(64)
 k_prep32(int nstar, const StarPrep *__restrict__ stars, float eps_scale, int dim_prior,
-         Star32 *__restrict__ out) {
+         Star32 *__restrict__ out, CallInit init) {
     // one wave per star, lane = band (like k_prep); the band sums are added up in band order
     static_assert(NBMAX <= 64, "one lane per band");
     __shared__ double s_a[NBMAX], s_b[NBMAX], s_c[NBMAX];
@@ -61,6 +68,12 @@ k_prep32(int nstar, const StarPrep *__restrict__ stars, float eps_scale, int dim
     __shared__ int s_bad;
     const int s = blockIdx.x, j = threadIdx.x;
     if (s >= nstar) return;
+    if (init.ids_all && j == 0) {
+        init.ids_all[s] = s;
+        init.kfix[s] = 2;
+        init.k2[s] = 2;
+    }
+    if (init.counters && s == 0 && j < init.ncounters) init.counters[j] = 0;
     const StarPrep &sp = stars[s];
     Star32 &o = out[s];
     // bands with a non-positive flux carry mags_var = 1e50: no weight

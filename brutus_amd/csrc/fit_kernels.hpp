@@ -638,24 +638,32 @@ struct OffsetsJob {
     const int64_t *counts;
     int64_t *offsets, *star_off;
     int32_t *wbase;
+    int64_t *total_out;      // (optional) the grand total once more, where the host collects its results
 };
-__global__ void __launch_bounds__(BRUTUS_MAX_BATCH)
+// (Round 5: 1024 threads and one workgroup per SCAN -- blockIdx.x = 2 * job + scan -- instead of
+// 256 threads running a job's two scans one after the other with 32-64 entries per lane:
+// 30 -> ~8 us per launch; the work-item scan reads only the counts, not the first scan's output.)
+constexpr int OFF_T = 1024;
+__global__ void __launch_bounds__(OFF_T)
 k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
-    constexpr int NT = BRUTUS_MAX_BATCH;
-    constexpr int EPT = NCHUNK;                       // entries per lane at the full batch
+    constexpr int NT = OFF_T;
+    constexpr int EPT = (BRUTUS_MAX_BATCH * NCHUNK + NT - 1) / NT;      // entries per lane at the full batch
     __shared__ int64_t s_slot64[NT / 64 + 1];
     __shared__ int32_t s_slot32[NT / 64 + 1];
-    const OffsetsJob job = blockIdx.x == 0 ? job0 : job1;
+    const OffsetsJob job = (blockIdx.x >> 1) == 0 ? job0 : job1;
+    const bool items = (blockIdx.x & 1) != 0;
     const int64_t *__restrict__ counts = job.counts;
     const int total = nstar * NCHUNK;
     const int ept = (total + NT - 1) / NT;
     const int e0 = threadIdx.x * ept;
-    {
+    if (!items) {
         int64_t r[EPT];
         int64_t sum = 0;
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
-            r[k] = k < ept && e0 + k < total ? counts[e0 + k] : 0;
+            const int e = e0 + k;
+            const int64_t v = counts[e < total ? e : total - 1];      // (clamped address + select)
+            r[k] = k < ept && e < total ? v : 0;
             sum += r[k];
         }
         int64_t all;
@@ -668,19 +676,28 @@ k_offsets(int nstar, OffsetsJob job0, OffsetsJob job1) {
             }
             pre += r[k];
         }
-        if (threadIdx.x == 0) job.star_off[nstar] = all;
+        if (threadIdx.x == 0) {
+            job.star_off[nstar] = all;
+            if (job.total_out) *job.total_out = all;
+        }
+        return;
     }
     if (!job.wbase) return;
-    __syncthreads();
     {
         int32_t r[EPT];
         int32_t sum = 0;
+        int c = e0 / nstar, q = e0 - c * nstar;      // e = c * nstar + q, stepped without divisions
 #pragma unroll
         for (int k = 0; k < EPT; ++k) {
-            const int e = e0 + k;                     // = c * nstar + q
-            const int c = e / nstar, q = e - c * nstar;
-            r[k] = k < ept && e < total ? (int32_t)((counts[(int64_t)q * NCHUNK + c] + TILE - 1) / TILE) : 0;
+            const int e = e0 + k;
+            const bool in = k < ept && e < total;
+            const int64_t v = counts[in ? (int64_t)q * NCHUNK + c : 0];
+            r[k] = in ? (int32_t)((v + TILE - 1) / TILE) : 0;
             sum += r[k];
+            if (++q == nstar) {
+                q = 0;
+                ++c;
+            }
         }
         int32_t all;
         int32_t pre = block_exclusive_sum<int32_t, NT>(sum, s_slot32, all);
@@ -1135,9 +1152,12 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
 __global__ void k_fflux_decide(int nstar, const int32_t *__restrict__ wbase,
                                const double *__restrict__ part, double ln_sub,
                                int32_t *__restrict__ k2state, double *__restrict__ maxsurv,
-                               int32_t *__restrict__ n_unconv, int32_t *__restrict__ act) {
+                               int32_t *__restrict__ n_unconv, int32_t *__restrict__ act,
+                               int32_t *__restrict__ zero_next) {
     __shared__ double sm[3][4];
     const int s = blockIdx.x;
+    // (the counter the NEXT round's decision adds to: free since the launch before this one read it)
+    if (zero_next && s == 0 && threadIdx.x == 0) *zero_next = 0;
     if (k2state[s] < 0) return;
     double v[3] = {-INFINITY, -INFINITY, -INFINITY};
     const int per = TILE / 64;       // k_fflux leaves one partial per wave
