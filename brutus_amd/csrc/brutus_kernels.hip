@@ -2279,6 +2279,30 @@ int brutus_debug_galprior_mc(const brutus_post_params *params, int n, const doub
     return 0;
 }
 
+int brutus_debug_galprior_sl(const brutus_post_params *params, int n, const double *d_dist,
+                             const double *d_coord, const double *d_feh, const double *d_loga,
+                             double *d_out, int32_t *d_used, void *stream) {
+    if (!params || !d_dist || !d_coord || !d_feh || !d_loga || !d_out || !d_used || n <= 0)
+        return fail(BRUTUS_EINVAL, "bad arguments");
+    PostParams pp;
+    fill_post_params(pp, params);
+    if (pp.halo_tbl == 0.) return fail(BRUTUS_EINVAL, "these parameters do not admit the halo table: no sightline table");
+    hipStream_t st = (hipStream_t)stream;
+    StarGeom *geom = nullptr;
+    HIP_TRY(hipMalloc(&geom, sizeof(StarGeom)));
+    DustCtx dc{};
+    hipLaunchKernelGGL(k_post_geom, dim3(1), dim3(64), 0, st, pp, 1, d_coord, (const double *)nullptr,
+                       (const double *)nullptr, dc, geom);
+    hipLaunchKernelGGL(k_debug_galprior_sl, dim3((n + TILE - 1) / TILE), dim3(TILE), 0, st, pp, n, d_dist, geom,
+                       d_feh, d_loga, d_out, d_used);
+    hipError_t e = hipGetLastError();
+    hipError_t e2 = hipStreamSynchronize(st);
+    hipFree(geom);
+    HIP_TRY(e);
+    HIP_TRY(e2);
+    return 0;
+}
+
 int brutus_calibrate_traffic(const float *d_in, double *d_out, int64_t n, void *stream) {
     if (!d_in || !d_out || n <= 0) return fail(BRUTUS_EINVAL, "bad calibration arguments");
     hipLaunchKernelGGL(k_calib_stream, dim3(4096), dim3(TILE), 0, (hipStream_t)stream, d_in, d_out, n);

@@ -652,29 +652,16 @@ __device__ __forceinline__ void mc_sample_lin(const PostParams &pp, const StarGe
           r_mc >= pp.rvlim[0] && r_mc <= pp.rvlim[1];
 }
 
-// mc_sample_lin with the object's constants read through `cb` (StarGeom::mc, McC) and the
-// halo table: the form the two Monte Carlo kernels run when the table is valid.  Same
-// quantities; R^2 from the quadratic in d (rounding differs from x^2 + y^2 by ~1e-15
-// relative to R^2 + Rs^2), clamped at 0 against cancellation on a sightline through the
-// Galactic centre's axis.
-__device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const StarGeom &g, bool has_par,
-                                            bool dust_on, bool one_rs, double z0, double z1, double z2,
-                                            double s0, double a0, double r0, const double (&L)[6],
-                                            const double (&EF)[3], const double (&EA)[3],
+// the three density components along the object's sightline at distance d, relative to e^lnK
+// (`aZ` = |Z|, or sigma Z with a fixed sign for the smooth continuation the sightline table fits)
+__device__ __forceinline__ void sightline_T(CPtr cb, bool one_rs, double d, double Z, double aZ,
                                             const double *__restrict__ tbl, const double *__restrict__ ht,
-                                            bool &inb, double &lin, double &epar) {
-    const double s_mc = s0 + L[0] * z0;
-    const double a_mc = a0 + (L[1] * z0 + L[2] * z1);
-    const double r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
-    double par, d;
-    fast_sqrt_rsqrt_pos(s_mc, par, d);       // (s_mc <= 0: NaN, and the sample is out of bounds)
+                                            double &T0, double &T1, double &T2) {
     const double R2 = fmax(fma(fma(cb[MC_A2], d, cb[MC_A1]), d, cb[MC_A0]), 0.);
-    const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
-    const double aZ = fabs(Z);
     const double Rt = fast_sqrt_pos(R2 + cb[MC_RS_THIN2]);      // (Rs^2, rq^2 > 0: fill_post_params)
     const double Rk = one_rs ? Rt : fast_sqrt_pos(R2 + cb[MC_RS_THICK2]);
-    const double T0 = fast_exp_fin(cb[MC_C0T] - fma(Rt, cb[MC_IRT], aZ * cb[MC_IZT]), tbl);
-    const double T1 = fast_exp_fin(cb[MC_C0K] - fma(Rk, cb[MC_IRK], aZ * cb[MC_IZK]), tbl);
+    T0 = fast_exp_fin(cb[MC_C0T] - fma(Rt, cb[MC_IRT], aZ * cb[MC_IZT]), tbl);
+    T1 = fast_exp_fin(cb[MC_C0K] - fma(Rk, cb[MC_IRK], aZ * cb[MC_IZK]), tbl);
     const double q = cb[MC_QINF] -
                      cb[MC_DQE] * fast_exp_fin(-(fast_sqrt_pos(fma(Z, Z, R2) + cb[MC_RQ2]) * cb[MC_IRQ]), tbl);
     const double zq = Z * fast_rcp(q);
@@ -682,7 +669,11 @@ __device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const
         CPtr c;
         __device__ __forceinline__ double operator[](int k) const { return c[MC_B1 + k]; }
     };
-    const double T2 = halo_pow(HB{cb}, fma(zq, zq, R2) + cb[MC_RS_HALO2], ht);
+    T2 = halo_pow(HB{cb}, fma(zq, zq, R2) + cb[MC_RS_HALO2], ht);
+}
+// volume factor x mixture of the components with the record's label weights (gal_prior_lin's tail)
+__device__ __forceinline__ double mc_mix(const PostParams &pp, double d, double T0, double T1, double T2,
+                                         const double (&EF)[3], const double (&EA)[3]) {
     double num = d * d + 1e-300;                    // volume factor (pdf.py:626)
     if (pp.has_feh) num *= T0 * EF[0] + T1 * EF[1] + T2 * EF[2];
     if (pp.has_loga) num *= T0 * EA[0] + T1 * EA[1] + T2 * EA[2];
@@ -690,7 +681,203 @@ __device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const
     const int npow = (pp.has_feh ? 1 : 0) + (pp.has_loga ? 1 : 0);
     if (npow == 2) num *= fast_rcp(S);
     else if (npow == 0) num *= S;
-    lin = num;
+    return num;
+}
+
+// ---- sightline table -------------------------------------------------------------------
+// T0, T1, T2 depend on the sample only through its distance, and the samples of one work item
+// (object, chunk) all lie on one sightline: the item's workgroup tabulates the three functions
+// once, in LDS, and a sample evaluates three degree-7 polynomials (21 fused multiply-adds, 12
+// 16-byte LDS reads) in place of three square roots, three exponentials, a reciprocal and the
+// halo's power law (~100 float64 operations).
+//   * abscissa: s = 1 / d^2, the quantity a sample is drawn in -- the interval of a sample is
+//     bits 62..48 of s (exponent and four mantissa bits: SL_K = 16 equal intervals per octave of
+//     s), the position t in [-1, 1) inside it is the rest of the mantissa: no logarithm, no
+//     division, exact;
+//   * window: the SL_NI = 144 intervals (nine octaves of s, a factor 22.6 in distance) ending
+//     with the one that holds max(s0 + 4 sigma_s) over the item's records; a sample outside it
+//     takes the closed form (wave-divergent, rare);
+//   * fit: interpolation at the eight Chebyshev nodes of the interval, turned into monomial
+//     coefficients with the inverse Vandermonde matrix of tools/gen_sl_vinv.py.  Mixture error
+//     <= 2e-12 relative over 32 sightlines x 2^-7 .. 2^8 kpc (tools/dev/sightline_fit.py; the
+//     GPU test bounds it on 10^6 distances against the closed form);
+//   * certified: interpolation at Chebyshev nodes errs most at t = 0, where the polynomial is its
+//     constant coefficient: the builder evaluates the closed form there once more and an interval
+//     where any COMPONENT is off by more than SL_TOL of itself (the disks far above the plane,
+//     where an interval spans several scale heights; a component of e^-50 still decides the label
+//     terms of a model whose age or metallicity the other components exclude) is left to the
+//     closed form together with every interval beyond it (`lo`);
+//   * |Z|: T0, T1 have a kink where the sightline crosses the plane Z = 0.  The (at most one)
+//     interval with the crossing holds two fits, each of the smooth continuation with the sign
+//     of Z fixed (row SL_NI for Z < 0); the sample picks by the sign of its own Z.
+#ifndef BRUTUS_SL_NOCT
+#define BRUTUS_SL_NOCT 9
+#endif
+constexpr int SL_K_LOG2 = 4, SL_NOCT = BRUTUS_SL_NOCT, SL_NI = SL_NOCT << SL_K_LOG2, SL_ROW = 3 * 8;
+#ifdef BRUTUS_NO_SIGHTLINE_TABLE          // (A/B builds: the closed form for every sample)
+constexpr bool SL_ON = false;
+#else
+constexpr bool SL_ON = true;
+#endif
+constexpr double SL_TOL = 2.5e-12;
+#include "sl_vinv.inc"
+static_assert(SL_NODES == 8, "degree-7 fits");
+struct SlTab {
+    const double2 *c;     // LDS: (SL_NI + 1) rows of SL_ROW doubles, function-major, t^0 .. t^7
+    int base, kink;       // bits 62..48 of s of the first interval; interval with the Z = 0 crossing or -1
+    int ni;               // intervals (row ni: the second fit of the crossing's interval)
+    int lo;               // intervals [lo, ni) are certified
+};
+// window of an item from the largest s its samples are expected at
+__device__ __forceinline__ int sl_window(double top, int ni) {
+    const int p = top > 0x1p-900 && top < 0x1p900 ? (__double2hiint(top) >> 16) : 0x3ff0;   // (else: around s = 1)
+    return p + 1 - ni;
+}
+// all threads of the workgroup; follow with __syncthreads().  `kink` is an LDS int set to -1
+// (and synchronised) by the caller.
+__device__ __forceinline__ void sl_build(CPtr cb, bool one_rs, const double *__restrict__ tbl,
+                                         const double *__restrict__ ht, int base, int ni,
+                                         double *__restrict__ sl, int *__restrict__ kink, int *__restrict__ lo) {
+    for (int i = threadIdx.x; i < ni; i += blockDim.x) {
+        const double s_lo = __hiloint2double((base + i) << 16, 0), s_hi = __hiloint2double((base + i + 1) << 16, 0);
+        const double h = 0.5 * (s_hi - s_lo), mid = s_lo + h;
+        double pa, da, pb, db;
+        fast_sqrt_rsqrt_pos(s_lo, pa, da);
+        fast_sqrt_rsqrt_pos(s_hi, pb, db);
+        const bool na = fma(da, cb[MC_UZ], cb[MC_O2]) < 0., nb = fma(db, cb[MC_UZ], cb[MC_O2]) < 0.;
+        const int nfit = na != nb ? 2 : 1;
+        if (nfit == 2) *kink = i;
+#pragma unroll 1
+        for (int f = 0; f < nfit; ++f) {
+            const double sg = nfit == 2 ? (f == 0 ? 1. : -1.) : (na ? -1. : 1.);
+            double *const row = sl + (f == 0 ? i : ni) * SL_ROW;
+#pragma unroll 1
+            for (int j = 0; j < SL_NODES; ++j) {
+                double par, d, T0, T1, T2;
+                fast_sqrt_rsqrt_pos(fma(h, kSlNode[j], mid), par, d);
+                const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
+                sightline_T(cb, one_rs, d, Z, sg * Z, tbl, ht, T0, T1, T2);
+                row[j] = T0;
+                row[8 + j] = T1;
+                row[16 + j] = T2;
+            }
+#pragma unroll 1
+            for (int fn = 0; fn < 3; ++fn) {
+                double v[SL_NODES], c[SL_NODES];
+#pragma unroll
+                for (int j = 0; j < SL_NODES; ++j) v[j] = row[fn * 8 + j];
+#pragma unroll
+                for (int m = 0; m < SL_NODES; ++m) {
+                    double a = 0.;
+#pragma unroll
+                    for (int j = 0; j < SL_NODES; ++j) a = fma(kSlVinv[m][j], v[j], a);
+                    c[m] = a;
+                }
+#pragma unroll
+                for (int m = 0; m < SL_NODES; ++m) row[fn * 8 + m] = c[m];
+            }
+            {
+                double par, d, T0, T1, T2;
+                fast_sqrt_rsqrt_pos(mid, par, d);
+                const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
+                sightline_T(cb, one_rs, d, Z, sg * Z, tbl, ht, T0, T1, T2);
+                const bool ok = fabs(row[0] - T0) <= fma(SL_TOL, T0, 1e-290) && fabs(row[8] - T1) <= fma(SL_TOL, T1, 1e-290) &&
+                                fabs(row[16] - T2) <= fma(SL_TOL, T2, 1e-290);
+                if (!ok) atomicMax(lo, i + 1);
+            }
+        }
+    }
+}
+__device__ __forceinline__ double sl_poly(const double2 *__restrict__ c, double t) {
+    const double2 c01 = c[0], c23 = c[1], c45 = c[2], c67 = c[3];
+    double p = fma(c67.y, t, c67.x);
+    p = fma(p, t, c45.y);
+    p = fma(p, t, c45.x);
+    p = fma(p, t, c23.y);
+    p = fma(p, t, c23.x);
+    p = fma(p, t, c01.y);
+    return fma(p, t, c01.x);
+}
+
+// LDS of a workgroup that keeps a sightline table, besides the rows themselves
+struct SlCtl {
+    double top[4];
+    int kink, lo;
+};
+// The table of one work item: records [a, b) of the list `rp` of the object whose selected
+// rows start at `row0`.  All threads of the workgroup (barriers inside).
+__device__ __forceinline__ SlTab sl_item(CPtr cb, bool one_rs, const double *__restrict__ tbl,
+                                         const double *__restrict__ ht, int ni, double2 *__restrict__ rows,
+                                         SlCtl *__restrict__ ctl, int64_t a, int64_t b, bool on,
+                                         const int32_t *__restrict__ rec_slot, int64_t row0, const RecPost &rp,
+                                         const double *__restrict__ sel_vals, int64_t cap) {
+    // window: the ni intervals ending with the one of max(s0 + 4 sigma_s) over the records (centring
+    // it on the records' mean octave instead made no difference: r05_sightline_table_ab.txt)
+    double top = 0.;
+    if (threadIdx.x == 0) ctl->kink = -1, ctl->lo = 0;
+    __syncthreads();
+    if (on)
+        for (int64_t o = a + threadIdx.x; o < b; o += blockDim.x)
+            top = fmax(top, fma(4., rp.chol[o], sel_vals[2 * cap + rec_slot[row0 + rp.src[o]]]));
+    top = wave_max(top);
+    if ((threadIdx.x & 63) == 0) ctl->top[threadIdx.x >> 6] = top;
+    __syncthreads();
+    SlTab sl;
+    sl.ni = ni;
+    sl.base = __builtin_amdgcn_readfirstlane(
+        sl_window(fmax(fmax(ctl->top[0], ctl->top[1]), fmax(ctl->top[2], ctl->top[3])), ni));
+    sl_build(cb, one_rs, tbl, ht, sl.base, ni, reinterpret_cast<double *>(rows), &ctl->kink, &ctl->lo);
+    __syncthreads();
+    sl.c = rows;
+    sl.kink = __builtin_amdgcn_readfirstlane(ctl->kink);
+    sl.lo = __builtin_amdgcn_readfirstlane(ctl->lo);
+    return sl;
+}
+
+// mc_sample_lin with the object's constants read through `cb` (StarGeom::mc, McC) and the
+// halo table: the form the two Monte Carlo kernels run when the table is valid.  Same
+// quantities; R^2 from the quadratic in d (rounding differs from x^2 + y^2 by ~1e-15
+// relative to R^2 + Rs^2), clamped at 0 against cancellation on a sightline through the
+// Galactic centre's axis.  With a sightline table (`sl`) the components come from it when the
+// sample lies inside its window (`tab` says so).
+template <bool SL = false>
+__device__ __forceinline__ void mc_sample_c(CPtr cb, const PostParams &pp, const StarGeom &g, bool has_par,
+                                            bool dust_on, bool one_rs, double z0, double z1, double z2,
+                                            double s0, double a0, double r0, const double (&L)[6],
+                                            const double (&EF)[3], const double (&EA)[3],
+                                            const double *__restrict__ tbl, const double *__restrict__ ht,
+                                            bool &inb, double &lin, double &epar, SlTab sl = SlTab{},
+                                            bool *tab = nullptr) {
+    const double s_mc = s0 + L[0] * z0;
+    const double a_mc = a0 + (L[1] * z0 + L[2] * z1);
+    const double r_mc = r0 + (L[3] * z0 + L[4] * z1 + L[5] * z2);
+    double par, d;
+    fast_sqrt_rsqrt_pos(s_mc, par, d);       // (s_mc <= 0: NaN, and the sample is out of bounds)
+    const double Z = fma(d, cb[MC_UZ], cb[MC_O2]);
+    double T0, T1, T2;
+    if constexpr (SL) {
+        const int hi = __double2hiint(s_mc), lo = __double2loint(s_mc);
+        const int idx = (hi >> 16) - sl.base;
+        const bool in = (unsigned)(idx - sl.lo) < (unsigned)(sl.ni - sl.lo);
+        if (tab) *tab = in;
+        if (in) {
+            const int row = (idx == sl.kink && Z < 0.) ? sl.ni : idx;
+            // mantissa bits 47..0 of s as a number in [2, 4), minus 3
+            const unsigned mh = (((unsigned)hi << SL_K_LOG2) | ((unsigned)lo >> (32 - SL_K_LOG2))) & 0x000fffffu;
+            const double t = __hiloint2double((int)(mh | 0x40000000u), (int)((unsigned)lo << SL_K_LOG2)) - 3.;
+            const double2 *const c = sl.c + row * (SL_ROW / 2);
+            T0 = sl_poly(c, t);
+            T1 = sl_poly(c + 4, t);
+            T2 = sl_poly(c + 8, t);
+        } else if (s_mc >= 1e-20) {
+            sightline_T(cb, one_rs, d, Z, fabs(Z), tbl, ht, T0, T1, T2);
+        } else {
+            T0 = T1 = T2 = 1.;               // (out of bounds: the value is not used)
+        }
+    } else {
+        sightline_T(cb, one_rs, d, Z, fabs(Z), tbl, ht, T0, T1, T2);
+    }
+    lin = mc_mix(pp, d, T0, T1, T2, EF, EA);
     epar = 0.;
     if (has_par) {
         const double dp = par - cb[MC_PAR];                     // pdf.py:166-173
@@ -772,6 +959,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
     __shared__ double2 s_zp[ZIG_N];
     __shared__ unsigned short s_pend[MC_PEND][TILE];
     __shared__ double s_halo[HALO_TBL];
+    __shared__ double2 s_sl[HT && SL_ON ? (SL_NI + 1) * (SL_ROW / 2) : 1];
+    __shared__ SlCtl s_ctl;
     stage_exp_table(s_tbl);
     stage_zig_pairs(s_zp);
     if constexpr (HT) stage_halo_table(pp, s_halo);
@@ -797,6 +986,10 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
         const uint64_t nb = zarr ? 0ull : nbase[s];
         const uint64_t seed = star_seed(pp, s);
         double mx = -INFINITY, cmin = -INFINITY;   // cmin holds -min(chi2)
+        SlTab sl{};
+        if constexpr (HT && SL_ON)
+            sl = sl_item(cb0, one_rs, s_tbl, ht, SL_NI, s_sl, &s_ctl, a, b, !flags[s], rec_slot, sel_off[s], rp,
+                         sel_vals, cap);
         if (!flags[s]) {
             for (int64_t o0 = a; o0 < b; o0 += TILE) {
                 const int64_t o = o0 + threadIdx.x;
@@ -868,8 +1061,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                             zn2 = zat(j2);
                         }
                         if constexpr (HT)
-                            mc_sample_c(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, z0, z1, z2, s0,
-                                        a0, r0, L, Fc, Ac, s_tbl, ht, inb, lin, epar);
+                            mc_sample_c<SL_ON>(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, z0, z1, z2,
+                                              s0, a0, r0, L, Fc, Ac, s_tbl, ht, inb, lin, epar, sl);
                         else
                             mc_sample_lin(pp, g, z0, z1, z2, s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb, lin,
                                           epar);
@@ -916,6 +1109,9 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
 // shuffle steps.  The lane-per-record form (k_post_mc with `zarr`) copies every run into
 // a lane-interleaved staging column first: 16-byte loads at a 1.2 KB stride, then the same
 // bytes written and read once more -- three times the HBM traffic of this kernel.
+// (No sightline table here: with the tiles of normals there is room for three octaves of s beside
+// three workgroups per CU -- no gain, most waves then run both forms -- and nine octaves at two
+// workgroups per CU cost 20 %: profiles/r05_sightline_table_ab.txt.)
 constexpr int MCA_R = 8, MCA_G = 8, MCA_NMC = 64;
 constexpr int MCA_U = 8;          // loads of the tile copy a lane keeps in flight
 
@@ -1452,6 +1648,51 @@ __global__ void k_debug_galprior_mc(PostParams pp, int n, const double *__restri
     else
         mc_sample_lin(pp, g, 0., 0., 0., s0, a0, r0, L, Fc, Ac, s_tbl, d_, a_, r_, inb, lin, epar);
     out[i] = inb ? pp.lnK + fast_log_r(lin) : nan("");
+}
+
+// ... and through the sightline table of the Monte Carlo kernels: every workgroup builds the table
+// for the window of ITS 256 distances (sl_window of the largest s among them) and evaluates them
+// like samples; used[i] = 1 where the table was used, 0 where the sample fell outside the window
+// and took the closed form
+__global__ void __launch_bounds__(TILE)
+k_debug_galprior_sl(PostParams pp, int n, const double *__restrict__ dist, const StarGeom *__restrict__ geom,
+                    const double *__restrict__ feh, const double *__restrict__ loga,
+                    double *__restrict__ out, int32_t *__restrict__ used) {
+    __shared__ double s_tbl[64];
+    __shared__ double s_halo[HALO_TBL];
+    __shared__ double2 s_sl[(SL_NI + 1) * (SL_ROW / 2)];
+    __shared__ double s_top[4];
+    __shared__ int s_kink, s_lo;
+    stage_exp_table(s_tbl);
+    stage_halo_table(pp, s_halo);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    const StarGeom g = geom[0];
+    const CPtr cb = (CPtr)(uintptr_t)geom[0].mc;
+    const bool one_rs = pp.Rs_thick2 == pp.Rs_thin2;
+    const double s0 = i < n ? 1. / (dist[i] * dist[i]) : 0.;
+    const double top = wave_max(s0);
+    if ((threadIdx.x & 63) == 0) s_top[threadIdx.x >> 6] = top;
+    if (threadIdx.x == 0) s_kink = -1, s_lo = 0;
+    __syncthreads();
+    SlTab sl;
+    sl.ni = SL_NI;
+    sl.base = __builtin_amdgcn_readfirstlane(sl_window(fmax(fmax(s_top[0], s_top[1]), fmax(s_top[2], s_top[3])), SL_NI));
+    sl_build(cb, one_rs, s_tbl, s_halo, sl.base, SL_NI, reinterpret_cast<double *>(s_sl), &s_kink, &s_lo);
+    __syncthreads();
+    sl.c = s_sl;
+    sl.kink = __builtin_amdgcn_readfirstlane(s_kink);
+    sl.lo = __builtin_amdgcn_readfirstlane(s_lo);
+    if (i >= n) return;
+    double Fc[3], Ac[3];
+    label_terms(pp, feh[i], loga[i], Fc, Ac, s_tbl);
+    const double L[6] = {0., 0., 0., 0., 0., 0.};
+    const double a0 = 0.5 * (pp.avlim[0] + pp.avlim[1]), r0 = 0.5 * (pp.rvlim[0] + pp.rvlim[1]);
+    double lin, epar;
+    bool inb, tab = false;
+    mc_sample_c<true>(mc_refresh(cb), pp, g, false, false, one_rs, 0., 0., 0., s0, a0, r0, L, Fc, Ac, s_tbl,
+                      s_halo, inb, lin, epar, sl, &tab);
+    out[i] = inb ? pp.lnK + fast_log_r(lin) : nan("");
+    used[i] = tab ? 1 : 0;
 }
 
 }  // namespace

@@ -40,6 +40,16 @@ int brutus_debug_galprior_mc(const brutus_post_params *params, int n,
                              const double *d_feh, const double *d_loga, double *d_out,
                              void *stream);
 
+/* ... and through the sightline table the Monte Carlo kernels tabulate per work item
+ * (post_kernels.hpp, "sightline table"): every 256 consecutive distances share one table whose
+ * window is set by the nearest of them; d_used[i] = 1 where the table served the distance, 0
+ * where it lay outside the window and the closed form was evaluated.  Fails with BRUTUS_EINVAL
+ * for parameters that do not admit the halo table.  Synchronises the stream. */
+int brutus_debug_galprior_sl(const brutus_post_params *params, int n,
+                             const double *d_dist, const double *d_coord,
+                             const double *d_feh, const double *d_loga, double *d_out,
+                             int32_t *d_used, void *stream);
+
 /* Measurement aid: brutus_fit_batch calls of this process so far and how many of them had to
  * be repeated by the host-driven driver (a star with more than eight magnitude sweeps, a flux
  * phase longer than the device-driven call's continuation rounds).  Needs no GPU. */

@@ -97,6 +97,76 @@ def test_device_galprior_matches_host():
                 assert _lnp_err(refk, out.cpu().numpy()) < 1e-12, (frame, coord, kw)
 
 
+def test_sightline_table_matches_closed_form():
+    """The per-item sightline table of the Monte Carlo kernels (post_kernels.hpp: degree-7 fits of
+    the three density components in s = 1 / d^2, sixteen intervals per octave) against the closed
+    form it replaces, on 10^6 distances per sightline: sorted distances (every workgroup's 256
+    distances inside its window: the table must serve all of them within 2 kpc), the neighbourhood of the
+    Z = 0 crossing where |Z| has its kink, and unsorted distances over six decades (most of them
+    outside the window of their workgroup: closed form)."""
+    import torch
+    from brutus_amd import _lib
+    from brutus_amd.galprior import _frame
+    L = _lib.lib()
+    rng = np.random.RandomState(11)
+    n = 1 << 20
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a, dtype=np.float64)).cuda()
+    feh, loga = rng.uniform(-3, 0.6, n), rng.uniform(7.5, 10.2, n)
+    tf, tl = t(feh), t(loga)
+
+    def both(d, coord):
+        td, tc = t(d), t(np.array(coord))
+        ref = torch.empty(n, dtype=torch.float64, device="cuda")
+        out = torch.empty(n, dtype=torch.float64, device="cuda")
+        used = torch.zeros(n, dtype=torch.int32, device="cuda")
+        _lib.check(L.brutus_debug_galprior_mc(_post_params(), n, td.data_ptr(), tc.data_ptr(), tf.data_ptr(),
+                                              tl.data_ptr(), ref.data_ptr(), None))
+        _lib.check(L.brutus_debug_galprior_sl(_post_params(), n, td.data_ptr(), tc.data_ptr(), tf.data_ptr(),
+                                              tl.data_ptr(), out.data_ptr(), used.data_ptr(), None))
+        torch.cuda.synchronize()
+        return ref.cpu().numpy(), out.cpu().numpy(), used.cpu().numpy().astype(bool)
+
+    def gap(ref, out):
+        # (-inf where the age prior excludes the model: in both or in neither)
+        fin = np.isfinite(ref)
+        assert np.array_equal(fin, np.isfinite(out)) and np.array_equal(ref[~fin], out[~fin]) and fin.any()
+        return float(np.max(np.abs(out[fin] - ref[fin])))
+
+    M, off = _frame("astropy", 8.2, 0.025)
+    worst = 0.
+    for coord in ((204.7, -19.2), (0., 90.), (0., -90.), (33., 2.), (0.02, -0.01), (0., -0.17), (180., -5.),
+                  (90., -30.)):
+        d = np.sort(10. ** rng.uniform(-2.5, 2.3, n))
+        ref, out, used = both(d, coord)
+        # (far above the plane an interval spans several scale heights of the disks: the builder
+        # certifies every fit against the closed form and leaves those intervals to it)
+        assert used[d < 2.].all() and used.mean() > 0.5, (coord, used.mean())
+        worst = max(worst, gap(ref, out))
+        # the crossing of the plane Z = 0, if this sightline has one: a million distances within
+        # +-2 % of it (one or two intervals of the table around the kink)
+        ell, b = np.deg2rad(coord)
+        uz = (M @ np.array([np.cos(b) * np.cos(ell), np.cos(b) * np.sin(ell), np.sin(b)]))[2]
+        if uz != 0. and -off[2] / uz > 1e-3:
+            dk = -off[2] / uz
+            ref, out, used = both(np.sort(dk * (1. + rng.uniform(-0.02, 0.02, n))), coord)
+            assert used.all() or dk > 2., coord
+            worst = max(worst, gap(ref, out))
+        # unsorted: the window of a workgroup covers a factor 22 below its nearest distance
+        ref, out, used = both(10. ** rng.uniform(-3, 3, n), coord)
+        assert 0.05 < used.mean() < 0.9, used.mean()
+        assert gap(ref[~used], out[~used]) < 1e-13, coord      # (the same closed form, inlined elsewhere)
+        worst = max(worst, gap(ref, out))
+    # |ln prior (table) - ln prior (closed form)|: every component within ~1e-11 of itself (SL_TOL at
+    # the point where the interpolation errs most), whatever the label weights make of them
+    assert worst < 1e-10, worst
+    # parameters that do not admit the halo table: refused (the kernels then run without either table)
+    td, tc = t(np.ones(n)), t(np.array((10., 10.)))
+    out = torch.empty(n, dtype=torch.float64, device="cuda")
+    used = torch.zeros(n, dtype=torch.int32, device="cuda")
+    assert L.brutus_debug_galprior_sl(_post_params(eta_halo=40.), n, td.data_ptr(), tc.data_ptr(), tf.data_ptr(),
+                                      tl.data_ptr(), out.data_ptr(), used.data_ptr(), None) != 0
+
+
 def _setup(nmodel=6000, nstar=9, seed=31):
     from brutus_amd import fitting, synth
     from oracle import brutus_oracle as O

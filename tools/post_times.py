@@ -23,6 +23,7 @@ def main():
     ap.add_argument("--config", type=int, default=2)
     ap.add_argument("--stars", type=int, default=64)
     ap.add_argument("--tag", default="")
+    ap.add_argument("--no-parallax", action="store_true")
     a = ap.parse_args()
     L = _lib.lib()
     models, labels, lmask = synth.make_mist_like_grid(750000, 12)
@@ -36,8 +37,8 @@ def main():
     def run(lo, hi):
         with tempfile.TemporaryDirectory() as tmp:
             bf.fit(st["flux"][lo:hi], st["err"][lo:hi], st["mask"][lo:hi], np.arange(hi - lo),
-                   os.path.join(tmp, "x"), parallax=st["parallax"][lo:hi],
-                   parallax_err=st["parallax_err"][lo:hi], data_coords=st["coords"][lo:hi],
+                   os.path.join(tmp, "x"), parallax=None if a.no_parallax else st["parallax"][lo:hi],
+                   parallax_err=None if a.no_parallax else st["parallax_err"][lo:hi], data_coords=st["coords"][lo:hi],
                    rstate=PhiloxRandomState(862), **kw)
 
     # count the records each stage sees: wrap the engine's post call
