@@ -592,7 +592,8 @@ def TIMER_OF(kernel):
     """The library's timer name (`kernels_ms`) a kernel runs under (brutus_kernels.hip, run_fit)."""
     k = kernel.split("<")[0]
     if k == "k_fflux":                              # k_fflux<NB, RVF, FIRST>: the continuation launches
-        return "k_fflux" if kernel.rstrip(">").endswith("true") else "k_fflux_cont"
+        # (the traffic table names the family without its template arguments: its bytes are the first launch's)
+        return "k_fflux" if "<" not in kernel or kernel.rstrip(">").endswith("true") else "k_fflux_cont"
     if k in ("k_pre32", "k_pre32s"):
         return "k_pre32"
     if k in ("k_top", "k_top1", "k_hot_list"):

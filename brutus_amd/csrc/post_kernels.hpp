@@ -924,6 +924,10 @@ __host__ __device__ inline int mc_npair_max(int nmc) { return (3 * nmc) / 2 + 2;
 // go to the lane's column of `zs` as one 16-byte store (lane-interleaved rows of
 // double2); afterwards the lane integrates, reading three normals per sample.
 constexpr int MC_PEND = 8;
+// > |z| of any normal of either stream: the ziggurat's tail returns R + xt with xt^2 < 2 yt <=
+// 2 x 53 ln 2, i.e. |z| < 4.04 + 8.58 = 12.62; numpy's polar method sqrt(-2 ln r2) <= 12.01 at the
+// smallest r2 = 2^-104 two 53-bit uniforms can form
+constexpr double MC_ZMAX = 13.;
 
 // Objects s0 .. s1 - 1 by falling number of kept records: the Monte Carlo kernels take the work
 // items (object, chunk) in this order, largest first, so that the items left for the end of the
@@ -999,15 +1003,49 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                 // pair q - p_lo goes to row q - p_lo of the slot as one 16-byte store
                 const uint64_t j_lo = nb + (uint64_t)(3 * n * (int64_t)pp.nmc);
                 const uint64_t p_lo = j_lo >> 1;
+                // The record: its mean (s0, a0, r0) and Cholesky factor L.  Of its three runs of
+                // normals, the integrand sees the second (z1) and the third (z2) only through the
+                // bounds on Av and Rv (and z1 through the dust prior): a_mc = a0 + L1 z0 + L2 z1,
+                // r_mc = r0 + L3 z0 + L4 z1 + L5 z2.  |z| < MC_ZMAX for every normal either stream can
+                // produce, so a record whose mean is MC_ZMAX sum|L| away from the limits is in bounds whatever
+                // the normals are: a wave whose records all are (an Rv pinned by its prior: every
+                // record; NOT one pinned by rvlim = (x, x): there a sample is in bounds only where
+                // L5 z2 rounds to nothing, as in the reference) skips the third run -- a third of the generator's work --, and the
+                // second too where Av is as safe.  Same sums, bit for bit.
+                int64_t i = 0, vs = 0;
+                double L[6] = {0., 0., 0., 0., 0., 0.}, s0 = 0., a0 = 0., r0 = 0.;
+                bool need1 = false, need2 = false;
+                if (live) {
+                    const int64_t r = sel_off[s] + rp.src[o];
+                    i = sel_idx[r];
+                    vs = rec_slot[r];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
+                    s0 = sel_vals[2 * cap + vs];
+                    a0 = sel_vals[3 * cap + vs];
+                    r0 = sel_vals[4 * cap + vs];
+                    const double mr = MC_ZMAX * (fabs(L[3]) + fabs(L[4]) + fabs(L[5])),
+                                 ma = MC_ZMAX * (fabs(L[1]) + fabs(L[2]));
+                    // (NaN anywhere: not safe)
+                    const bool rv_safe = r0 - mr >= pp.rvlim[0] && r0 + mr <= pp.rvlim[1];
+                    const bool av_safe = a0 - ma >= pp.avlim[0] && a0 + ma <= pp.avlim[1];
+                    need2 = !rv_safe;
+                    need1 = need2 || !av_safe || g.dust_on;
+#ifdef BRUTUS_MC_NO_RUN_SKIP                  // (A/B builds: all three runs, always)
+                    need1 = need2 = true;
+#endif
+                }
+                const bool w2 = __any(need2), w1 = w2 || __any(need1);      // wave-uniform
+                const int nnorm = (w2 ? 3 : w1 ? 2 : 1) * pp.nmc;            // normals of the run in use
                 if (zsrc) {
                     // copy the record's run of the stream into the lane's staging column
                     // (the last pair may reach one normal past the object's slice: the
                     // buffer is padded, the value is never used)
-                    const uint64_t p_hi = (j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1;
+                    const uint64_t p_hi = (j_lo + (uint64_t)nnorm - 1) >> 1;
                     if (live)
                         for (uint64_t p = p_lo; p <= p_hi; ++p) col[(int64_t)(p - p_lo) * TILE] = zsrc[p];
                 } else {
-                    const int nrow = live ? (int)(((j_lo + (uint64_t)(3 * pp.nmc) - 1) >> 1) - p_lo) + 1 : 0;
+                    const int nrow = live ? (int)(((j_lo + (uint64_t)nnorm - 1) >> 1) - p_lo) + 1 : 0;
                     // both normals of row `row` by the full algorithm (slow path where needed)
                     auto redo = [&](int row) {
                         double z0, z1;
@@ -1031,14 +1069,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     while (npend > 0) redo((int)s_pend[--npend][threadIdx.x]);
                 }
                 if (live) {
-                    const int64_t r = sel_off[s] + rp.src[o];
-                    const int64_t i = sel_idx[r], vs = rec_slot[r];
-                    double Fc[3], Ac[3], L[6];
+                    double Fc[3], Ac[3];
                     label_terms(pp, pp.has_feh ? feh[i] : 0., pp.has_loga ? loga[i] : 0., Fc, Ac, s_tbl);
-#pragma unroll
-                    for (int k = 0; k < 6; ++k) L[k] = rp.chol[(int64_t)k * cap + o];
-                    const double s0 = sel_vals[2 * cap + vs], a0 = sel_vals[3 * cap + vs],
-                                 r0 = sel_vals[4 * cap + vs];
                     // sum_t lin_t e^{epar_t} over the in-bounds samples, with a
                     // running maximum M of epar only (lin needs none); branch-free
                     double M = -INFINITY, acc = 0.;
@@ -1047,7 +1079,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                     const int jb = (int)(j_lo & 1);
                     // (the normals of sample t + 1 are requested while sample t is integrated)
                     auto zat = [&](int jj) { return zc[(int64_t)(jj >> 1) * (2 * TILE) + (jj & 1)]; };
-                    double zn0 = zat(jb), zn1 = zat(jb + pp.nmc), zn2 = zat(jb + 2 * pp.nmc);
+                    // (a run that was not generated reads as zeros: in bounds, like the real ones)
+                    double zn0 = zat(jb), zn1 = w1 ? zat(jb + pp.nmc) : 0., zn2 = w2 ? zat(jb + 2 * pp.nmc) : 0.;
                     for (int t = 0; t < pp.nmc; ++t) {
                         double d_, a_, r_, lin, epar;
                         bool inb;
@@ -1057,8 +1090,8 @@ k_post_mc(PostParams pp, int64_t cap, int item_base, int nitem, unsigned int *__
                             const int tn = t + 1 < pp.nmc ? t + 1 : t;
                             const int j0 = jb + tn, j1 = j0 + pp.nmc, j2 = j1 + pp.nmc;
                             zn0 = zat(j0);
-                            zn1 = zat(j1);
-                            zn2 = zat(j2);
+                            zn1 = w1 ? zat(j1) : 0.;
+                            zn2 = w2 ? zat(j2) : 0.;
                         }
                         if constexpr (HT)
                             mc_sample_c<SL_ON>(mc_refresh(cb0), pp, g, g.has_par, g.dust_on, one_rs, z0, z1, z2,

@@ -217,6 +217,32 @@ def test_device_lnpost_shared_stream_vs_oracle():
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
 
 
+@pytest.mark.parametrize("lims", [dict(rvlim=(3.32, 3.32), rv_gauss=(3.32, 1e-6)),
+                                  dict(rvlim=(3.32, 3.32), rv_gauss=(3.32, 1e-6), avlim=(-30., 50.))])
+def test_device_lnpost_unseen_normal_runs_vs_oracle(lims):
+    """k_post_mc generates only the runs of normals the integrand can see: with Rv pinned every
+    record is in the Rv bounds whatever its normals are (third run skipped), with Av limits far
+    from every record's Av as well (second run skipped too).  Same stream positions, same sums:
+    the oracle draws all three runs."""
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup()
+    BF.batch_size = 4
+    rs = PhiloxRandomState(31)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60,
+                       rstate=rs, **lims))
+    ro = PhiloxRandomState(31)
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60, **lims)
+        _compare(dev[i], ref, (sorted(lims), i))
+    assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
 def _steep_halo_hook():
     """The built-in prior with a halo too steep for the table form of its power law (the
     library must run the plain form: `k_post_mc<false>` / `k_post_mc_arr<false>`)."""
