@@ -243,6 +243,26 @@ def test_device_lnpost_unseen_normal_runs_vs_oracle(lims):
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
 
 
+def test_randomised_fits_vs_oracle():
+    """Thirty random cases of tools/fuzz_lnpost.py (grid size, bands, stars, S/N, parallaxes, masks,
+    Nmc_prior 7 - 70, Ndraws, Av / Rv limits and priors incl. the ones that let k_post_mc skip runs
+    of normals, counter-based and numpy streams): `_fit` against the oracle with the same stream.
+    (675 cases of nine other seeds ran clean in round 5: profiles/r05_fuzz.txt.)"""
+    import os
+    import sys
+    tools = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools")
+    if tools not in sys.path:
+        sys.path.insert(0, tools)
+    import fuzz_lnpost as F
+    rng = np.random.RandomState(21)
+    for c in range(30):
+        models, labels, lmask, st, kw, stream, desc = F.case(rng)
+        try:
+            F.check(models, labels, lmask, st, kw, stream, 500 + c)
+        except AssertionError as e:
+            raise AssertionError("case %d %s: %s" % (c, desc, e))
+
+
 def _steep_halo_hook():
     """The built-in prior with a halo too steep for the table form of its power law (the
     library must run the plain form: `k_post_mc<false>` / `k_post_mc_arr<false>`)."""
