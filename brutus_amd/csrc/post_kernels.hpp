@@ -720,6 +720,10 @@ constexpr bool SL_ON = false;
 constexpr bool SL_ON = true;
 #endif
 constexpr double SL_TOL = 2.5e-12;
+#ifndef BRUTUS_SL_MIN_REC
+#define BRUTUS_SL_MIN_REC 256
+#endif
+constexpr int SL_MIN_REC = BRUTUS_SL_MIN_REC;    // records of a work item from which it gets a table
 #include "sl_vinv.inc"
 static_assert(SL_NODES == 8, "degree-7 fits");
 struct SlTab {
@@ -811,6 +815,16 @@ __device__ __forceinline__ SlTab sl_item(CPtr cb, bool one_rs, const double *__r
                                          SlCtl *__restrict__ ctl, int64_t a, int64_t b, bool on,
                                          const int32_t *__restrict__ rec_slot, int64_t row0, const RecPost &rp,
                                          const double *__restrict__ sel_vals, int64_t cap) {
+    // (building the table costs about what 50 records' samples save: a short item -- sharp
+    // posteriors keep ~10^3 models per object, 15 per item -- goes without, uniformly for the workgroup)
+    if (b - a < SL_MIN_REC) {
+        SlTab none;
+        none.c = rows;
+        none.base = 0;
+        none.kink = -1;
+        none.ni = none.lo = 0;
+        return none;
+    }
     // window: the ni intervals ending with the one of max(s0 + 4 sigma_s) over the records (centring
     // it on the records' mean octave instead made no difference: r05_sightline_table_ab.txt)
     double top = 0.;
