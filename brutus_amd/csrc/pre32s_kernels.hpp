@@ -89,7 +89,11 @@ __global__ void __launch_bounds__(PS_TILE, 3)
 k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
          const int32_t *__restrict__ star_ids, const Star32 *__restrict__ stars, P32 p,
          float *__restrict__ lnlp32, float *__restrict__ lnpr32, float *__restrict__ part) {
-    constexpr int ROW = ps_row(NB);
+    // (general rows carry r0^2, r0 dr, dr^2 behind the rest: the five sums without y then cost one
+    // fma per band each -- 11 instead of 13 operations per band and pair, k_pre32s<12, general>
+    // 1.33 -> 1.24 ms with its re-run; occupancy is not what limits this kernel: two workgroups
+    // per CU instead of three cost the pinned form 12 %, the general one 3 %)
+    constexpr int ROW = RVF ? ps_row(NB) : ps_row(NB) + 3 * NB;
     constexpr int NBG = NB / 4;                   // bands per staging lane
     constexpr int NF = 3;                         // per-band fields of a row
     __shared__ float s_t[4][2][PS_M][PS_STRIDE];
@@ -169,6 +173,9 @@ k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int
                 } else {
                     rw[NB + j] = cr0[k];
                     rw[2 * NB + j] = cdr[k];
+                    rw[NF * NB + 4 + j] = cr0[k] * cr0[k];
+                    rw[NF * NB + 4 + NB + j] = cr0[k] * cdr[k];
+                    rw[NF * NB + 4 + 2 * NB + j] = cdr[k] * cdr[k];
                 }
             }
             if (bg == 0) rw[NF * NB] = C10 * mbar;
@@ -218,18 +225,26 @@ k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int
             } else {
                 float ua = 0.f, ub = 0.f, uy = 0.f, aa = 0.f, ab = 0.f, bb = 0.f, ay = 0.f, by = 0.f, yy = 0.f;
 #pragma unroll
-                for (int j = 0; j < NB; ++j) {
-                    const float y = gcC[j] - mcC[j];
-                    const float aw = A[j] * w[j], bw = B[j] * w[j], yw = y * w[j];
-                    ua += aw;
-                    ub += bw;
-                    uy += yw;
-                    aa = fmaf(A[j], aw, aa);
-                    ab = fmaf(A[j], bw, ab);
-                    bb = fmaf(B[j], bw, bb);
-                    ay = fmaf(A[j], yw, ay);
-                    by = fmaf(B[j], yw, by);
-                    yy = fmaf(y, yw, yy);
+                for (int k = 0; k < NB / 4; ++k) {
+                    const float4 pa = r4[(NF * NB + 4) / 4 + k], pc = r4[(NF * NB + 4 + NB) / 4 + k],
+                                 pb = r4[(NF * NB + 4 + 2 * NB) / 4 + k];
+                    const float A2[4] = {pa.x, pa.y, pa.z, pa.w}, AB[4] = {pc.x, pc.y, pc.z, pc.w},
+                                B2[4] = {pb.x, pb.y, pb.z, pb.w};
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int j = 4 * k + q;
+                        const float y = gcC[j] - mcC[j];
+                        const float yw = y * w[j];
+                        ua = fmaf(A[j], w[j], ua);
+                        ub = fmaf(B[j], w[j], ub);
+                        aa = fmaf(A2[q], w[j], aa);
+                        ab = fmaf(AB[q], w[j], ab);
+                        bb = fmaf(B2[q], w[j], bb);
+                        uy += yw;
+                        ay = fmaf(A[j], yw, ay);
+                        by = fmaf(B[j], yw, by);
+                        yy = fmaf(y, yw, yy);
+                    }
                 }
                 // one sweep of fitting.py:176-243 with av -> c av: the Av half as above; in the
                 // Rv half every product av x (a y-free sum) carries one c and every product
