@@ -358,6 +358,8 @@ k_pre32s(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int
             const int64_t base = s_base[ss];
 #ifndef PS_DIAG_NOSTORE
             if (sm < nm && base >= 0) {
+                // (plain stores: two tiles of this wave complete a 128-byte line in the L2; as
+                // non-temporal 64-byte pieces the pass ran 2-3 % slower, its readers 0.02 ms faster)
                 lnlp32[base + ib + sm] = a;
                 lnpr32[base + ib + sm] = b;
             }
