@@ -30,6 +30,9 @@ okw = {k: kw[k] for k in kw}
 lnl, Ndim, chi2, sc, av, rv, icov = c_oracle.loglike(st["flux"][star], st["err"][star], st["mask"][star], models,
                                                      parallax=par[star], parallax_err=perr[star], trace=tr, **okw)
 rec = recs[star]
+if model < 0:       # the selected model where the two device pipelines differ most in Av
+    model = int(rec["sel"][int(np.argmax(np.abs(full["av"][star][rec["sel"]] - rec["av"])))])
+    print("model", model)
 pos = int(np.where(rec["sel"] == model)[0][0])
 print("K1 hot %d full %d C %d   K2 hot %d full %d C %d" % (rec["K1"], full["k1"][star], tr["K1"], rec["K2"], full["k2"][star], tr["K2"]))
 for k, cv in (("lnl", lnl), ("chi2", chi2), ("scale", sc), ("av", av), ("rv", rv)):
