@@ -11,6 +11,53 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+LINE_KEYS = {
+    "metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+    "scaling", "vs_baseline", "dtype", "data", "config", "ranks_seen", "statistic", "repeats",
+    "value_min", "value_max", "repeat_s", "per_rank_s", "timed_region_s", "parity", "roofline",
+    "survey8d_value", "survey8d_frac", "survey8d_grid", "other_config", "sharp_posterior",
+    "fit_end_to_end", "cpu_baseline", "cluster_mode", "detail"}
+
+
+def _no_rate_above_peak_without_reuse(node, path=""):
+    """Every bytes-per-second figure anywhere in the record: at most the HBM peak, unless the
+    object it sits in says how (a `reuse` factor) and the key says it is not an HBM rate."""
+    if isinstance(node, dict):
+        for k, v in node.items():
+            if isinstance(v, (int, float)) and not isinstance(v, bool):
+                if k in ("achieved_gbs", "hbm_gbs", "hbm_gbs_after_reuse", "measured_stream_gbs") or (
+                        k == "achieved" and node.get("unit") == "GB/s"):
+                    assert v <= 8000., (path, k, v)
+                if k == "algorithmic_gbs_before_reuse":
+                    assert node.get("reuse", 0.) > 1., (path, k)
+                if k == "frac" and node.get("unit") in ("GB/s", "TFLOP/s"):
+                    assert 0. <= v <= 1., (path, v)
+            else:
+                _no_rate_above_peak_without_reuse(v, path + "/" + k)
+    elif isinstance(node, list):
+        for i, v in enumerate(node):
+            _no_rate_above_peak_without_reuse(v, "%s[%d]" % (path, i))
+
+
+def test_compact_line_of_a_full_size_record_fits_the_driver():
+    """CPU: the line built from last round's full-size record (profiles/) is < 8 KB and has
+    exactly the key set the small-grid GPU run is held to."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    with open(os.path.join(ROOT, "profiles", "r05_v7_bench_default.json")) as f:
+        full = json.load(f)
+    text = json.dumps(bench.compact_line(full), separators=(",", ":"))
+    assert len(text) < 8192 and "\n" not in text
+    d = json.loads(text)
+    assert set(d) == LINE_KEYS, sorted(set(d) ^ LINE_KEYS)
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in d["roofline"]
+    for k in ("value", "unit", "cores", "kind", "sample"):
+        assert k in d["cpu_baseline"]
+
+
 @pytest.mark.gpu
 def test_bench_line_contract_small_grid():
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--nmodel", "60000", "--steps", "3",
@@ -20,7 +67,21 @@ def test_bench_line_contract_small_grid():
     assert out.returncode == 0, out.stderr.decode("utf-8", "replace")[-3000:]
     lines = [ln for ln in out.stdout.decode().splitlines() if ln.startswith("{")]
     assert len(lines) == 1
+    # the driver keeps an 8 KB tail of stdout and parses the last line: the line must fit
+    # (round 5's 24.8 KB line left BENCH_r05.json with parsed = null)
+    assert len(lines[0]) < 8192, len(lines[0])
+    assert out.stdout.decode().strip().splitlines()[-1] == lines[0]
     d = json.loads(lines[0])
+    # exactly the key set of the full-size run (bench.compact_line builds both)
+    assert set(d) == LINE_KEYS, sorted(set(d) ^ LINE_KEYS)
+    # ... and the per-kernel tables are in the detail file beside bench.py
+    with open(os.path.join(ROOT, d["detail"])) as f:
+        full = json.load(f)
+    assert full["value"] == pytest.approx(d["value"], rel=1e-5)
+    assert "kernels" in full["roofline"] and "kernels" in full["other_config"]["roofline"]
+    _no_rate_above_peak_without_reuse(d)
+    _no_rate_above_peak_without_reuse(full)
+    assert d["survey8d_frac"] == d["survey8d_grid"]["frac"]
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step",
               "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config", "roofline",
               "cpu_baseline", "repeats", "value_min", "value_max", "repeat_s", "per_rank_s", "parity"):
@@ -52,10 +113,7 @@ def test_bench_line_contract_small_grid():
     assert sp["value"] > 0 and sp["selected_fraction"] < 0.2, sp["selected_fraction"]
     assert sp["parity"]["sel_equal"] and sp["parity"]["k1_k2_equal"] and sp["parity"]["max_rel"] < 1e-8
     assert sp["fit_end_to_end"]["value"] > 0
-    # no kernel claims more bytes per second than the memory has without saying how
-    for name, k in rl["kernels"].items():
-        if k.get("achieved_gbs", 0.) > 8000. and k.get("traffic"):
-            assert k["reuse"] > 1., name
+    assert sp["bound"].startswith("vector issue") and "frac" not in sp
 
 
 @pytest.mark.gpu
