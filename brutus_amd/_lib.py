@@ -63,7 +63,7 @@ class PostParams(C.Structure):
 
 # name -> (restype, argtypes); mirrors include/brutus_amd.h (product ABI) and
 # include/brutus_amd_debug.h (test hooks / measurement aids, see DEBUG_NAMES) one to one
-DEBUG_NAMES = ("brutus_calibrate_traffic", "brutus_calibrate_copy16", "brutus_calibrate_issue", "brutus_debug_exp10", "brutus_debug_math", "brutus_debug_mt_stream", "brutus_debug_rng", "brutus_debug_galprior", "brutus_debug_galprior_mc", "brutus_debug_galprior_sl", "brutus_debug_zig_table", "brutus_debug_copy", "brutus_debug_sizeof_star32", "brutus_debug_fit_stats")
+DEBUG_NAMES = ("brutus_calibrate_traffic", "brutus_calibrate_copy16", "brutus_calibrate_issue", "brutus_debug_exp10", "brutus_debug_math", "brutus_debug_mt_stream", "brutus_debug_rng", "brutus_debug_galprior", "brutus_debug_galprior_mc", "brutus_debug_galprior_sl", "brutus_debug_zig_table", "brutus_debug_copy", "brutus_debug_sizeof_star32", "brutus_debug_fit_stats", "brutus_debug_pre32_time")
 SIGNATURES = {
     "brutus_abi_version": (C.c_int, []),
     "brutus_last_error": (C.c_char_p, []),
@@ -111,6 +111,8 @@ SIGNATURES = {
                                            _vp, _vp, _vp]),
     "brutus_debug_copy": (C.c_int, [_vp, _sz, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "brutus_debug_sizeof_star32": (C.c_int, []),
+    "brutus_debug_pre32_time": (C.c_int, [_vp, _sz, _vp, _i64, _i32, _i32, C.POINTER(Params), _i32, _i32,
+                                          C.POINTER(C.c_float), _vp]),
     "brutus_cluster_points": (C.c_int, [_i64, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "brutus_cluster_points_grid": (C.c_int, [_i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
     "brutus_offsets_weights": (C.c_int, [_i32, _i32, _i32, _i64] + [_vp] * 12 + [_i32, _vp, _vp, _vp]),

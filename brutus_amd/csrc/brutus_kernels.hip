@@ -387,6 +387,7 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
 }
 
 // ---- hot path host orchestration (brutus_fit_batch) ----------------------------------
+thread_local int t_audit_call = 0;        // dispatch_fit: this call's float32 bound is audited and enforced
 constexpr int BRUTUS_RETRY_HOSTDRIVEN = -1000;     // internal: never leaves dispatch_fit
 std::atomic<long long> g_fit_calls{0}, g_fit_retries{0};     // device-driven calls / repeated host-driven
 constexpr int FS_TILES_PER_BLOCK = 8;
@@ -522,13 +523,21 @@ int launch_pre32(const float *grid, int64_t nmodel, int nfilt, int nstar,
     // Long star lists take the star-lane pass (pre32s_kernels.hpp: lane = star, the models' rows
     // broadcast from LDS); short ones -- the re-run over a handful of stars, lists with other
     // sweep counts than the opening pass's two -- the tile pass.
-    bool lanes_are_stars = brutus_i_pre32s_bands(NB) && mode != 2 && nrun >= 32 &&
+    // (development / test switches, read per call: the tests flip them inside one process)
+    const int use_mfma = env_int("BRUTUS_PRE32_MFMA", 0);     // (measured, not the default: pre32m_kernels.hpp)
+    const int min_stars = env_int("BRUTUS_PRE32_STAR_LANES_MIN", 32);
+    bool lanes_are_stars = brutus_i_pre32s_bands(NB) && mode != 2 && nrun >= min_stars &&
                            env_int("BRUTUS_PRE32_STAR_LANES", 1) != 0;
+    // (two translation units, one definition of the shared layout: pre32_types.hpp)
+    if (brutus_i_pre32_layout(0) != (int)sizeof(Star32) || brutus_i_pre32_layout(1) != (int)sizeof(P32) ||
+        brutus_i_pre32_layout(2) != F2_T || brutus_i_pre32_layout(3) != TILE || brutus_i_pre32_layout(4) != NV32)
+        return fail(BRUTUS_EINVAL, "float32 pass: the library's translation units disagree on the Star32 / "
+                                   "tile layout (built with different flags?)");
     if (lanes_are_stars && !RVF)
         for (int k = 0; k < nrun && lanes_are_stars; ++k) lanes_are_stars = kfix[ids[k]] == 2;
     if (lanes_are_stars) {
         tm.begin("k_pre32");
-        if (brutus_i_pre32s_launch(NB, RVF ? 1 : 0, grid, nmodel, nmodel_pad, nstar, nrun, list, w.s32, &q,
+        if (brutus_i_pre32s_launch(NB, use_mfma, RVF ? 1 : 0, grid, nmodel, nmodel_pad, nstar, nrun, list, w.s32, &q,
                                    w.lnlp32, w.lnpr32, w.part32, st))
             return fail(BRUTUS_EHIP, "star-lane float32 pass: launch failed");
         tm.end();
@@ -562,7 +571,10 @@ int run_fit(const float *grid, int64_t nmodel, int nfilt, int nstar, const DevPa
     const RecPlanes rec{d_rec_vals, capacity};
     std::vector<int32_t> ids(nstar), kfix(nstar, 2), k1(nstar, 0), status(nstar, 0);
     for (int s = 0; s < nstar; ++s) ids[s] = s;
-    const int audit_on = env_int("BRUTUS_AUDIT", 0);
+    // the run-time audit of the float32 bound: every call with BRUTUS_AUDIT=1 (recorded for the
+    // caller to read: tests, tools/fuzz_fit.py), and ENFORCED on the calls dispatch_fit picks
+    // (the first of the process and every BRUTUS_AUDIT_EVERY-th after it, audit_verdict below)
+    const int audit_on = env_int("BRUTUS_AUDIT", 0) != 0 || t_audit_call;
     float *aud = audit_on ? w.aud : nullptr;
     if (aud) HIP_TRY(hipMemsetAsync(w.aud, 0, sizeof(float) * nstar * 4, st));
     h_counts[0] = h_counts[1] = h_counts[2] = 0;
@@ -1190,6 +1202,28 @@ int mt_walk(int nstream, const std::vector<int32_t> &seg, uint32_t *d_states, st
 // specialisation computes the same thing
 inline bool rv_pinned(const DevParams &p) { return p.rvmin == p.rvmax && p.rv_mean == p.rvmin; }
 
+// The float32 pass only classifies, and what it "proves" below a threshold never reaches the
+// output: Star32::eps has to bound |float32 - float64| for that to be sound.  Every pair the call
+// re-evaluates in float64 anyway (the nominees of both exact maxima, the pairs inside the
+// first-cut band) is compared with its float32 value on an audited call; one at or above eps
+// fails the call -- loudly, instead of a model silently missing from a posterior.
+int audit_verdict(const Workspace &w, int nstar, hipStream_t st) {
+    std::vector<float> aud(4 * (size_t)nstar);
+    std::vector<Star32> s32(nstar);
+    HIP_TRY(hipMemcpyAsync(aud.data(), w.aud, sizeof(float) * aud.size(), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipMemcpyAsync(s32.data(), w.s32, sizeof(Star32) * (size_t)nstar, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    static const char *what[3] = {"cull statistic", "first-cut statistic (maximum)", "first-cut statistic (band)"};
+    for (int r = 0; r < 3; ++r)
+        for (int s = 0; s < nstar; ++s)
+            if (!(aud[(size_t)r * nstar + s] < s32[s].eps))
+                return fail(BRUTUS_EPRECISION,
+                            "float32 proof bound violated: star %d of the batch, %s: |float32 - float64| = %.3g "
+                            "against eps = %.3g (BRUTUS_EPS_SCALE raises the bound; please report the input)",
+                            s, what[r], (double)aud[(size_t)r * nstar + s], (double)s32[s].eps);
+    return 0;
+}
+
 int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar,
                  const DevParams &p, int max_iter, Workspace &w, int64_t capacity,
                  int32_t *d_rec_idx, int32_t *d_rec_slot, double *d_rec_vals, int64_t *d_rec_off,
@@ -1198,10 +1232,14 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
     // BRUTUS_FIT_HOSTDRIVEN=1: round 3's driver for every batch (A/B timing, and the tests
     // that compare the two drivers record for record)
     const bool hostdriven = env_int("BRUTUS_FIT_HOSTDRIVEN", 0) != 0;
+    {
+        const long long call_no = g_fit_calls.fetch_add(1);
+        const int every = env_int("BRUTUS_AUDIT_EVERY", 256);
+        t_audit_call = every > 0 && call_no % every == 0;
+    }
 #define BRUTUS_CASE(N)                                                                             \
     case N: {                                                                                      \
         int rc = hostdriven ? BRUTUS_RETRY_HOSTDRIVEN : 0;                                         \
-        g_fit_calls.fetch_add(1);                                                                  \
         if (!hostdriven)                                                                           \
             rc = rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,      \
                                         d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,  \
@@ -1209,14 +1247,18 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
                      : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,     \
                                          d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2, \
                                          h_counts, st, tm, true);                                  \
-        if (rc != BRUTUS_RETRY_HOSTDRIVEN) return rc;                                              \
-        if (!hostdriven) g_fit_retries.fetch_add(1);                                               \
-        return rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,        \
-                                      d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,    \
-                                      h_counts, st, tm, false)                                     \
-                   : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,       \
-                                       d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,   \
-                                       h_counts, st, tm, false);                                   \
+        if (rc == BRUTUS_RETRY_HOSTDRIVEN) {                                                       \
+            if (!hostdriven) g_fit_retries.fetch_add(1);                                           \
+            rc = rvf ? run_fit<N, true>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,      \
+                                        d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2,  \
+                                        h_counts, st, tm, false)                                   \
+                     : run_fit<N, false>(grid, nmodel, nfilt, nstar, p, max_iter, w, capacity,     \
+                                         d_rec_idx, d_rec_slot, d_rec_vals, d_rec_off, h_k1, h_k2, \
+                                         h_counts, st, tm, false);                                 \
+        }                                                                                          \
+        if (rc == 0 && t_audit_call) rc = audit_verdict(w, nstar, st);                             \
+        t_audit_call = 0;                                                                          \
+        return rc;                                                                                 \
     }
     switch (nb) {
         BRUTUS_CASE(12)
@@ -2380,6 +2422,46 @@ int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
 }
 
 int brutus_debug_sizeof_star32(void) { return (int)sizeof(Star32); }
+
+int brutus_debug_pre32_time(void *d_workspace, size_t workspace_bytes, const float *d_grid_soa,
+                            int64_t nmodel, int nfilt, int nstar, const brutus_params *params,
+                            int form, int reps, float *h_ms, void *stream) {
+    if (int rc = check_common(nmodel, nfilt, nstar)) return rc;
+    if (!d_workspace || !d_grid_soa || !h_ms || reps < 1) return fail(BRUTUS_EINVAL, "bad arguments");
+    DevParams p;
+    if (int rc = make_params(params, p)) return rc;
+    Workspace w = carve((char *)d_workspace, nmodel, nstar, true);
+    if (w.bytes > workspace_bytes) return fail(BRUTUS_ENOMEM, "workspace too small");
+    const int nb = brutus_padded_filters(nfilt);
+    if (!brutus_i_pre32s_bands(nb)) return fail(BRUTUS_EINVAL, "no star-lane pass for %d bands", nb);
+    const bool rvf = p.rvmin == p.rvmax && p.rvmin == p.rv_mean;
+    P32 q;
+    q.avmin = (float)p.avmin; q.avmax = (float)p.avmax; q.rvmin = (float)p.rvmin; q.rvmax = (float)p.rvmax;
+    q.av_mean = (float)p.av_mean; q.av_ivar = (float)p.av_ivar; q.rv_mean = (float)p.rv_mean;
+    q.rv_ivar = (float)p.rv_ivar;
+    q.mtol_hi = (float)(p.mtol * 1.002 + 1e-4);
+    q.mtol_lo = (float)(p.mtol * 0.998 - 1e-4);
+    q.dim_prior = p.dim_prior;
+    q.nfilt = nfilt;
+    hipStream_t st = (hipStream_t)stream;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    for (int k = 0; k < reps + 1; ++k) {
+        if (k == 1) HIP_TRY(hipEventRecord(a, st));
+        if (brutus_i_pre32s_launch(nb, form, rvf ? 1 : 0, d_grid_soa, nmodel, pad_models(nmodel), nstar, nstar,
+                                   w.ids_all, w.s32, &q, w.lnlp32, w.lnpr32, w.part32, st))
+            return fail(BRUTUS_EHIP, "star-lane float32 pass: launch failed");
+    }
+    HIP_TRY(hipEventRecord(b, st));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    *h_ms = ms / reps;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return 0;
+}
 
 void brutus_enable_timing(int on) { g_timing = on != 0; }
 

@@ -48,6 +48,10 @@
 
 namespace {
 
+// pre32_types.hpp names the tile geometry on its own (it is also compiled into pre32s_unit.hip,
+// which does not see common.hpp): one definition in effect
+static_assert(PS_TILE == TILE && PS_NBMAX == NBMAX, "pre32_types.hpp and common.hpp disagree");
+
 // ---------------------------------------------------------------------------
 // per-star float32 companion of StarPrep
 // ---------------------------------------------------------------------------

@@ -46,7 +46,10 @@ struct P32 {
 // count (8 or 12; brutus_pre32s_bands says which are built), rvf: Rv pinned.  Returns 0, or -1
 // for a band count that is not built.  Not part of the C ABI (hidden visibility).
 extern "C" __attribute__((visibility("hidden"))) int brutus_i_pre32s_bands(int nb);
+extern "C" __attribute__((visibility("hidden"))) int brutus_i_pre32_layout(int what);
+// mfma: 1 = k_pre32m (pre32m_kernels.hpp: the band contractions on the matrix pipe, 16 stars per
+// wave), 0 = k_pre32s (all-vector, 64 stars per wave)
 extern "C" __attribute__((visibility("hidden"))) int brutus_i_pre32s_launch(
-    int nb, int rvf, const float *grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+    int nb, int mfma, int rvf, const float *grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
     const int32_t *star_ids, const void *stars32, const void *p32, float *lnlp32, float *lnpr32,
     float *part32, void *stream);

@@ -14,15 +14,39 @@
 #include <stdint.h>
 
 #include "pre32s_kernels.hpp"
+#include "pre32m_kernels.hpp"
 
 namespace {
 
 template <int NB>
-int launch_nb(int rvf, const float *grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
+int launch_nb(int mfma, int rvf, const float *grid, int64_t nmodel, int64_t nmodel_pad, int nstar, int nrun,
               const int32_t *star_ids, const Star32 *stars, const P32 &p, float *lnlp32,
               float *lnpr32, float *part32, hipStream_t st) {
     const int ntile = (int)(nmodel_pad / PS_TILE);
     const int nblkx = (ntile + F2_T - 1) / F2_T;
+#ifdef BRUTUS_DEV_PRE32M_DIAG
+    if (mfma == 2) {
+        const dim3 gm(8 * ((nblkx + 7) / 8) * ((nrun + 15) / 16)), bm(PS_TILE);
+        if (rvf)
+            hipLaunchKernelGGL((k_pre32m<NB, true, 1>), gm, bm, 0, st, grid, nmodel, nmodel_pad, nblkx, nstar, nrun,
+                               star_ids, stars, p, lnlp32, lnpr32, part32);
+        else
+            hipLaunchKernelGGL((k_pre32m<NB, false, 1>), gm, bm, 0, st, grid, nmodel, nmodel_pad, nblkx, nstar, nrun,
+                               star_ids, stars, p, lnlp32, lnpr32, part32);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
+#endif
+    if (mfma) {
+        // (k_pre32m: 16 stars per wave, the band contractions on the matrix pipe)
+        const dim3 gm(8 * ((nblkx + 7) / 8) * ((nrun + 15) / 16)), bm(PS_TILE);
+        if (rvf)
+            hipLaunchKernelGGL((k_pre32m<NB, true>), gm, bm, 0, st, grid, nmodel, nmodel_pad, nblkx, nstar, nrun,
+                               star_ids, stars, p, lnlp32, lnpr32, part32);
+        else
+            hipLaunchKernelGGL((k_pre32m<NB, false>), gm, bm, 0, st, grid, nmodel, nmodel_pad, nblkx, nstar, nrun,
+                               star_ids, stars, p, lnlp32, lnpr32, part32);
+        return hipGetLastError() == hipSuccess ? 0 : -2;
+    }
     const dim3 g(nblkx * ((nrun + 63) / 64)), b(PS_TILE);
     if (rvf)
         hipLaunchKernelGGL((k_pre32s<NB, true>), g, b, 0, st, grid, nmodel, nmodel_pad, nstar, nrun,
@@ -42,7 +66,19 @@ extern "C" int brutus_i_pre32s_bands(int nb) {
     return nb == 12 && ps_bands(12) ? 1 : 0;
 }
 
-extern "C" int brutus_i_pre32s_launch(int nb, int rvf, const float *grid, int64_t nmodel,
+extern "C" int brutus_i_pre32_layout(int what) {
+    // what the two translation units must agree on (pre32_types.hpp is compiled into both)
+    switch (what) {
+        case 0: return (int)sizeof(Star32);
+        case 1: return (int)sizeof(P32);
+        case 2: return F2_T;
+        case 3: return PS_TILE;
+        case 4: return NV32;
+        default: return -1;
+    }
+}
+
+extern "C" int brutus_i_pre32s_launch(int nb, int mfma, int rvf, const float *grid, int64_t nmodel,
                                       int64_t nmodel_pad, int nstar, int nrun,
                                       const int32_t *star_ids, const void *stars32,
                                       const void *p32, float *lnlp32, float *lnpr32,
@@ -52,9 +88,9 @@ extern "C" int brutus_i_pre32s_launch(int nb, int rvf, const float *grid, int64_
     hipStream_t st = (hipStream_t)stream;
     switch (nb) {
 #ifndef BRUTUS_DEV_NB12_ONLY
-        case 8: return launch_nb<8>(rvf, grid, nmodel, nmodel_pad, nstar, nrun, star_ids, stars, p, lnlp32, lnpr32, part32, st);
+        case 8: return launch_nb<8>(mfma, rvf, grid, nmodel, nmodel_pad, nstar, nrun, star_ids, stars, p, lnlp32, lnpr32, part32, st);
 #endif
-        case 12: return launch_nb<12>(rvf, grid, nmodel, nmodel_pad, nstar, nrun, star_ids, stars, p, lnlp32, lnpr32, part32, st);
+        case 12: return launch_nb<12>(mfma, rvf, grid, nmodel, nmodel_pad, nstar, nrun, star_ids, stars, p, lnlp32, lnpr32, part32, st);
         default: return -1;
     }
 }

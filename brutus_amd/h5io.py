@@ -99,6 +99,8 @@ def _lib():
         "H5free_memory": (herr_t, [C.c_void_p]),
         "H5Pcreate": (hid_t, [hid_t]),
         "H5Pset_obj_track_times": (herr_t, [hid_t, C.c_uint]),
+        "H5Pset_virtual": (herr_t, [hid_t, hid_t, C.c_char_p, C.c_char_p, hid_t]),
+        "H5Sselect_all": (herr_t, [hid_t]),
         "H5Pclose": (herr_t, [hid_t]),
         "H5Gopen2": (hid_t, [hid_t, C.c_char_p, hid_t]),
         "H5Gcreate2": (hid_t, [hid_t, C.c_char_p, hid_t, hid_t, hid_t]),
@@ -345,6 +347,25 @@ class _File(object):
         L.H5Sclose(msp)
         L.H5Sclose(fsp)
 
+    def read_rows(self, name, start, n):
+        """Rows [start, start + n) along axis 0 of a bound dataset."""
+        L = self.L
+        did, tid, _, shape, dt = self._dsets[name]
+        nd = len(shape)
+        out = np.empty((n,) + tuple(shape[1:]), dtype=dt)
+        if out.size == 0:
+            return out
+        fsp = L.H5Dget_space(did)
+        st = (hsize_t * nd)(*([start] + [0] * (nd - 1)))
+        cnt = (hsize_t * nd)(*([n] + list(shape[1:])))
+        _check(L.H5Sselect_hyperslab(fsp, H5S_SELECT_SET, st, None, cnt, None), "H5Sselect_hyperslab")
+        msp = L.H5Screate_simple(nd, cnt, None)
+        _check(L.H5Dread(did, tid, msp, fsp, H5P_DEFAULT, out.ctypes.data_as(C.c_void_p)),
+               "H5Dread rows " + name)
+        L.H5Sclose(msp)
+        L.H5Sclose(fsp)
+        return out
+
     def flush(self):
         self.L.H5Fflush(self.fid, 1)
 
@@ -416,6 +437,68 @@ def read_dataset(path, name):
         return out
     finally:
         f.close()
+
+
+def write_virtual_index(path, Ndata, Ndraws, save_dar_draws, data_labels, parts, overwrite=False):
+    """`{save_file}.h5` of a `fit_sharded(writer="per_rank")` run: the reference's datasets
+    (fitting.py:1635-1662) as HDF5 VIRTUAL datasets whose row range `[lo, hi)` maps onto the
+    dataset of the same name in part file `name` -- `parts` = [(lo, hi, file name relative to
+    the index)], together covering `[0, Ndata)`.  Nothing is copied: a reader (h5py,
+    `read_dataset`) opens this file and libhdf5 fetches the rows from the parts, which have to
+    stay beside it.  `labels` is small and written for real."""
+    L = _lib()
+    self = ResultsFile.__new__(ResultsFile)
+    self.Ndraws, self.save_dar_draws = Ndraws, save_dar_draws
+    layout = self._layout()
+    f = _File(path, "w" if overwrite else "w-")
+    try:
+        if data_labels is not None:
+            f.create_dataset("labels", np.asarray(data_labels))
+        for k, (rs, dt, fill, _) in layout.items():
+            shape = (Ndata,) + tuple(rs)
+            nd = len(shape)
+            dcpl = _check(L.H5Pcreate(hid_t.in_dll(L, "H5P_CLS_DATASET_CREATE_ID_g").value), "H5Pcreate")
+            L.H5Pset_obj_track_times(dcpl, 0)
+            vsp = _check(L.H5Screate_simple(nd, (hsize_t * nd)(*shape), None), "H5Screate_simple")
+            for lo, hi, name in parts:
+                st = (hsize_t * nd)(*([lo] + [0] * (nd - 1)))
+                cnt = (hsize_t * nd)(*([hi - lo] + list(shape[1:])))
+                _check(L.H5Sselect_hyperslab(vsp, H5S_SELECT_SET, st, None, cnt, None), "H5Sselect_hyperslab")
+                ssp = _check(L.H5Screate_simple(nd, cnt, None), "H5Screate_simple")
+                _check(L.H5Pset_virtual(dcpl, vsp, name.encode(), k.encode(), ssp), "H5Pset_virtual " + k)
+                L.H5Sclose(ssp)
+            L.H5Sselect_all(vsp)
+            tid, close = _h5type(np.dtype(dt))
+            did = _check(L.H5Dcreate2(f.fid, k.encode(), tid, vsp, H5P_DEFAULT, dcpl, H5P_DEFAULT),
+                         "H5Dcreate2 (virtual) " + k)
+            L.H5Dclose(did)
+            if close:
+                L.H5Tclose(tid)
+            L.H5Sclose(vsp)
+            L.H5Pclose(dcpl)
+    finally:
+        f.close()
+
+
+def materialize(index_path, out_path, block_rows=4096):
+    """Copy a results file -- in particular the virtual index of a per-rank run -- into ONE plain
+    HDF5 file with the same datasets (for moving a result without its part files)."""
+    src = _File(index_path, "r")
+    dst = _File(out_path, "w-")
+    try:
+        for k in list_datasets(index_path):
+            shape, _ = src.bind_dataset(k)
+            did, tid, _, _, dt = src._dsets[k]
+            if k == "labels" or len(shape) == 0:
+                dst.create_dataset(k, read_dataset(index_path, k))
+                continue
+            dst.create_filled(k, shape, dt, 0, block_rows=block_rows)
+            for a in range(0, shape[0], block_rows):
+                n = min(block_rows, shape[0] - a)
+                dst.write_rows(k, a, src.read_rows(k, a, n))
+    finally:
+        src.close()
+        dst.close()
 
 
 class ResultsFile(object):

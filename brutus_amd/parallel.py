@@ -87,7 +87,8 @@ def gather_rows(local_rows, dst=0):
 
 
 def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
-                seed0=0, rng="philox", chunk=256, rank0_share=1.0, queue_depth=4, **fit_kwargs):
+                seed0=0, rng="philox", chunk=256, rank0_share=1.0, queue_depth=4, writer="rank0",
+                **fit_kwargs):
     """`BruteForce.fit` over all ranks of the default process group.
 
     Every rank fits the contiguous shard `shard_bounds(Ndata, world, rank0_share)[rank]` on
@@ -138,7 +139,19 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     the completed file equals an uninterrupted run's, for any number of ranks before and
     after).  Returns the number of objects this rank fitted; `fit_sharded.last_stats` holds this rank's
     timings (`fit_s`: until its last row was packed, `total_s`).
+
+    `writer="per_rank"` takes the funnel out altogether: every rank writes the rows of ITS shard
+    to `{save_file}.rNN.h5` (same datasets, `hi - lo` rows, its own asynchronous libhdf5 writer;
+    nothing but the tiny headers crosses the side group), and when all are closed rank 0 writes
+    `{save_file}.h5` as an INDEX: the 13 datasets as HDF5 virtual datasets that map row range
+    `[lo_r, hi_r)` onto part `r` (`h5io.write_virtual_index`; the part files must stay beside it,
+    `h5io.materialize` copies everything into one plain file when that is wanted).  Readers --
+    h5py, `h5io.read_dataset` -- see the reference's layout.  With one writer 8 ranks x 25 k
+    objects/s x 18 KB = 3.6 GB/s would pass through one gloo receiver and one libhdf5 thread;
+    per rank it is 0.45 GB/s into a file of its own.  `resume=True` re-opens every rank's part
+    (same number of ranks as the interrupted run).
     """
+    import os
     import queue
     import threading
     import time
@@ -177,36 +190,67 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     par = kw.get("parallax")
     perr = kw.get("parallax_err")
     t_start = time.time()
+    if writer not in ("rank0", "per_rank"):
+        raise ValueError("fit_sharded: writer must be 'rank0' or 'per_rank'")
+    per_rank = writer == "per_rank"
     side = dist.new_group(backend="gloo") if world > 1 else None     # host-to-host hand-off
     out = None
     todo = None
-    if resume:
-        # Rank 0 re-opens the interrupted file and reads the sentinel column (`model_idx[:, 0]
-        # == -99`: never fitted, reference fitting.py:1635); every rank then fits only the
-        # unfinished rows of ITS shard, each contiguous run of them as one `_fit` call seeded
-        # `seed0 + first row` -- object i draws from stream `seed0 + i` as in the interrupted
-        # run, so the completed file equals an uninterrupted one.
-        state = torch.zeros(Ndata + 1, dtype=torch.uint8)
-        open_error = None
-        if rank == 0:
+    # Who writes what: one file on rank 0 (rows arrive over the side group), or a part per rank.
+    owner = rank == 0 or (per_rank and hi > lo)
+    my_path = ("{0}.r{1:02d}.h5".format(save_file, rank) if per_rank else "{0}.h5".format(save_file))
+    my_rows = (hi - lo) if per_rank else Ndata
+    my_first = lo if per_rank else 0
+    if per_rank and rank == 0 and hi == lo:
+        owner = False
+    open_error = None
+    if owner:
+        try:
+            if resume:
+                # the interrupted file(s): rows whose `model_idx[:, 0]` still holds the sentinel
+                # -99 were never fitted (reference fitting.py:1635)
+                out = h5io.ResultsFile.resume(my_path, my_rows, Ndraws, save_dar_draws)
+            else:
+                lab = data_labels
+                if per_rank and lab is not None:
+                    lab = np.asarray(lab)[lo:hi]
+                out = h5io.ResultsFile(my_path, my_rows, Ndraws, lab, save_dar_draws,
+                                       running_io=running_io)
+        except BaseException as e:
+            open_error = e
+    # One handshake for every way of opening: a rank that could not create / re-open its file
+    # says so before anybody enters the hand-off protocol, and EVERY rank raises (without it
+    # the others would wait for the failed rank in the first round of headers).
+    ok = torch.tensor([0 if open_error is not None else 1], dtype=torch.int64)
+    if world > 1:
+        oks = [torch.empty(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(oks, ok, group=side)
+        bad = [r for r in range(world) if not int(oks[r])]
+    else:
+        bad = [] if int(ok) else [0]
+    if bad:
+        if out is not None:
             try:
-                out = h5io.ResultsFile.resume("{0}.h5".format(save_file), Ndata, Ndraws,
-                                              save_dar_draws)
-                state[0] = 1
-                state[1:][torch.from_numpy(np.asarray(out.todo, dtype=np.int64))] = 1
-            except BaseException as e:
-                open_error = e
-        if world > 1:
+                out.close()
+                if not resume:
+                    os.remove(my_path)          # created a moment ago, holds nothing: a rerun must not trip over it
+            except BaseException:
+                pass
+        if side is not None:
+            dist.destroy_process_group(side)
+        raise open_error or RuntimeError(
+            "fit_sharded: rank(s) %s could not open their results file; this rank stops too"
+            % ", ".join(str(r) for r in bad))
+    if resume:
+        # every rank fits only the unfinished rows of ITS shard, each contiguous run of them as
+        # one `_fit` call seeded `seed0 + first row` -- object i draws from stream `seed0 + i` as
+        # in the interrupted run, so the completed file equals an uninterrupted one.
+        state = torch.zeros(Ndata, dtype=torch.uint8)
+        if out is not None:
+            state[my_first + torch.from_numpy(np.asarray(out.todo, dtype=np.int64))] = 1
+        if world > 1 and not per_rank:
             dist.broadcast(state, src=0, group=side)
-        if not int(state[0]):
-            if side is not None:
-                dist.destroy_process_group(side)
-            raise open_error or RuntimeError("fit_sharded: rank 0 could not re-open %s.h5" % save_file)
-        todo = state[1:].numpy().astype(bool)
-    elif rank == 0:
-        out = h5io.ResultsFile("{0}.h5".format(save_file), Ndata, Ndraws,
-                               data_labels, save_dar_draws,
-                               running_io=running_io)
+        todo = state.numpy().astype(bool)
     # the contiguous runs [a, b) of rows this rank fits
     if todo is None:
         runs = [(lo, hi)] if hi > lo else []
@@ -239,7 +283,6 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
             current[0] = None
 
     gen = fitted_rows()
-    bf._catalogue_mask = data_mask       # one band set for all ranks and runs (BruteForce._bands_for)
     rowdt, positions = h5io.ResultsFile.row_dtype(Ndraws, save_dar_draws)
     rowbytes = rowdt.itemsize
     q = queue.Queue(maxsize=max(1, int(queue_depth)))
@@ -308,20 +351,40 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                     # flushed and closed.  Rank 0 does that HERE, and one more round of headers
                     # tells everybody how it went; otherwise rank 0 alone would raise after the
                     # threads have ended and the others would wait in the closing barrier.
-                    if rank == 0:
-                        try:
-                            out.close()
-                        except BaseException as e:
-                            failure["local"] = e
-                    if world > 1:
+                    def closing_round():
+                        """Everybody's verdict on the step just taken; True if all went well."""
+                        if world == 1:
+                            return failure["local"] is None
                         last = torch.tensor([0, 0, 1, 0 if failure["local"] is None else 1],
                                             dtype=torch.int64)
                         lasts = [torch.empty(4, dtype=torch.int64) for _ in range(world)]
                         dist.all_gather(lasts, last, group=side)
-                        if int(lasts[0][3]) and rank != 0:
+                        badr = [r for r in range(world) if int(lasts[r][3])]
+                        if badr and failure["local"] is None:
                             failure["remote"] = RuntimeError(
-                                "fit_sharded: rank 0 could not finish the results file; "
-                                "this rank stops too")
+                                "fit_sharded: rank %s could not finish the results file; "
+                                "this rank stops too" % ", ".join(str(r) for r in badr))
+                        return not badr
+                    if out is not None:
+                        try:
+                            out.close()
+                        except BaseException as e:
+                            failure["local"] = e
+                    all_closed = closing_round()
+                    if per_rank and all_closed:
+                        # every part is complete and closed: the index that presents them as
+                        # the reference's one file
+                        if rank == 0:
+                            try:
+                                h5io.write_virtual_index(
+                                    "{0}.h5".format(save_file), Ndata, Ndraws, save_dar_draws,
+                                    data_labels,
+                                    [(a, b, os.path.basename("{0}.r{1:02d}.h5".format(save_file, r)))
+                                     for r, (a, b) in enumerate(bounds) if b > a],
+                                    overwrite=resume)
+                            except BaseException as e:
+                                failure["local"] = e
+                        closing_round()
                     return
         except BaseException as e:                   # the collective itself failed
             failure["local"] = failure["local"] or e
@@ -344,6 +407,7 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     fit_error = None
     t_fit = None
     try:
+        bf._catalogue_mask = data_mask       # one band set for all ranks and runs (BruteForce._bands_for)
         try:
             exhausted = False
             pending = None                           # a row of the next run, already fitted
@@ -369,7 +433,11 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
                         for name, pos in positions:
                             block[name][n] = res[pos]
                         n += 1
-                if n:
+                if n and per_rank:
+                    if abort.is_set():               # somebody else failed: stop fitting
+                        raise failure["remote"] or failure["local"] or RuntimeError("fit_sharded aborted")
+                    out.write_block(start - lo, {name: block[name][:n] for name, _ in positions})
+                elif n:
                     put(("rows", start, n, block))
             t_fit = time.time() - t_start
             put(("done",))
@@ -395,6 +463,6 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     if err is not None:
         raise err
     fit_sharded.last_stats = {"fit_s": t_fit, "total_s": time.time() - t_start,
-                              "objects": nmine}
+                              "objects": nmine, "writer": writer}
     dist.barrier()
     return nmine

@@ -52,7 +52,7 @@ def make_grid(nmodel=750000, nfilt=12, seed=GRID_SEED):
 
 
 def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
-               min_frac_err=0.02, frac_err=None, parallax_snr=None):
+               min_frac_err=0.02, frac_err=None, parallax_snr=None, av_range=(0., 2.5)):
     """Draw `nstar` synthetic stars from the grid.
 
     Returns dict with flux, err (nstar, nfilt) f64 in maggies, mask (bool, all
@@ -61,12 +61,12 @@ def make_stars(models, nstar, seed=1, with_parallax=True, frac_no_parallax=0.25,
     the reference's Orion demo fixture (median 0.025-0.06 mag, tail to 0.14).
     `frac_err`: one fractional error for every band instead (0.02 = S/N 50);
     `parallax_snr`: parallax errors as that fraction of the true parallax instead of the
-    log-uniform 0.05-1.5 mas.
+    log-uniform 0.05-1.5 mas.  `av_range`: the true extinctions are uniform in it.
     """
     rng = np.random.RandomState(seed)
     nmodel, nfilt, _ = models.shape
     idx = rng.randint(0, nmodel, size=nstar)
-    av = rng.uniform(0., 2.5, size=nstar)
+    av = rng.uniform(av_range[0], av_range[1], size=nstar)
     rv = np.clip(rng.normal(3.32, 0.18, size=nstar), 1., 8.)
     dist = 10. ** rng.uniform(np.log10(0.1), np.log10(5.), size=nstar)  # kpc
     c = models[idx].astype(np.float64)

@@ -45,6 +45,7 @@ extern "C" {
 #define BRUTUS_ENOMEM (-2)    /* workspace / record buffer too small               */
 #define BRUTUS_EHIP (-3)      /* HIP runtime error (message in brutus_last_error)  */
 #define BRUTUS_ENOCONV (-4)   /* iteration cap hit (the reference would spin)      */
+#define BRUTUS_EPRECISION (-5) /* brutus_fit_batch: the audited float32 error bound does not hold (see there) */
 
 /* Keyword arguments of fitting.loglike (fitting.py:579-585) plus lnpost's
  * wt_thresh (fitting.py:823-827).  av_gauss=None maps to (0, 1e6) on the host
@@ -124,7 +125,12 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
  * every record's rv is rv_gauss[0].
  * h_counts (host, 3 x int64): [0] selected models of the batch (= off[nstar]),
  * [1] ncand, [2] columns needed = ncand + nder.  BRUTUS_ENOMEM if [2] > capacity (or
- * already [1] > capacity: then [2] is an estimate): call again with larger buffers. */
+ * already [1] > capacity: then [2] is an estimate): call again with larger buffers.
+ * Float32 never produces an output value or a decision here, it only proves models to be below
+ * the thresholds; the error bound that rests on is AUDITED on the first call of a process and
+ * every BRUTUS_AUDIT_EVERY-th (environment, default 256; 0 = never) after it -- every pair the
+ * call re-evaluates in float64 anyway is compared with its float32 value -- and a call whose
+ * audit finds |float32 - float64| >= the bound fails with BRUTUS_EPRECISION. */
 int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
                      int nstar, const double *d_flux, const double *d_err,
                      const uint8_t *d_mask, const double *d_parallax,

@@ -93,6 +93,15 @@ int brutus_debug_copy(void *d_workspace, size_t workspace_bytes, int64_t nmodel,
                       void *stream);
 int brutus_debug_sizeof_star32(void);
 
+/* Measurement aid: the float32 pass alone.  Re-launches it `reps` (+ 1 untimed) times over the
+ * star constants the last brutus_fit_batch left in the workspace (same nmodel / nfilt / nstar /
+ * params; the float32 planes are overwritten with the same values) and reports the average
+ * duration by HIP events on `stream`.  form: 0 = k_pre32s (all-vector), 1 = k_pre32m (band
+ * contractions on the matrix pipe), other values = development variants where built. */
+int brutus_debug_pre32_time(void *d_workspace, size_t workspace_bytes, const float *d_grid_soa,
+                            int64_t nmodel, int nfilt, int nstar, const brutus_params *params,
+                            int form, int reps, float *h_ms, void *stream);
+
 
 #ifdef __cplusplus
 }

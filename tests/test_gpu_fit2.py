@@ -89,7 +89,10 @@ def _vs_full_grid(grid, st, kw, with_par=True, tol=1e-9, audit_frac=0.25):
         d = np.sqrt(np.abs(ic[[0, 3, 5]]))                  # sqrt of the diagonal
         pairs = ((0, 0), (0, 1), (0, 2), (1, 1), (1, 2), (2, 2))
         for q, (a, b) in enumerate(pairs):
-            assert np.max(np.abs(rec["icov"][:, a, b] - ic[q]) / (d[a] * d[b])) < tol, (kw, i, q)
+            # (scale: the geometric mean of the diagonal, or the entry itself where it is larger --
+            # the Av-Rv entry carries F - F0, 10^6 times the reddened flux at Av 15)
+            sc = np.maximum(d[a] * d[b], np.abs(ic[q]))
+            assert np.max(np.abs(rec["icov"][:, a, b] - ic[q]) / sc) < tol, (kw, i, q)
     return recs
 
 
@@ -187,24 +190,25 @@ ADVERSARIAL = [
     ("avlim_open", 12, dict(kw=dict(avlim=(0., 100.)))),
     ("avlim_open_sn1e3_pinned", 12, dict(frac=1e-3, kw=dict(avlim=(0., 100.), rvlim=(3.32, 3.32)))),
     ("negative_flux", 12, dict(neg=True)),
+    # truly reddened stars: the models that matter sit at Av 8 - 19.5, where the float32 sweep
+    # statistic cancels between terms ~ Av^2 sum w R^2 and the exponent Av R + m reaches 40
+    ("true_av8_sn100", 12, dict(av=(7.9, 8.1), frac=1e-2, exact_noise=True)),
+    ("true_av15_sn100_pinned", 12, dict(av=(14.9, 15.1), frac=1e-2, exact_noise=True, kw=dict(rvlim=(3.32, 3.32)))),
+    ("true_av19p5_sn100", 12, dict(av=(19.4, 19.6), frac=1e-2, exact_noise=True)),
+    ("true_av8_sn1000_pinned", 12, dict(av=(7.9, 8.1), frac=1e-3, exact_noise=True, kw=dict(rvlim=(3.32, 3.32)))),
+    ("true_av15_sn1000", 12, dict(av=(14.9, 15.1), frac=1e-3, exact_noise=True)),
+    ("true_av19p5_sn1000_pinned", 12, dict(av=(19.4, 19.6), frac=1e-3, exact_noise=True, kw=dict(rvlim=(3.32, 3.32)))),
 ]
 
 
-@pytest.mark.parametrize("case", ADVERSARIAL, ids=[c[0] for c in ADVERSARIAL])
-def test_float32_proof_bound_adversarial(case):
-    """`Star32::eps` is a formula with hand-picked constants; a model it wrongly "proves"
-    below a threshold would silently drop out of the output.  Shapes chosen against it --
-    photometry at S/N 10^3 - 10^4 (the float32 chi2 cancels against sum (S/N)^2), precise
-    parallaxes, four-band stars, 24 / 32 bands, stars 30 mag fainter / brighter than the
-    grid (scale 1e-12 / 1e12), the Av range wide open, negative fluxes: in every case the
-    run-time audit max|float32 - float64| stays below eps AND the selected sets, K1, K2
-    equal the float64 full-grid pipeline + host cut (`_vs_full_grid` asserts both)."""
-    from brutus_amd import fitting, synth
+def _adversarial_inputs(case, S=8):
+    """(grid models, stars, fit kwargs, value tolerance) of one ADVERSARIAL entry."""
+    from brutus_amd import synth
     name, nb, o = case
     models, _, _ = synth.make_mist_like_grid(30000, nb, seed=17)
-    S = 8
-    st = synth.make_stars(models, S, seed=23, min_frac_err=min(0.02, o.get("frac", 0.02)))
-    if "frac" in o:
+    st = synth.make_stars(models, S, seed=23, min_frac_err=min(0.02, o.get("frac", 0.02)),
+                          av_range=o.get("av", (0., 2.5)), frac_err=o["frac"] if o.get("exact_noise") else None)
+    if "frac" in o and not o.get("exact_noise"):
         # (the drawn fluxes keep their 2 % scatter about the model: at these errors no model
         # of a 30k grid fits, chi2 ~ 1e5 - 1e7 and the flux phase runs for hundreds to
         # thousands of damped iterations, like the reference's uncapped while loop does)
@@ -225,9 +229,61 @@ def test_float32_proof_bound_adversarial(case):
     if o.get("neg"):
         st["flux"][::2, 1] = -np.abs(st["flux"][::2, 1]) * 0.3
         st["flux"][1::3, 7] = -np.abs(st["flux"][1::3, 7])
-    grid = fitting.DeviceGrid(models)
     tol = 1e-7 if o.get("frac", 1.) <= 1e-3 else 1e-9     # (chi2 up to 1e9 at S/N 1e4)
-    _vs_full_grid(grid, st, o.get("kw", dict()), tol=tol, audit_frac=1.0)
+    return models, st, o.get("kw", dict()), tol
+
+
+@pytest.mark.parametrize("lanes", ["tile", "star_lanes"])
+@pytest.mark.parametrize("case", ADVERSARIAL, ids=[c[0] for c in ADVERSARIAL])
+def test_float32_proof_bound_adversarial(case, lanes):
+    """`Star32::eps` is a formula with hand-picked constants; a model it wrongly "proves"
+    below a threshold would silently drop out of the output.  Shapes chosen against it --
+    photometry at S/N 10^3 - 10^4 (the float32 chi2 cancels against sum (S/N)^2), precise
+    parallaxes, four-band stars, 24 / 32 bands, stars 30 mag fainter / brighter than the
+    grid (scale 1e-12 / 1e12), the Av range wide open, negative fluxes, TRULY reddened stars
+    (Av 8 - 19.5 at S/N 100 and 1000, general and pinned Rv): in every case the
+    run-time audit max|float32 - float64| stays below eps AND the selected sets, K1, K2
+    equal the float64 full-grid pipeline + host cut (`_vs_full_grid` asserts both).  Both
+    float32 passes: the tile kernel (short star lists) and, with the threshold lowered, the
+    star-lane kernel the full-size batches take."""
+    from brutus_amd import fitting
+    models, st, kw, tol = _adversarial_inputs(case)
+    grid = fitting.DeviceGrid(models)
+    with _Env(BRUTUS_PRE32_STAR_LANES_MIN=1 if lanes == "star_lanes" else 1000):
+        _vs_full_grid(grid, st, kw, tol=tol, audit_frac=1.0)
+
+
+def test_audit_is_enforced_and_fails_loudly_when_the_bound_is_too_small():
+    """Production safety net of the float32 proof: on an audited call (the first of a process and
+    every BRUTUS_AUDIT_EVERY-th after it) every pair the call re-evaluates in float64 anyway is
+    compared with its float32 value, and the call FAILS when one differs by eps or more.  With the
+    bound shrunk a thousandfold (BRUTUS_EPS_SCALE=1e-3) float32's real error exceeds it: the fit
+    raises instead of returning posteriors that may miss models; with the bound as shipped the
+    same audited call passes, in both float32 passes."""
+    from brutus_amd import _lib, fitting, synth
+    models, _, _ = synth.make_mist_like_grid(30000, 12, seed=17)
+    st = synth.make_stars(models, 40, seed=5)
+    grid = fitting.DeviceGrid(models)
+    eng = fitting._Engine(grid, max_batch=40, mem_budget=200e9)
+    args = (st["flux"], st["err"], st["mask"], st["parallax"], st["parallax_err"], _params(dict()))
+    for min_stars in (1000, 1):
+        with _Env(BRUTUS_AUDIT_EVERY=1, BRUTUS_PRE32_STAR_LANES_MIN=min_stars):
+            eng.fit_batch(*args)
+            with _Env(BRUTUS_EPS_SCALE=1e-3):
+                with pytest.raises(_lib.BrutusError, match="float32 proof bound violated"):
+                    eng.fit_batch(*args)
+
+
+def test_matrix_pipe_form_of_the_float32_pass_agrees():
+    """k_pre32m (the band contractions of the float32 pass as float32 MFMAs; measured, not the
+    default: profiles/r06_pre32m_ab.txt) still classifies like the vector form: selected sets, K1,
+    K2 and the audit on the shapes that stress its expanded sums."""
+    from brutus_amd import fitting
+    for name in ("sn1e3", "faint_30mag", "true_av19p5_sn100", "true_av15_sn1000", "negative_flux"):
+        case = next(c for c in ADVERSARIAL if c[0] == name)
+        models, st, kw, tol = _adversarial_inputs(case, S=20)
+        with _Env(BRUTUS_PRE32_STAR_LANES_MIN=1, BRUTUS_PRE32_MFMA=1):
+            _vs_full_grid(fitting.DeviceGrid(models), st, kw, tol=tol, audit_frac=1.0)
 
 
 def test_random_order_grid_and_tiny_shapes():

@@ -279,7 +279,7 @@ def _stub_class(fail_at=None):
     return Stub
 
 
-def _worker_resume(rank, world, port, tmp, name, fail_at, resume):
+def _worker_resume(rank, world, port, tmp, name, fail_at, resume, writer="rank0"):
     sys.path.insert(0, ROOT)
     import torch.distributed as dist
     from brutus_amd import parallel, synth
@@ -295,10 +295,12 @@ def _worker_resume(rank, world, port, tmp, name, fail_at, resume):
         n = parallel.fit_sharded(bf, flux, 0.05 * flux, np.ones((ndata, 6), dtype=bool), None,
                                  os.path.join(tmp, name), seed0=1000, Ndraws=7, chunk=16,
                                  lngalprior=lambda *a, **k: 0., data_coords=np.zeros((ndata, 2)),
-                                 resume=resume)
+                                 resume=resume, writer=writer)
         msg = "ok %d" % n
     except FloatingPointError as e:
         msg = "own %s" % e
+    except OSError as e:
+        msg = "own OSError %s" % e
     except RuntimeError as e:
         msg = "remote %s" % e
     with open(os.path.join(tmp, "%s_%d.txt" % (name, rank)), "w") as f:
@@ -376,3 +378,113 @@ def test_fit_sharded_writer_failure_at_the_very_end_reaches_every_rank(tmp_path)
     res = [open(os.path.join(str(tmp_path), "cf_%d.txt" % r)).read() for r in range(3)]
     assert res[0].startswith("own No space left"), res
     assert all(r.startswith("remote") and "rank 0" in r for r in res[1:]), res
+
+
+def _worker_per_rank(rank, world, port, tmp, writer, resume_rows):
+    """`fit_sharded(writer=...)` with a deterministic stand-in for `_fit`; `resume_rows`: first
+    pass fits everything but dies... no: rows to blank out again before a resume pass."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from brutus_amd import fitting, parallel, synth
+    dist.init_process_group("gloo", init_method="tcp://127.0.0.1:%d" % port,
+                            rank=rank, world_size=world)
+    models, labels, lmask = synth.make_grid(64, 6, seed=1)
+    st = synth.make_stars(models, 23, seed=2)
+
+    class Stub(fitting.BruteForce):
+        def _fit(self, data, data_err, data_mask, parallax=None, Ndraws=250,
+                 seed0=None, return_distreds=True, rstate_per_object=None, **kw):
+            for i in range(data.shape[0]):
+                rs = np.random.RandomState(seed0 + i)
+                idx = rs.randint(0, 64, size=Ndraws)
+                val = rs.uniform(size=Ndraws)
+                cov = rs.uniform(size=(Ndraws, 3, 3))
+                yield (idx, val, 2. * val, 3. * val, cov, 6, val - 1.,
+                       float(rs.uniform()), float(np.sum(data[i])), val, val + 1., val + 2., val + 3.)
+
+    bf = Stub(models, labels, lmask)
+    lab = np.zeros(23, dtype=[("id", "i8"), ("name", "S6")])
+    lab["id"] = np.arange(23)
+    lab["name"] = [b"s%04d" % i for i in range(23)]
+    n = parallel.fit_sharded(bf, st["flux"], st["err"], st["mask"], lab,
+                             os.path.join(tmp, "%s_w%d" % (writer, world)), seed0=100,
+                             Ndraws=5, chunk=4, lngalprior=lambda *a, **k: 0.,
+                             parallax=st["parallax"], parallax_err=st["parallax_err"],
+                             data_coords=st["coords"], writer=writer)
+    lo, hi = parallel.shard_range(23, rank, world)
+    assert n == hi - lo
+    assert parallel.fit_sharded.last_stats["writer"] == writer
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [1, 2, 3, 8])
+def test_per_rank_writer_index_equals_the_single_writer_file(tmp_path, world):
+    """`writer="per_rank"`: every rank writes `{save_file}.rNN.h5`, rank 0 an index of virtual
+    datasets -- read through the index, every dataset equals the file one writer on rank 0
+    produces, for 1 - 8 ranks (8 ranks on 23 objects: shards of 2 - 3 rows), and
+    `h5io.materialize` turns the index into one plain file with the same content."""
+    import torch.multiprocessing as mp
+    from brutus_amd import h5io
+    for writer in ("rank0", "per_rank"):
+        mp.spawn(_worker_per_rank, args=(world, _free_port(), str(tmp_path), writer, None),
+                 nprocs=world, join=True)
+    one = os.path.join(str(tmp_path), "rank0_w%d.h5" % world)
+    idx = os.path.join(str(tmp_path), "per_rank_w%d.h5" % world)
+    names = sorted(h5io.list_datasets(one))
+    assert names == sorted(h5io.list_datasets(idx)) and len(names) == 14
+    parts = [f for f in os.listdir(str(tmp_path)) if f.startswith("per_rank_w%d.r" % world)]
+    assert len(parts) == world
+    here = os.getcwd()
+    os.chdir("/")                        # (the index finds its parts relative to ITSELF)
+    try:
+        for k in names:
+            a, b = h5io.read_dataset(one, k), h5io.read_dataset(idx, k)
+            assert a.dtype == b.dtype and a.shape == b.shape, k
+            assert np.array_equal(a, b), k
+        flat = os.path.join(str(tmp_path), "flat_w%d.h5" % world)
+        h5io.materialize(idx, flat)
+        for k in names:
+            assert np.array_equal(h5io.read_dataset(one, k), h5io.read_dataset(flat, k)), k
+    finally:
+        os.chdir(here)
+
+
+def test_fit_sharded_resume_with_per_rank_parts(tmp_path):
+    """`writer="per_rank"`, three ranks: object 1230 (rank 2's shard) raises, everybody stops, no
+    index is written.  `resume=True` with the same three ranks re-opens every part, fits the rows
+    that still hold the sentinel and writes the index: equal to an uninterrupted single-writer run."""
+    import torch.multiprocessing as mp
+    from brutus_amd import h5io
+    tmp = str(tmp_path)
+    mp.spawn(_worker_resume, args=(1, _free_port(), tmp, "full", None, False), nprocs=1, join=True)
+    mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "pp", 1230, False, "per_rank"), nprocs=3, join=True)
+    res = [open(os.path.join(tmp, "pp_%d.txt" % r)).read() for r in range(3)]
+    assert res[2].startswith("own object 1230") and all(r.startswith("remote") for r in res[:2]), res
+    assert not os.path.exists(os.path.join(tmp, "pp.h5"))
+    mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "pp", None, True, "per_rank"), nprocs=3, join=True)
+    res = [open(os.path.join(tmp, "pp_%d.txt" % r)).read().split() for r in range(3)]
+    assert all(x[0] == "ok" for x in res), res
+    assert 0 < sum(int(x[1]) for x in res) < 301            # only the unfinished rows were fitted
+    for k in h5io.list_datasets(os.path.join(tmp, "full.h5")):
+        a = h5io.read_dataset(os.path.join(tmp, "full.h5"), k)
+        b = h5io.read_dataset(os.path.join(tmp, "pp.h5"), k)
+        assert a.dtype == b.dtype and np.array_equal(a, b), k
+
+
+def test_fit_sharded_file_that_cannot_be_created_stops_every_rank(tmp_path):
+    """The results file exists already (`"w-"`, reference fitting.py:1632): rank 0 raises its
+    OSError and the other ranks a RuntimeError naming it -- before anybody enters the hand-off
+    protocol (they used to wait for rank 0 in its first round); same with per-rank parts when
+    one rank's part exists."""
+    import torch.multiprocessing as mp
+    tmp = str(tmp_path)
+    open(os.path.join(tmp, "ex.h5"), "w").close()
+    mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "ex", None, False), nprocs=3, join=True)
+    res = [open(os.path.join(tmp, "ex_%d.txt" % r)).read() for r in range(3)]
+    assert res[0].startswith("own OSError"), res
+    assert all(r.startswith("remote") and "rank(s) 0" in r for r in res[1:]), res
+    open(os.path.join(tmp, "ey.r01.h5"), "w").close()
+    mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "ey", None, False, "per_rank"), nprocs=3, join=True)
+    res = [open(os.path.join(tmp, "ey_%d.txt" % r)).read() for r in range(3)]
+    assert res[1].startswith("own OSError"), res
+    assert all(res[r].startswith("remote") and "rank(s) 1" in res[r] for r in (0, 2)), res
