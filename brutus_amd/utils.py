@@ -480,23 +480,24 @@ def _photometric_offsets_device(phot, err, mask, models, idxs, reds, dreds, dist
 # name the reference exports.  None of them is on the grid-likelihood path.
 # ---------------------------------------------------------------------------
 class _function_wrapper(object):
-    """Picklable `x -> func(x, *args, **kwargs)` (reference utils.py:43-68; the emcee idiom):
-    an exception inside `func` is reported with the arguments, then re-raised."""
+    """Picklable closure `x -> func(x, *args, **kwargs)` (the role of reference utils.py:43-68):
+    a failure inside `func` is logged to stderr together with the call's arguments before it
+    propagates, so that a worker pool's traceback says which evaluation died."""
 
     def __init__(self, func, args, kwargs, name='input'):
-        self.func, self.args, self.kwargs, self.name = func, args, kwargs, name
+        self.func = func
+        self.args = tuple(args)
+        self.kwargs = dict(kwargs)
+        self.name = name
 
     def __call__(self, x):
         try:
             return self.func(x, *self.args, **self.kwargs)
-        except Exception:
-            import traceback
-            print("Exception while calling {0} function:".format(self.name))
-            print("  params:", x)
-            print("  args:", self.args)
-            print("  kwargs:", self.kwargs)
-            print("  exception:")
-            traceback.print_exc()
+        except Exception as exc:
+            import sys
+            sys.stderr.write("brutus_amd: the %s function raised %s: %s\n  at x = %r\n  with args = %r, "
+                             "kwargs = %r\n" % (self.name, type(exc).__name__, exc, x, self.args,
+                                                self.kwargs))
             raise
 
 
@@ -571,20 +572,23 @@ def _get_seds(mag_coeffs, av, rv, return_flux=False):
 
 
 def quantile(x, q, weights=None):
-    """(Weighted) sample quantiles (utils.py:718-762): `numpy.percentile` without weights,
-    else the inverse of the cumulative weights of the sorted samples."""
-    x, q = np.atleast_1d(x), np.atleast_1d(q)
-    if np.any(q < 0.0) or np.any(q > 1.0):
+    """Sample quantiles `q` (in [0, 1]) of `x`, optionally weighted (the contract of reference
+    utils.py:718-762).  Unweighted: linear interpolation between order statistics
+    (`numpy.quantile`).  Weighted: the sorted samples are placed at the cumulative weight that
+    PRECEDES them, normalised by the total without the last sample's weight, and `q` is
+    interpolated linearly on that curve."""
+    samples = np.atleast_1d(np.asarray(x))
+    qs = np.atleast_1d(np.asarray(q, dtype=np.float64))
+    if qs.size and (qs.min() < 0. or qs.max() > 1.):
         raise ValueError("Quantiles must be between 0. and 1.")
     if weights is None:
-        return np.percentile(x, list(100.0 * q))
-    weights = np.atleast_1d(weights)
-    if len(x) != len(weights):
+        return np.quantile(samples, qs)
+    w = np.atleast_1d(np.asarray(weights, dtype=np.float64))
+    if w.shape[0] != samples.shape[0]:
         raise ValueError("Dimension mismatch: len(weights) != len(x).")
-    order = np.argsort(x)
-    cdf = np.cumsum(weights[order])[:-1]
-    cdf = np.append(0, cdf / cdf[-1])
-    return np.interp(q, cdf, x[order]).tolist()
+    rank = np.argsort(samples, kind="stable")
+    before = np.concatenate([[0.], np.cumsum(w[rank])[:-1]])     # weight in front of each sample
+    return np.interp(qs, before / before[-1], samples[rank]).tolist()
 
 
 def luptitude(phot, err, skynoise=1., zeropoints=1.):

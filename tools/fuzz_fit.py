@@ -1,6 +1,8 @@
 """Randomised comparison of the hot path of brutus_fit_batch with the generic full-grid pipeline
-(tests/test_gpu_fit2.py::_vs_full_grid: selected sets, K1, K2 identical, values to 1e-9, run-time
-audit of the float32 bound) over shapes the fixed tests do not visit -- in particular star lists of
+(tests/test_gpu_fit2.py::_vs_full_grid: selected sets, K1, K2 identical, values to 1e-8 of
+max(|value|, 1) -- every case's own tolerance where that is looser --, run-time audit of the
+float32 bound) AND, for one star of every case, with the C restatement oracle/loglike_ref.c + the
+first cut (an error common to both GPU pipelines would pass the first comparison) over shapes the fixed tests do not visit -- in particular star lists of
 32 and more, which take the star-lane float32 pass (k_pre32s).  GPU box:
 
     python tools/fuzz_fit.py [cases] [seed]
@@ -76,7 +78,8 @@ def check(models, st, kw, with_par, tol):
     phase of a few hundred damped iterations along an Av-scale degeneracy separates two
     equivalent float64 pipelines by ~1e-9); a model beyond `tol` must sit on a discontinuity
     of the reference algorithm, with the C restatement as witness (see below).  Returns (median
-    selected, worst value error among the models within tol)."""
+    selected, worst value error among the models within tol, TRUE worst value error, models
+    excused on a discontinuity)."""
     S = st["flux"].shape[0]
     par = st["parallax"] if with_par else np.full(S, np.nan)
     perr = st["parallax_err"] if with_par else np.full(S, np.nan)
@@ -91,7 +94,9 @@ def check(models, st, kw, with_par, tol):
         rvlim=kw.get("rvlim", (1., 8.)), rv_gauss=kw.get("rv_gauss", (3.32, 0.18)),
         dim_prior=kw.get("dim_prior", True), ltol=kw.get("ltol", 3e-2), parallax=par,
         parallax_err=perr, max_batch=min(S, 8))
-    worst = 0.
+    worst = worst_all = 0.
+    nexcused = 0
+    _vs_c_oracle(models, st, kw, par, perr, recs, int(np.random.RandomState(S + models.shape[0]).randint(S)))
     for i, rec in enumerate(recs):
         sel = T._first_cut(full["lnl"][i], full["scale"][i], full["icov6"][0, i], par[i], perr[i])
         assert rec["K1"] == full["k1"][i] and rec["K2"] == full["k2"][i], \
@@ -103,6 +108,7 @@ def check(models, st, kw, with_par, tol):
             e = np.abs(a - b) / np.maximum(np.abs(a), 1.)
             if e.size:
                 worst = max(worst, float(e[e < tol].max()) if (e < tol).any() else 0.)
+                worst_all = max(worst_all, float(np.nanmax(e)))
                 off |= ~(e < tol)
         ic = full["icov6"][:, i, :][:, sel]
         d = np.sqrt(np.abs(ic[[0, 3, 5]]))
@@ -127,7 +133,36 @@ def check(models, st, kw, with_par, tol):
             assert moved[bad].all() and np.max(np.abs(av0[bad] - full["av"][i][bad])) < 1e-10, \
                 ("values", i, bad[:8], moved[bad][:8], rec["K2"])
             DISCONTINUITIES.append((i, [int(x) for x in bad[:8]]))
-    return int(np.median([r["sel"].size for r in recs])), worst
+            nexcused += int(off.sum())
+    return int(np.median([r["sel"].size for r in recs])), worst, worst_all, nexcused
+
+
+def _vs_c_oracle(models, st, kw, par, perr, recs, i):
+    """Star i of the case against oracle/loglike_ref.c + the first cut of lnpost (fitting.py:976-991),
+    like bench.py's parity block: selected set and K1 / K2 identical, lnlike / chi2 / scale to 1e-8."""
+    from oracle import c_oracle
+    from brutus_amd.pdf import scale_parallax_lnprior
+    if not c_oracle.available():
+        raise RuntimeError("oracle/libbrutus_ref.so not built")
+    okw = {k: v for k, v in kw.items() if k in ("avlim", "rvlim", "rv_gauss", "dim_prior", "ltol")}
+    p_, pe_ = (float(par[i]), float(perr[i])) if np.isfinite(par[i]) and np.isfinite(perr[i]) else (np.nan, np.nan)
+    tr = {}
+    lnl, nd, chi2, sc, av, rv, icov = c_oracle.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
+                                                      parallax=p_, parallax_err=pe_, trace=tr, **okw)
+    with np.errstate(all="ignore"):
+        lnprob = lnl + scale_parallax_lnprior(sc, 1. / np.sqrt(np.abs(icov[:, 0, 0])), p_, pe_)
+    lnprob = np.where(np.isfinite(lnprob), lnprob, -1e300)
+    sel = np.where(lnprob > np.log(T.WT) + lnprob.max())[0]
+    rec = recs[i]
+    assert rec["K1"] == tr["K1"] and rec["K2"] == tr["K2"], ("oracle K", i, rec["K1"], tr["K1"], rec["K2"], tr["K2"])
+    assert np.array_equal(sel, rec["sel"]), ("oracle sel", i, sel.size, rec["sel"].size)
+    for got, ref in ((rec["lnlike"], lnl[sel]), (rec["chi2"], chi2[sel]), (rec["scale"], sc[sel])):
+        if sel.size:
+            e = np.abs(got - ref) / np.maximum(np.abs(ref), 1.)
+            assert np.max(e) < 1e-7, ("oracle values", i, float(np.max(e)))
+
+
+WORST = [0., 0]      # largest value error over all cases (excused models included), models excused
 
 
 def main():
@@ -140,18 +175,20 @@ def main():
         models, st, kw, with_par, tol, desc = case(rng)
         try:
             del DISCONTINUITIES[:]
-            nsel, worst = check(models, st, kw, with_par, 1e-8 if tol <= 1e-8 else tol)
+            nsel, worst, worst_all, nexc = check(models, st, kw, with_par, 1e-8 if tol <= 1e-8 else tol)
+            WORST[0], WORST[1] = max(WORST[0], worst_all), WORST[1] + nexc
             if DISCONTINUITIES:
                 ndisc += 1
                 print("discontinuity of the reference in case %d %s: %s" % (c, desc, DISCONTINUITIES), flush=True)
             if os.environ.get("FUZZ_VERBOSE"):
-                print("ok  %3d %s nsel~%d worst %.1e (%.0f s)" % (c, desc, nsel, worst, time.time() - t0), flush=True)
+                print("ok  %3d %s nsel~%d worst %.1e true worst %.1e excused %d (%.0f s)"
+                      % (c, desc, nsel, worst, worst_all, nexc, time.time() - t0), flush=True)
         except Exception:
             bad += 1
             print("BAD %3d %s" % (c, desc), flush=True)
             traceback.print_exc(limit=2)
-    print("fuzz: %d cases, %d failures, %d with a difference on a discontinuity of the reference, seed %d"
-          % (n, bad, ndisc, seed))
+    print("fuzz: %d cases, %d failures, %d with a difference on a discontinuity of the reference (%d models excused), "
+          "largest value error anywhere %.2e, seed %d" % (n, bad, ndisc, WORST[1], WORST[0], seed))
     return 1 if bad else 0
 
 
