@@ -1020,7 +1020,11 @@ k_fflux(const float *__restrict__ grid, int64_t nmodel, int64_t nmodel_pad, int 
             // degree-13 form until round 3 -- 19 instead of 15 operations per exponential --
             // for the sake of registers it turned out not to need: 215 -> 223 VGPRs, still
             // two waves per SIMD, k_fflux 1.12 -> 1.00 ms per 128 stars on configs[2])
+#ifdef BRUTUS_F0_FROM_TABLE        // (A/B build, profiles/r06_f0_table_ab.txt: 12 gathers instead of 12 exponentials)
+            if constexpr (!WIDE) load_F0<NB>(grid, nmodel_pad, i, F0);
+#else
             if constexpr (!WIDE) compute_F0_tbl<NB>(c, s_tbl, F0);
+#endif
             double av, rv, step, lnl_old;
             double R[RVF && !WIDE ? NB : 1];
             if constexpr (RVF && !WIDE) coef_R<NB>(c, p.rv_mean, R);
@@ -1354,7 +1358,11 @@ k_derive(const float *__restrict__ grid, int64_t nmodel_pad, int nstar,
         if (wave_live) {
             const StarPrep &sp = stars[s];
             double F0[WIDE ? 1 : NB];
+#ifdef BRUTUS_F0_FROM_TABLE
+            if constexpr (!WIDE) load_F0<NB>(grid, nmodel_pad, i0, F0);
+#else
             if constexpr (!WIDE) compute_F0_tbl<NB>(c, s_tbl, F0);
+#endif
             double av = p.av_mean, rv = p.rv_mean;
             const int K = k1[s];
             if constexpr (RVF) {
