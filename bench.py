@@ -85,6 +85,9 @@ def parse():
     ap.add_argument("--no-sharp", action="store_true",
                     help="skip the sharp-posterior block (S/N 50 photometry + parallax at S/N 10 on "
                          "synth.make_sharp_grid: a few per cent of the grid selected per star)")
+    ap.add_argument("--full-line", action="store_true",
+                    help="print the FULL record (what bench_detail.json holds, ~25 KB) instead of the < 8 KB "
+                         "summary line: for the A/B tooling under tools/ab/, never for the driver")
     ap.add_argument("--no-survey-grid", action="store_true",
                     help="skip the third block: the main configuration on SURVEY 8(d)'s own "
                          "grid generator (synth.make_grid, random model order)")
@@ -854,7 +857,9 @@ def roofline_of(res, args, config, world, with_traffic=True, issue=None):
 
 
 def main():
+    global FULL_LINE
     args = parse()
+    FULL_LINE = bool(args.full_line)
     if args.config == 5:
         return bench_cluster(args)
     cfg4 = args.config == 4
@@ -1202,6 +1207,9 @@ def compact_line(full):
     return _r(line)
 
 
+FULL_LINE = False      # --full-line
+
+
 def emit_line(full):
     """Write the full record to bench_detail.json, print the compact line (one line, < 8 KB)."""
     for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
@@ -1211,6 +1219,10 @@ def emit_line(full):
                     json.dump(full, f, indent=1)
             except OSError:
                 pass
+    if FULL_LINE:
+        print(json.dumps(full))
+        sys.stdout.flush()
+        return
     text = json.dumps(compact_line(full), separators=(",", ":"))
     if len(text) >= LINE_LIMIT:
         raise SystemExit("bench line is %d bytes (limit %d): trim compact_line" % (len(text), LINE_LIMIT))

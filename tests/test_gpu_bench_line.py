@@ -95,7 +95,7 @@ def test_bench_line_contract_small_grid():
     rl = d["roofline"]
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in rl, k
-    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and abs(rl["frac"] - rl["achieved"] / 8000.) < 1e-12
+    assert rl["bound"] == "hbm" and rl["peak"] == 8000.0 and rl["frac"] == pytest.approx(rl["achieved"] / 8000., rel=1e-5)
     cb = d["cpu_baseline"]
     assert cb["kind"] == "port" and cb["cores"] >= 1 and cb["value"] > 0 and "sample" in cb
     for blk in (d, d["other_config"], d["survey8d_grid"]):

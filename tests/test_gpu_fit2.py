@@ -232,8 +232,9 @@ def _adversarial_inputs(case, S=8):
     tol = 1e-7 if o.get("frac", 1.) <= 1e-3 else 1e-9     # (chi2 up to 1e9 at S/N 1e4)
     if "av" in o:
         # (Av 19.5 at S/N 100: the two float64 pipelines' Av differ by 4e-14 relative, and
-        # d chi2 / d Av ~ 2 sqrt(chi2 sum (S/N)^2) R ~ 3e3 turns that into 2e-9 of lnl)
-        tol = max(tol, 1e-8)
+        # d chi2 / d Av ~ 2 sqrt(chi2 sum (S/N)^2) R ~ 3e3 turns that into 2e-9 .. 1.5e-8 of lnl,
+        # seen over 20 stars)
+        tol = max(tol, 1e-7)
     return models, st, o.get("kw", dict()), tol
 
 
