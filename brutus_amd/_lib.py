@@ -8,15 +8,16 @@ import ctypes as C
 import os
 
 __all__ = ["lib", "Params", "PostParams", "check", "LIB_PATH", "BrutusError", "NVALS",
-           "MAX_BATCH", "MAX_FILT"]
+           "MAX_BATCH", "MAX_FILT", "MAX_FILT_FIT"]
 
 # BRUTUS_AMD_LIB: another build of the same library (A/B kernel timing)
 LIB_PATH = os.environ.get("BRUTUS_AMD_LIB") or os.path.join(
     os.path.dirname(os.path.abspath(__file__)), "libbrutus_amd.so")
 NVALS = 11
-ABI_VERSION = 3
+ABI_VERSION = 4
 MAX_BATCH = 256
-MAX_FILT = 32
+MAX_FILT = 64          # bands per call (full-grid pipeline); include/brutus_amd.h
+MAX_FILT_FIT = 32      # bands the hot path (brutus_fit_batch) takes at once
 
 _lib = None
 

@@ -66,7 +66,9 @@ namespace {
 // ---------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------
-const int kCompiledNB[] = {8, 12, 16, 24, 32};
+// (48, 64: the full-grid pipeline only -- brutus_loglike_batch; the hot path's list kernels hold
+// 5 NB values per lane and stop at BRUTUS_MAX_FILT_FIT = 32, where they already run one wave per SIMD)
+const int kCompiledNB[] = {8, 12, 16, 24, 32, 48, 64};
 
 int padded_nb(int nfilt) {
     for (int nb : kCompiledNB)
@@ -381,6 +383,8 @@ int dispatch_pipeline(int nb, const float *grid, int64_t nmodel, int nstar, cons
         case 16: return run_pipeline<16>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
         case 24: return run_pipeline<24>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
         case 32: return run_pipeline<32>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
+        case 48: return run_pipeline<48>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
+        case 64: return run_pipeline<64>(grid, nmodel, nstar, p, max_iter, w, h_k1, h_k2, st, tm, av_init, rv_init);
 #endif
     }
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
@@ -1270,6 +1274,9 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
 #endif
     }
 #undef BRUTUS_CASE
+    if (nb > BRUTUS_MAX_FILT_FIT)
+        return fail(BRUTUS_EINVAL, "brutus_fit_batch fits at most %d bands at once (%d given): take the full-grid "
+                                   "outputs of brutus_loglike_batch and cut on them", BRUTUS_MAX_FILT_FIT, nfilt);
     return fail(BRUTUS_EINVAL, "unsupported band count %d", nb);
 }
 
@@ -1460,6 +1467,8 @@ static int cluster_part(int nobj, int nfilt, int npts, const double *d_pts_flux,
         BRUTUS_CL(24)
         BRUTUS_CL(32)
 #endif
+        default:
+            return fail(BRUTUS_EINVAL, "cluster likelihood: at most %d bands (%d given)", BRUTUS_MAX_FILT_FIT, nfilt);
     }
 #undef BRUTUS_CL
     tm.end();

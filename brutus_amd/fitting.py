@@ -29,7 +29,7 @@ import os
 import numpy as np
 
 from . import _lib
-from .pdf import (imf_lnprior, parallax_lnprior, ps1_MrLF_lnprior,
+from .pdf import (imf_lnprior, parallax_lnprior, parallax_to_scale, ps1_MrLF_lnprior,
                   scale_parallax_lnprior)
 from .utils import _inverse3, magnitude, sample_multivariate_normal
 
@@ -92,8 +92,8 @@ def _bands_in_use(data_mask, nfilt):
     of the call uses never enters a result: compacting the grid to the used bands changes
     nothing but the amount of work -- and lets a grid file with all 49 filters
     (`load_models(filters=None)`, utils.py:575-576) be fitted with the data's few bands.
-    Compaction happens when it saves a padded band count or is needed to fit the kernels'
-    32-band limit."""
+    Compaction happens when it saves a padded band count (8 / 12 / 16 / 24 / 32 for the hot
+    path, 48 / 64 for the full-grid route) or is needed to fit the 64-band limit."""
     used = np.asarray(data_mask, dtype=bool).reshape(-1, nfilt).any(axis=0)
     nused = int(used.sum())
     if nused == nfilt or nused == 0:
@@ -203,6 +203,11 @@ class _Engine(object):
         nb = int(max(1, min(_lib.MAX_BATCH, mem_budget // per_star)))
         if max_batch is not None:
             nb = max(1, min(nb, int(max_batch)))
+        # more than 32 bands: the full-grid route (fit_batch_device below) holds eleven float64
+        # planes per star on top of the pipeline's workspace
+        self.wide = self.L.brutus_padded_filters(grid.nfilt) > _lib.MAX_FILT_FIT
+        if self.wide:
+            nb = int(max(1, min(nb, mem_budget // (260 * grid.nmodel + 65536))))
         self.batch = nb
         self._ws = None
         self._ws_batch = 0
@@ -296,6 +301,8 @@ class _Engine(object):
         steady stream of batches settles after the first) -- `self.regrown` counts that."""
         torch, L, g = self.torch, self.L, self.grid
         S = f.shape[0]
+        if self.wide:
+            return self._fit_batch_device_full_grid(f, e, m, p, pe, has_par, params)
         ws = self._workspace(S)
         if buffers is None:
             buffers = getattr(self, "_rec_bufs", None)
@@ -332,6 +339,66 @@ class _Engine(object):
         rv_const = (float(params.rv_gauss[0])
                     if params.rvlim[0] == params.rvlim[1] == params.rv_gauss[0] else None)
         return Records(idx, slot, vals, off, rv_const, counts), ndim, k1, k2
+
+    def _fit_batch_device_full_grid(self, f, e, m, p, pe, has_par, params, chunk=8):
+        """`fit_batch_device` for more than 32 bands (33 - 64): the hot path's list kernels stop at
+        32, the full-grid pipeline (`brutus_loglike_batch`: every model in float64) does not.  Its
+        outputs stay on the device, the parallax clip + first `wt_thresh` cut of `lnpost`
+        (reference fitting.py:976-991, pdf.py:209-218) are taken there too, and the selected models
+        come back as dense `Records` in ascending model order -- everything downstream (device
+        `lnpost`, host stage, HDF5) is the same code as for any other band count.  Slower per star
+        by the work the float32 proof saves, not by a different result."""
+        torch, L, g = self.torch, self.L, self.grid
+        S = f.shape[0]
+        dev = g.device
+        kw = dict(dtype=torch.float64, device=dev)
+        ln_wt = float(np.log(params.wt_thresh))
+        k1 = np.zeros(S, dtype=np.int32)
+        k2 = np.zeros(S, dtype=np.int32)
+        ndim = torch.empty(S, dtype=torch.int32, device=dev)
+        par_h = p.cpu().numpy() if p is not None else np.full(S, np.nan)
+        perr_h = pe.cpu().numpy() if pe is not None else np.full(S, np.nan)
+        idx_parts, val_parts, counts = [], [], np.zeros(S, dtype=np.int64)
+        with torch.cuda.device(dev):
+            for a in range(0, S, chunk):
+                b = min(S, a + chunk)
+                n = b - a
+                ws = self._workspace(n)
+                out = torch.empty((5 + 6, n, g.nmodel), **kw)      # lnl chi2 scale av rv | icov[6]
+                k1c, k2c = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+                _lib.check(L.brutus_loglike_batch(
+                    g.soa.data_ptr(), g.nmodel, g.nfilt, n, f[a:b].data_ptr(), e[a:b].data_ptr(),
+                    m[a:b].data_ptr(), p[a:b].data_ptr() if p is not None else None,
+                    pe[a:b].data_ptr() if pe is not None else None, has_par, params,
+                    ws.data_ptr(), ws.numel(), out[0].data_ptr(), out[1].data_ptr(),
+                    out[2].data_ptr(), out[3].data_ptr(), out[4].data_ptr(), out[5].data_ptr(),
+                    ndim[a:b].data_ptr(), k1c.ctypes.data, k2c.ctypes.data, None, None,
+                    _stream_ptr(torch)))
+                k1[a:b], k2[a:b] = k1c, k2c
+                for s in range(n):
+                    lnprob = out[0, s]
+                    pm, ps = float(par_h[a + s]), float(perr_h[a + s])
+                    if has_par and np.isfinite(pm) and np.isfinite(ps) and pm / ps > 4.:
+                        s_mean, s_std = parallax_to_scale(pm, ps)
+                        serr = 1. / torch.sqrt(out[5, s].abs())               # fitting.py:976-981
+                        var = float(s_std) ** 2 + serr ** 2
+                        lnprob = lnprob - 0.5 * ((out[2, s] - float(s_mean)) ** 2 / var
+                                                 + torch.log(2. * np.pi * var))
+                    lnprob = torch.where(torch.isfinite(lnprob), lnprob,
+                                         torch.full_like(lnprob, -1e300))
+                    sel = torch.nonzero(lnprob > ln_wt + lnprob.max()).reshape(-1)
+                    counts[a + s] = int(sel.numel())
+                    idx_parts.append(sel.to(torch.int32))
+                    val_parts.append(out[:, s, :].index_select(1, sel))
+                del out
+        off = torch.zeros(S + 1, dtype=torch.int64, device=dev)
+        off[1:] = torch.from_numpy(np.cumsum(counts)).to(dev)
+        idx = torch.cat(idx_parts) if idx_parts else torch.empty(0, dtype=torch.int32, device=dev)
+        vals = torch.cat(val_parts, dim=1).contiguous() if val_parts else torch.empty((_lib.NVALS, 0), **kw)
+        rec = Records.dense(idx, vals, off)
+        ntot = int(counts.sum())
+        rec.counts = np.array([ntot, ntot, ntot], dtype=np.int64)
+        return rec, ndim, k1, k2
 
     def records_device(self, f, e, m, p, pe, has_par, params):
         """`fit_batch_device` plus the host copies the callers need:

@@ -35,8 +35,11 @@
 extern "C" {
 #endif
 
-#define BRUTUS_ABI_VERSION 3
-#define BRUTUS_MAX_FILT 32   /* bands per fit (device register budget)            */
+#define BRUTUS_ABI_VERSION 4
+#ifndef BRUTUS_MAX_FILT      /* (overridable for A/B builds of the library only: it sizes the per-star blocks) */
+#define BRUTUS_MAX_FILT 64   /* bands per call: brutus_loglike_batch (full-grid outputs), offsets */
+#endif
+#define BRUTUS_MAX_FILT_FIT 32 /* bands per brutus_fit_batch / cluster call (register budget of the list kernels) */
 #define BRUTUS_MAX_BATCH 256 /* stars per brutus_*_batch call                     */
 #define BRUTUS_NVALS 11      /* lnlike, chi2, scale, av, rv, icov[00,01,02,11,12,22] */
 
@@ -74,7 +77,8 @@ const char *brutus_last_error(void);
  * loads, and a model-major [nmodel_pad][nfilt_pad][3] copy for the kernels
  * that gather single models -- followed by the band-major float64 table of
  * unreddened model fluxes 10^(-0.4 mag) (fitting.py:529).
- * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters),
+ * nfilt_pad = the compiled band count >= nfilt (see brutus_padded_filters: 8, 12, 16, 24, 32 and,
+ * for brutus_loglike_batch only, 48 and 64),
  * nmodel_pad = nmodel rounded up to 256.  Padded entries are zero. */
 int brutus_padded_filters(int nfilt);              /* <0 if nfilt unsupported     */
 size_t brutus_grid_soa_bytes(int64_t nmodel, int nfilt);

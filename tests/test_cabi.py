@@ -97,13 +97,14 @@ def test_hot_kernels_do_not_spill():
 def test_abi_version_and_queries():
     from brutus_amd import _lib
     L = _lib.lib()
-    assert L.brutus_abi_version() == _lib.ABI_VERSION == 3
+    assert L.brutus_abi_version() == _lib.ABI_VERSION == 4
     assert L.brutus_padded_filters(6) == 8
     assert L.brutus_padded_filters(12) == 12
-    assert L.brutus_padded_filters(33) < 0
+    assert L.brutus_padded_filters(33) == 48 and L.brutus_padded_filters(64) == 64     # full-grid pipeline only
+    assert L.brutus_padded_filters(65) < 0
     assert L.brutus_grid_soa_bytes(1000, 12) == 8 * 12 * 1024 * 4
     assert L.brutus_workspace_bytes(750000, 12, 64) > 28 * 750000 * 64
-    assert L.brutus_workspace_bytes(750000, 40, 64) == 0
+    assert L.brutus_workspace_bytes(750000, 70, 64) == 0
 
 
 def test_product_refuses_to_run_without_gpu():

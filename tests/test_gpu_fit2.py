@@ -108,7 +108,11 @@ def _audit(eng, nmodel, nfilt, S):
         _lib.check(L.brutus_debug_copy(ws.data_ptr(), ws.numel(), nmodel, nfilt, S, which,
                                        t.data_ptr(), t.numel() * 4, None))
     torch.cuda.synchronize()
-    return aud.cpu().numpy(), s32[:, 4 * 32 + 9].cpu().numpy()
+    # Star32 (pre32_types.hpp): four float arrays of BRUTUS_MAX_FILT bands, then S, DD2, gbar, par,
+    # par_ivar, sp_mean, sp_var, c0, c1, eps (index 9), epsw, chi2_lo and three ints
+    nbmax = (n32 - 15) // 4
+    assert 4 * nbmax + 15 == n32
+    return aud.cpu().numpy(), s32[:, 4 * nbmax + 9].cpu().numpy()
 
 
 @pytest.mark.parametrize("kw", [dict(), dict(rvlim=(3.32, 3.32)), dict(ltol=3e-3),

@@ -217,6 +217,36 @@ def test_device_lnpost_shared_stream_vs_oracle():
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
 
 
+@pytest.mark.parametrize("nfilt", [40, 64])
+def test_more_than_32_bands_fit_vs_oracle(nfilt):
+    """33 - 64 bands unmasked at once: `_fit` takes the full-grid pipeline, cuts on the device and
+    hands dense records to the same device `lnpost` as any other band count -- against the oracle
+    driven by the same counter-based stream: resampled indices bit-exact, two batches (the second
+    ragged), a masked pair of bands, a negative flux."""
+    from brutus_amd import fitting, synth
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    models, labels, lmask = synth.make_grid(6000, nfilt, seed=40 + nfilt)
+    st = synth.make_stars(models, 5, seed=41)
+    st["mask"][1, [3, nfilt - 2]] = False
+    st["flux"][2, 5] = -abs(st["flux"][2, 5])
+    BF = fitting.BruteForce(models, labels, lmask)
+    lnprior = O.static_lnprior(labels, lmask)
+    BF.batch_size = 3
+    rs = PhiloxRandomState(9)
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=20, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60, rstate=rs))
+    ro = PhiloxRandomState(9)
+    for i in range(len(dev)):
+        ref = O.fit_star(st["flux"][i], st["err"][i], st["mask"][i], models, lnprior,
+                         labels, st["coords"][i], st["parallax"][i],
+                         st["parallax_err"][i], ro, gal_lnprior, Nmc_prior=20, Ndraws=60)
+        _compare(dev[i], ref, i)
+    assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
 @pytest.mark.parametrize("lims", [dict(rvlim=(3.32, 3.32), rv_gauss=(3.32, 1e-6)),
                                   dict(rvlim=(3.32, 3.32), rv_gauss=(3.32, 1e-6), avlim=(-30., 50.))])
 def test_device_lnpost_unseen_normal_runs_vs_oracle(lims):

@@ -540,6 +540,27 @@ def test_shapes_and_padding_edge_cases(nmodel, nfilt, nstar):
         assert relerr(sc[sel], recs[i]["scale"]) < RTOL
 
 
+@pytest.mark.parametrize("nfilt", [40, 49, 64])
+def test_more_than_32_bands_in_one_call(nfilt):
+    """33 - 64 bands unmasked at once (the reference takes any number, fitting.py:709-716; its
+    filter list has 49 names): `loglike` against the C restatement over the whole grid (the `_fit`
+    path of these band counts: tests/test_gpu_lnpost.py)."""
+    from brutus_amd import fitting, synth
+    from oracle import c_oracle
+    models, labels, lmask = synth.make_grid(6000, nfilt, seed=40 + nfilt)
+    st = synth.make_stars(models, 5, seed=41)
+    st["mask"][1, [3, nfilt - 2]] = False
+    st["flux"][2, 5] = -abs(st["flux"][2, 5])
+    grid = fitting.DeviceGrid(models)
+    for i in range(3):
+        par, pe = st["parallax"][i], st["parallax_err"][i]
+        got = fitting.loglike(st["flux"][i], st["err"][i], st["mask"][i], grid, parallax=par,
+                              parallax_err=pe, return_vals=True)
+        ref = c_oracle.loglike(st["flux"][i], st["err"][i], st["mask"][i], models, parallax=par,
+                               parallax_err=pe)
+        _cmp_loglike(got, ref, "wide %d" % i)
+
+
 def test_argument_errors():
     from brutus_amd import fitting, synth
     models, _, _ = synth.make_grid(300, 6, seed=1)
@@ -550,11 +571,11 @@ def test_argument_errors():
     with pytest.raises(TypeError):
         fitting.loglike(f, e, m, models, init_thresh=None)
     with pytest.raises(ValueError, match="filters"):
-        fitting.DeviceGrid(np.zeros((10, 33, 3), np.float32))
-    # more than 32 bands UNMASKED in one call is the only band count that is refused
+        fitting.DeviceGrid(np.zeros((10, 65, 3), np.float32))
+    # more than 64 bands UNMASKED in one call is the only band count that is refused
     with pytest.raises(ValueError, match="filters"):
-        fitting.loglike(np.ones(40), np.ones(40), np.ones(40, bool),
-                        np.zeros((10, 40, 3), np.float32))
+        fitting.loglike(np.ones(70), np.ones(70), np.ones(70, bool),
+                        np.zeros((10, 70, 3), np.float32))
     with pytest.raises(ValueError, match="bands"):
         fitting.loglike(f[:5], e[:5], m[:5], models)
 
