@@ -1238,7 +1238,7 @@ int dispatch_fit(int nb, int nfilt, const float *grid, int64_t nmodel, int nstar
     const bool hostdriven = env_int("BRUTUS_FIT_HOSTDRIVEN", 0) != 0;
     {
         const long long call_no = g_fit_calls.fetch_add(1);
-        const int every = env_int("BRUTUS_AUDIT_EVERY", 256);
+        const int every = env_int("BRUTUS_AUDIT_EVERY", 64);
         t_audit_call = every > 0 && call_no % every == 0;
     }
 #define BRUTUS_CASE(N)                                                                             \

@@ -132,7 +132,7 @@ int brutus_loglike_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
  * already [1] > capacity: then [2] is an estimate): call again with larger buffers.
  * Float32 never produces an output value or a decision here, it only proves models to be below
  * the thresholds; the error bound that rests on is AUDITED on the first call of a process and
- * every BRUTUS_AUDIT_EVERY-th (environment, default 256; 0 = never) after it -- every pair the
+ * every BRUTUS_AUDIT_EVERY-th (environment, default 64; 0 = never) after it -- every pair the
  * call re-evaluates in float64 anyway is compared with its float32 value -- and a call whose
  * audit finds |float32 - float64| >= the bound fails with BRUTUS_EPRECISION. */
 int brutus_fit_batch(const float *d_grid_soa, int64_t nmodel, int nfilt,
