@@ -20,10 +20,12 @@ def _free_port():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world", [2, 3, 4])
-def test_fit_sharded_equals_unsharded(world):
+@pytest.mark.parametrize("world,writer", [(2, "rank0"), (3, "rank0"), (4, "rank0"), (3, "per_rank")])
+def test_fit_sharded_equals_unsharded(world, writer):
+    """(`writer="per_rank"`: every rank its own part file, the index of virtual datasets read back
+    on rank 0 -- same comparison.)"""
     env = dict(os.environ, BRUTUS_BENCH_ONE_DEVICE="1", BRUTUS_BENCH_BACKEND="gloo",
-               MASTER_ADDR="127.0.0.1")
+               MASTER_ADDR="127.0.0.1", SHARDED_WRITER=writer)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
            "--nproc-per-node", str(world), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()),

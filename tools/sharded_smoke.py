@@ -45,8 +45,9 @@ def main():
     box = [tmp]
     dist.broadcast_object_list(box, src=0)
     path = os.path.join(box[0], "sharded")
+    writer = os.environ.get("SHARDED_WRITER", "rank0")       # "per_rank": part files + virtual index
     n = parallel.fit_sharded(bf, st["flux"], st["err"], st["mask"], np.arange(nstar), path,
-                             seed0=500, **kw)
+                             seed0=500, writer=writer, **kw)
     lo, hi = parallel.shard_range(nstar, rank, world)
     assert n == hi - lo
     if rank == 0:
@@ -68,7 +69,9 @@ def main():
             assert np.array_equal(idx[i], r[0]), i
             assert np.allclose(post[i], r[6].astype(np.float32), rtol=1e-6, atol=0), i
             assert np.allclose(dist_s[i], r[9].astype(np.float32), rtol=1e-6, atol=0), i
-        print("sharded_smoke ok: %d ranks, %d objects, file == unsharded run" % (world, nstar))
+        if writer == "per_rank":
+            assert len([x for x in os.listdir(box[0]) if x.startswith("sharded.r")]) == world
+        print("sharded_smoke ok: %d ranks, %d objects, file == unsharded run (writer %s)" % (world, nstar, writer))
     dist.barrier()
     dist.destroy_process_group()
 
