@@ -204,6 +204,11 @@ def fit_sharded(bf, data, data_err, data_mask, data_labels, save_file,
     if per_rank and rank == 0 and hi == lo:
         owner = False
     open_error = None
+    if per_rank and rank == 0 and not resume and os.path.exists("{0}.h5".format(save_file)):
+        # the index is written LAST; that it cannot be created ("w-", reference fitting.py:1632)
+        # is said now, not after the whole catalogue has been fitted
+        open_error = OSError("fit_sharded: %s.h5 exists already" % save_file)
+        owner = False
     if owner:
         try:
             if resume:

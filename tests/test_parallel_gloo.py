@@ -483,6 +483,11 @@ def test_fit_sharded_file_that_cannot_be_created_stops_every_rank(tmp_path):
     res = [open(os.path.join(tmp, "ex_%d.txt" % r)).read() for r in range(3)]
     assert res[0].startswith("own OSError"), res
     assert all(r.startswith("remote") and "rank(s) 0" in r for r in res[1:]), res
+    open(os.path.join(tmp, "ez.h5"), "w").close()            # per-rank parts: the INDEX exists already
+    mp.spawn(_worker_resume, args=(2, _free_port(), tmp, "ez", None, False, "per_rank"), nprocs=2, join=True)
+    res = [open(os.path.join(tmp, "ez_%d.txt" % r)).read() for r in range(2)]
+    assert res[0].startswith("own OSError") and res[1].startswith("remote"), res
+    assert not [f for f in os.listdir(tmp) if f.startswith("ez.r")]      # nothing was fitted, no part left behind
     open(os.path.join(tmp, "ey.r01.h5"), "w").close()
     mp.spawn(_worker_resume, args=(3, _free_port(), tmp, "ey", None, False, "per_rank"), nprocs=3, join=True)
     res = [open(os.path.join(tmp, "ey_%d.txt" % r)).read() for r in range(3)]
