@@ -1108,6 +1108,8 @@ def _roofline_short(rl, top=4):
                      "traffic_stale", "algorithmic_bytes_per_star", "measured_stream_gbs",
                      "dominant_kernel", "sum_of_kernels_ms_per_sub_batch"))
     out["launch_unit"] = "brutus_fit_batch (one sub-batch call): achieved = stars/s x 108.0 MB"
+    if rl.get("traffic"):
+        out["traffic_is"] = "PMC HBM bytes (FETCH_SIZE + WRITE_SIZE, corrected) per step = all sub-batch calls of it"
     if rl.get("valu"):
         v = rl["valu"]
         out["valu"] = dict(_pick(v, ("frac", "issue_ms_per_call", "call_ms", "stale")),
