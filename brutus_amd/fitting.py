@@ -192,6 +192,15 @@ class Records(object):
         return idx, vals
 
 
+class _RowBlock(object):
+    """The finished rows of one batch as `fit()` writes them: objects `start .. start + n` of the
+    call, `arrays[dataset]` = (n, ...) in the results file's layout (h5io.ResultsFile)."""
+    __slots__ = ("start", "n", "arrays")
+
+    def __init__(self, start, n, arrays):
+        self.start, self.n, self.arrays = start, n, arrays
+
+
 class _Engine(object):
     """Owns the device workspace and drives the *_batch entry points."""
 
@@ -1149,8 +1158,18 @@ class BruteForce(object):
                             logl_initthresh=logl_initthresh, ltol=ltol,
                             mem_lim=mem_lim)
             Ndata = data.shape[0]
-            for i, results in enumerate(gen):
-                out.write_row(i if todo is None else int(todo[i]), results)
+            # whole batches where the device stage produced them (a resumed run maps rows one by one)
+            self._yield_row_blocks = todo is None
+            i = -1
+            for results in gen:
+                if isinstance(results, _RowBlock):
+                    out.write_block(results.start, results.arrays)
+                    i = results.start + results.n - 1
+                    results = (None,) * 5 + (int(results.arrays["obj_Nbands"][-1]), None, None,
+                                             float(results.arrays["obj_chi2min"][-1]))
+                else:
+                    i += 1
+                    out.write_row(i if todo is None else int(todo[i]), results)
                 if verbose:
                     t_avg = (time.time() - t0) / (i + 1)
                     t_est = t_avg * (Ndata - i - 1)
@@ -1166,6 +1185,7 @@ class BruteForce(object):
                 sys.stderr.write('\n')
                 sys.stderr.flush()
         finally:
+            self._yield_row_blocks = False
             out.close()
 
     # -- per-star generator (reference fitting.py:1803-2065) ------------------
@@ -1471,7 +1491,31 @@ class BruteForce(object):
 
         def rows(a, S, rec, off, ndim, k1, k2, out_idx, out_vals, star_out, flags,
                  nbase, ubase0, pre=None):
-            """The tuples `_fit` yields for the objects of one batch."""
+            """The tuples `_fit` yields for the objects of one batch -- or, for `fit()` (which only
+            wants the rows in the file: `self._yield_row_blocks`), the whole batch as ONE `_RowBlock`
+            of arrays in the file's layout: 128 tuples of 13 slices per batch are 1.2 ms of Python,
+            a third of `fit()`'s time where the posteriors are sharp."""
+            if (getattr(self, "_yield_row_blocks", False) and not np.any(flags[:S])
+                    and np.all(star_out[:S, 3] >= 1)):
+                v = out_vals[:S]
+                fin = np.isfinite(parallax[a:a + S]) & np.isfinite(parallax_err[a:a + S])
+                f4 = np.float32
+                with np.errstate(over="ignore"):   # -1e300 (out-of-bounds draw) -> -inf in f32, as h5py does
+                    # one contiguous pass to the file's float32; the per-dataset planes are VIEWS of it
+                    # (stride 13 or 17): the results writer's thread gathers them when it writes
+                    v4 = v.astype(f4)
+                    arr = {"model_idx": out_idx[:S].astype(np.int32),
+                           "ml_scale": v4[:, :, 0], "ml_av": v4[:, :, 1], "ml_rv": v4[:, :, 2],
+                           "ml_cov_sar": v4[:, :, 3:12].reshape(S, v4.shape[1], 3, 3),
+                           "obj_Nbands": (np.asarray(ndim[:S]).astype(np.int64) + fin).astype(np.int16),
+                           "obj_log_post": v4[:, :, 12],
+                           "obj_log_evid": star_out[:S, 0].astype(f4),
+                           "obj_chi2min": star_out[:S, 1].astype(f4)}
+                    if return_distreds:
+                        for q, name in enumerate(("samps_dist", "samps_red", "samps_dred", "samps_logp")):
+                            arr[name] = v4[:, :, 13 + q]
+                yield _RowBlock(a, S, arr)
+                return
             for s in range(S):
                 i = a + s
                 if flags[s]:

@@ -2,6 +2,8 @@
 reference semantics.  The random stream is brutus_amd/rng.PhiloxRandomState, a
 valid `rstate` object for the reference/oracle, so the device result is compared
 with the ORACLE run on the same `rstate` -- indices bit-exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -215,6 +217,42 @@ def test_device_lnpost_shared_stream_vs_oracle():
         _compare(dev[i], ref, i)
     # the device advanced the caller's rstate exactly like the host would have
     assert (rs.n_normal, rs.n_uniform) == (ro.n_normal, ro.n_uniform)
+
+
+@pytest.mark.parametrize("stream", ["philox", "numpy"])
+def test_fit_writes_whole_batches_like_rows(tmp_path, stream):
+    """`fit()` takes the device stage's results a batch at a time (`_RowBlock`: arrays in the file's
+    layout) instead of 13-tuples per object: the file must equal, dataset by dataset, the one
+    written row by row from `_fit`'s tuples -- ragged last batch, an object without parallax,
+    `running_io` on and off."""
+    from brutus_amd import h5io
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    BF, models, labels, st, lnprior = _setup()
+    n = st["flux"].shape[0]
+    BF.batch_size = 5
+    mk = (lambda: PhiloxRandomState(5)) if stream == "philox" else (lambda: np.random.RandomState(5))
+    kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
+              lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60)
+    for rio in (True, False):
+        path = os.path.join(str(tmp_path), "blk_%s_%d" % (stream, rio))
+        BF.fit(st["flux"], st["err"], st["mask"], np.arange(n), path, rstate=mk(), verbose=False,
+               running_io=rio, **kw)
+        assert BF._yield_row_blocks is False
+        ref = h5io.ResultsFile(path + "_rows.h5", n, 60, np.arange(n), True, running_io=rio)
+        (d, e, m, _, coords, lnp_, lng, lnd, avg, wt, _) = BF._setup(
+            st["flux"], st["err"], st["mask"], np.arange(n), parallax=st["parallax"],
+            parallax_err=st["parallax_err"], data_coords=st["coords"], lngalprior=gal_lnprior)
+        for i, row in enumerate(BF._fit(d, e, m, parallax=st["parallax"], parallax_err=st["parallax_err"],
+                                        lnprior=lnp_, lngalprior=lng, lndustprior=lnd, av_gauss=avg,
+                                        wt_thresh=wt, data_coords=coords, Nmc_prior=20, Ndraws=60,
+                                        rstate=mk())):
+            assert isinstance(row, tuple) and len(row) == 13
+            ref.write_row(i, row)
+        ref.close()
+        for k in h5io.list_datasets(path + ".h5"):
+            a, b = h5io.read_dataset(path + ".h5", k), h5io.read_dataset(path + "_rows.h5", k)
+            assert a.dtype == b.dtype and np.array_equal(a, b, equal_nan=(a.dtype.kind == "f")), (k, rio)
 
 
 @pytest.mark.parametrize("nfilt", [40, 64])
