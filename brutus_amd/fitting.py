@@ -210,6 +210,8 @@ class _Engine(object):
         self.grid = grid
         per_star = 104 * grid.nmodel + 65536       # workspace + records / full-grid outputs
         nb = int(max(1, min(_lib.MAX_BATCH, mem_budget // per_star)))
+        if nb >= 64:
+            nb -= nb % 64      # the star-lane float32 pass fills its waves with 64 stars each
         if max_batch is not None:
             nb = max(1, min(nb, int(max_batch)))
         # more than 32 bands: the full-grid route (fit_batch_device below) holds eleven float64
