@@ -304,7 +304,7 @@ class _Engine(object):
                 torch.empty(capacity, dtype=torch.int32, device=g.device),
                 torch.empty((_lib.NVALS, capacity), dtype=torch.float64, device=g.device))
 
-    def fit_batch_device(self, f, e, m, p, pe, has_par, params, buffers=None, grow=True):
+    def fit_batch_device(self, f, e, m, p, pe, has_par, params, buffers=None, grow=True, ext=None):
         """Device-resident inputs -> device-resident indexed records (`Records`).
         Returns (records, ndim tensor, k1, k2).  `buffers` = (idx, slot, vals) tensors to
         write into (default: the engine's own, kept between calls).  When they are too
@@ -312,8 +312,8 @@ class _Engine(object):
         steady stream of batches settles after the first) -- `self.regrown` counts that."""
         torch, L, g = self.torch, self.L, self.grid
         S = f.shape[0]
-        if self.wide:
-            return self._fit_batch_device_full_grid(f, e, m, p, pe, has_par, params)
+        if self.wide or ext is not None:
+            return self._fit_batch_device_full_grid(f, e, m, p, pe, has_par, params, ext=ext)
         ws = self._workspace(S)
         if buffers is None:
             buffers = getattr(self, "_rec_bufs", None)
@@ -351,14 +351,21 @@ class _Engine(object):
                     if params.rvlim[0] == params.rvlim[1] == params.rv_gauss[0] else None)
         return Records(idx, slot, vals, off, rv_const, counts), ndim, k1, k2
 
-    def _fit_batch_device_full_grid(self, f, e, m, p, pe, has_par, params, chunk=8):
+    def _fit_batch_device_full_grid(self, f, e, m, p, pe, has_par, params, chunk=8, ext=None):
         """`fit_batch_device` for more than 32 bands (33 - 64): the hot path's list kernels stop at
         32, the full-grid pipeline (`brutus_loglike_batch`: every model in float64) does not.  Its
         outputs stay on the device, the parallax clip + first `wt_thresh` cut of `lnpost`
         (reference fitting.py:976-991, pdf.py:209-218) are taken there too, and the selected models
         come back as dense `Records` in ascending model order -- everything downstream (device
         `lnpost`, host stage, HDF5) is the same code as for any other band count.  Slower per star
-        by the work the float32 proof saves, not by a different result."""
+        by the work the float32 proof saves, not by a different result.
+
+        `ext` = [(label column (Nmodel,) float64 on the device, means (S,), stds (S,))]: external
+        per-object Gaussian constraints on model labels (`lnprior_ext`, reference
+        fitting.py:1995-2009) -- they change lnlike over the WHOLE grid before the cut, which is
+        why they take this route at any band count: `lnlike += -((label - mean)^2 / std^2 + ln(2
+        pi std^2)) / 2` on the device, then the cut; the records carry the sum like the
+        reference's `results`."""
         torch, L, g = self.torch, self.L, self.grid
         S = f.shape[0]
         dev = g.device
@@ -387,6 +394,11 @@ class _Engine(object):
                     _stream_ptr(torch)))
                 k1[a:b], k2[a:b] = k1c, k2c
                 for s in range(n):
+                    for lab, means, stds in (ext or ()):
+                        mean, std = float(means[a + s]), float(stds[a + s])
+                        if np.isfinite(mean) and std > 0:
+                            ivar = 1. / std ** 2
+                            out[0, s] += -0.5 * ((lab - mean) ** 2 * ivar + float(np.log(2. * np.pi * std ** 2)))
                     lnprob = out[0, s]
                     pm, ps = float(par_h[a + s]), float(perr_h[a + s])
                     if has_par and np.isfinite(pm) and np.isfinite(ps) and pm / ps > 4.:
@@ -411,10 +423,10 @@ class _Engine(object):
         rec.counts = np.array([ntot, ntot, ntot], dtype=np.int64)
         return rec, ndim, k1, k2
 
-    def records_device(self, f, e, m, p, pe, has_par, params):
+    def records_device(self, f, e, m, p, pe, has_par, params, ext=None):
         """`fit_batch_device` plus the host copies the callers need:
         (records, off, ndim, k1, k2)."""
-        rec, ndim, k1, k2 = self.fit_batch_device(f, e, m, p, pe, has_par, params)
+        rec, ndim, k1, k2 = self.fit_batch_device(f, e, m, p, pe, has_par, params, ext=ext)
         return rec, rec.off.cpu().numpy(), ndim.cpu().numpy(), k1, k2
 
     def post_batch_device(self, rec, nstar, statics,
@@ -1267,6 +1279,7 @@ class BruteForce(object):
                               wt_thresh=wt_thresh)
         step = (eng.batch if lnprior_ext is None and not cdf_mode
                 else max(1, min(eng.batch, 8)))
+        step_device = eng.batch
         from .rng import PhiloxRandomState
         philox_per_object = (seed0 is not None and isinstance(rstate_per_object, str)
                              and rstate_per_object == "philox")
@@ -1301,7 +1314,7 @@ class BruteForce(object):
                 dust_tables = lambda a, b: (first if (a, b) == (0, b0) else
                                             _pdf.los_tables(dustfile, data_coords[a:b]))
         dust_ok = (not apply_av_prior and lndustprior is None) or dust_tables is not None
-        if (self.device_lnpost and lnprior_ext is None and dust_ok
+        if (self.device_lnpost and dust_ok
                 and wt_thresh is not None and wt_thresh > 0
                 and getattr(lngalprior, "device_params", None) is not None
                 and Ndraws <= 4096
@@ -1310,13 +1323,22 @@ class BruteForce(object):
                          and rstate_per_object is None)
                      or (np_mode is not None and self.device_numpy_rng))):
             philox = philox_per_object or isinstance(rstate, PhiloxRandomState)
+            ext = None
+            if lnprior_ext is not None:
+                # external per-object constraints on labels (fitting.py:1995-2009): the label
+                # columns go to the device once, the cut follows the full-grid pipeline there
+                torch = eng.torch
+                ext = [(torch.from_numpy(np.ascontiguousarray(self.models_labels[k], dtype=np.float64)
+                                         ).to(eng.grid.device),
+                        np.asarray(lnprior_ext[k], dtype=np.float64).reshape(-1, 2))
+                       for k in lnprior_ext.keys()]
             for out in self._fit_device_post(
-                    eng, params, step, data, data_err, data_mask, parallax,
+                    eng, params, step_device, data, data_err, data_mask, parallax,
                     parallax_err, data_coords, lnprior, lngalprior, dlabels,
                     Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim, rvlim,
                     mem_lim, return_distreds, rstate,
                     seed0 if (philox_per_object or (not philox and np_mode == "per_object")) else None,
-                    np_mode=None if philox else np_mode, dust_tables=dust_tables):
+                    np_mode=None if philox else np_mode, dust_tables=dust_tables, ext=ext):
                 yield out
             return
         pool = None
@@ -1394,7 +1416,7 @@ class BruteForce(object):
                          parallax, parallax_err, data_coords, lnprior, lngalprior,
                          dlabels, Nmc_prior, wt_thresh, cdf_thresh, Ndraws, avlim,
                          rvlim, mem_lim, return_distreds, rstate, seed0, np_mode=None,
-                         dust_tables=None):
+                         dust_tables=None, ext=None):
         """`_fit` with `lnpost` and the resampling on the device
         (`brutus_post_batch`): built-in priors, Philox random stream.  Yields
         exactly what the host stage yields for the same `rstate` -- one shared
@@ -1463,16 +1485,18 @@ class BruteForce(object):
             b = min(Ndata, a + step)
             en = engines[k % nE]
             with torch.cuda.device(dev):
+                # (external label constraints of the batch's objects: the full-grid route)
+                ext_b = None if ext is None else [(t, v[a:b, 0], v[a:b, 1]) for t, v in ext]
                 if streams[k % nE] is None:
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
-                    out = en.records_device(f, e, m, p, pe, hp, params)
+                    out = en.records_device(f, e, m, p, pe, hp, params, ext=ext_b)
                     out[0].fill_rv()
                     return out
                 with torch.cuda.stream(streams[k % nE]):
                     f, e, m, p, pe, hp = en._upload(data[a:b], data_err[a:b], data_mask[a:b],
                                                     parallax[a:b], parallax_err[a:b])
-                    out = en.records_device(f, e, m, p, pe, hp, params)
+                    out = en.records_device(f, e, m, p, pe, hp, params, ext=ext_b)
                     out[0].fill_rv()
                     streams[k % nE].synchronize()
                     return out

@@ -481,6 +481,54 @@ def test_device_lnpost_vs_reference_golden():
     assert (rs.n_normal, rs.n_uniform) == (int(z["n_normal"]), int(z["n_uniform"]))
 
 
+@pytest.mark.parametrize("stream", ["philox", "numpy"])
+def test_lnprior_ext_on_the_device_vs_oracle(stream):
+    """`lnprior_ext` with the built-in priors: the constraints are added to lnlike over the whole
+    grid ON THE DEVICE (full-grid pipeline), the cut and `lnpost` follow there -- against the oracle
+    assembled the way the reference's star loop does (fitting.py:1995-2012), same stream: resampled
+    indices bit-exact.  Two label columns, a NaN mean and a zero width (both skipped), two batches."""
+    from scipy.special import logsumexp
+    from brutus_amd.galprior import gal_lnprior
+    from brutus_amd.rng import PhiloxRandomState
+    from oracle import brutus_oracle as O
+    BF, models, labels, st, lnprior = _setup(nmodel=5000, nstar=6, seed=53)
+    BF.batch_size = 4
+    ext = {"feh": np.array([[-0.3, 0.2], [np.nan, 0.2], [0.1, 0.0], [-1.0, 0.5], [0.2, 0.3], [-0.5, 0.1]]),
+           "loga": np.array([[9.5, 0.3], [9.0, 0.2], [np.nan, 1.0], [9.8, 0.05], [8.7, 0.4], [9.2, 0.0]])}
+    mk = (lambda: PhiloxRandomState(5)) if stream == "philox" else (lambda: np.random.RandomState(5))
+    rs = mk()
+    dev = list(BF._fit(st["flux"], st["err"], st["mask"], parallax=st["parallax"],
+                       parallax_err=st["parallax_err"], Nmc_prior=15, lnprior=lnprior,
+                       lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=30,
+                       lnprior_ext=ext, rstate=rs))
+    ro = mk()
+    for i in range(6):
+        par, perr = st["parallax"][i], st["parallax_err"][i]
+        res = list(O.loglike(st["flux"][i], st["err"][i], st["mask"][i], models,
+                             av_gauss=(0., 1e6), parallax=par, parallax_err=perr,
+                             return_vals=True))
+        for k in ("feh", "loga"):
+            mean, std = ext[k][i]
+            if np.isfinite(mean) and std > 0:
+                res[0] = res[0] - 0.5 * ((labels[k] - mean) ** 2 * (1. / std ** 2)
+                                         + np.log(2. * np.pi * std ** 2))
+        sel, cov, lnp, dists, reds, dreds, logwts = O.lnpost(
+            tuple(res), parallax=par, parallax_err=perr, coord=st["coords"][i],
+            Nmc_prior=15, lnprior=lnprior, wt_thresh=1e-3, lngalprior=gal_lnprior,
+            lndustprior=None, dlabels=labels, avlim=(0., 20.), rvlim=(1., 8.), rstate=ro,
+            apply_av_prior=False, mem_lim=8000.)
+        wt = np.exp(lnp - logsumexp(lnp))
+        wt /= wt.sum()
+        idxs = ro.choice(len(sel), size=30, p=wt)
+        assert np.array_equal(dev[i][0], sel[idxs]), i
+        assert relerr(lnp[idxs], dev[i][6]) < 1e-8
+        # (the oracle's stream has to take the second resampling stage too, like the device did)
+        for j, idx in enumerate(idxs):
+            w = np.exp(logwts[idx] - logsumexp(logwts[idx]))
+            w /= w.sum()
+            ro.choice(15, p=w)
+
+
 def test_lnprior_ext_vs_oracle():
     """External per-object Gaussian label constraints (fitting.py:1993-2009): the
     full-grid device outputs + host cut, against the oracle pieces assembled the
