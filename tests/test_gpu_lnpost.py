@@ -234,20 +234,20 @@ def test_fit_writes_whole_batches_like_rows(tmp_path, stream):
     mk = (lambda: PhiloxRandomState(5)) if stream == "philox" else (lambda: np.random.RandomState(5))
     kw = dict(parallax=st["parallax"], parallax_err=st["parallax_err"], Nmc_prior=20,
               lngalprior=gal_lnprior, data_coords=st["coords"], Ndraws=60)
-    for rio in (True, False):
-        path = os.path.join(str(tmp_path), "blk_%s_%d" % (stream, rio))
+    for rio, dar in ((True, True), (False, True), (True, False)):
+        path = os.path.join(str(tmp_path), "blk_%s_%d_%d" % (stream, rio, dar))
         BF.fit(st["flux"], st["err"], st["mask"], np.arange(n), path, rstate=mk(), verbose=False,
-               running_io=rio, **kw)
+               running_io=rio, save_dar_draws=dar, **kw)
         assert BF._yield_row_blocks is False
-        ref = h5io.ResultsFile(path + "_rows.h5", n, 60, np.arange(n), True, running_io=rio)
+        ref = h5io.ResultsFile(path + "_rows.h5", n, 60, np.arange(n), dar, running_io=rio)
         (d, e, m, _, coords, lnp_, lng, lnd, avg, wt, _) = BF._setup(
             st["flux"], st["err"], st["mask"], np.arange(n), parallax=st["parallax"],
             parallax_err=st["parallax_err"], data_coords=st["coords"], lngalprior=gal_lnprior)
         for i, row in enumerate(BF._fit(d, e, m, parallax=st["parallax"], parallax_err=st["parallax_err"],
                                         lnprior=lnp_, lngalprior=lng, lndustprior=lnd, av_gauss=avg,
                                         wt_thresh=wt, data_coords=coords, Nmc_prior=20, Ndraws=60,
-                                        rstate=mk())):
-            assert isinstance(row, tuple) and len(row) == 13
+                                        return_distreds=dar, rstate=mk())):
+            assert isinstance(row, tuple) and len(row) == (13 if dar else 9)
             ref.write_row(i, row)
         ref.close()
         for k in h5io.list_datasets(path + ".h5"):
