@@ -16,7 +16,7 @@ for kind in ("sharp", "broad"):
         models, labels, lmask = synth.make_mist_like_grid(750000, 12)
         st = synth.make_stars(models, 2048, seed=4242, with_parallax=True)
     bf = fitting.BruteForce(models, labels, lmask)
-    for bs in (128, 256):
+    for bs in (int(x) for x in (sys.argv[1] if len(sys.argv) > 1 else "128,256").split(",")):
         bf.batch_size = bs
         for rep in range(2):
             with tempfile.TemporaryDirectory() as tmp:
